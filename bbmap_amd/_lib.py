@@ -1,0 +1,77 @@
+"""ctypes binding of libbbmap_amd.so (the C ABI declared in include/bbmap_amd.h).
+
+There is no fallback: if the shared library is missing, loading raises; if no gfx950 device is
+present, bbmsa_create() returns BBMAP_E_NODEVICE and the wrappers raise.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libbbmap_amd.so")
+
+# every symbol include/bbmap_amd.h declares
+EXPORTS = [
+    "bbmap_last_error", "bbmap_abi_version",
+    "bbmsa_create", "bbmsa_destroy", "bbmsa_align_batch_device", "bbmsa_align_batch",
+    "bbmsa_last_kernel_ms",
+]
+
+
+class bbmsa_job(C.Structure):
+    _fields_ = [("read_off", C.c_int64), ("ref_off", C.c_int64),
+                ("read_len", C.c_int32), ("ref_len", C.c_int32),
+                ("refStartLoc", C.c_int32), ("refEndLoc", C.c_int32),
+                ("minScore", C.c_int32), ("flags", C.c_int32)]
+
+
+class bbmsa_result(C.Structure):
+    _fields_ = [("result", C.c_int32 * 5), ("status", C.c_int32), ("iterations", C.c_int64),
+                ("score", C.c_int32 * 8), ("score_len", C.c_int32), ("match_len", C.c_int32),
+                ("fill_kind", C.c_int32), ("columns", C.c_int32)]
+
+
+class bbmsa_config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("maxRows", C.c_int32), ("maxColumns", C.c_int32),
+                ("bandwidth", C.c_int32), ("bandwidthRatio", C.c_float), ("reserved", C.c_int32 * 3)]
+
+
+assert C.sizeof(bbmsa_job) == 40 and C.sizeof(bbmsa_result) == 80
+
+_lib = None
+
+
+class BBMapAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise BBMapAmdError(
+            "libbbmap_amd.so is missing (%s). Build it with `python -m bbmap_amd.build`; "
+            "there is no CPU fallback." % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    L.bbmap_last_error.restype = C.c_char_p
+    L.bbmap_abi_version.restype = C.c_int
+    L.bbmsa_create.argtypes = [C.POINTER(bbmsa_config), C.POINTER(C.c_void_p)]
+    L.bbmsa_create.restype = C.c_int
+    L.bbmsa_destroy.argtypes = [C.c_void_p]
+    L.bbmsa_destroy.restype = None
+    L.bbmsa_align_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    L.bbmsa_align_batch_device.restype = C.c_int
+    L.bbmsa_align_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
+    L.bbmsa_align_batch.restype = C.c_int
+    L.bbmsa_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.bbmsa_last_kernel_ms.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise BBMapAmdError("%s failed (%d): %s" % (what, rc, load().bbmap_last_error().decode()))

@@ -1,0 +1,95 @@
+// Shared constants/types for the MultiStateAligner11ts HIP kernels (gfx950).
+// Score/time cell encoding and point values follow jni/MultiStateAligner11tsJNI.c:18-98.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bbmap_amd.h"
+
+namespace bbmsa {
+
+constexpr int kScoreOffset = 11;
+constexpr int kTimeMask = 0x7FF;
+constexpr int kScoreMask = (int)0xFFFFF800;
+constexpr int kMaxTime = 2047;
+
+#define BBMSA_PT(x) ((x) * 2048)
+constexpr int P_MATCH = BBMSA_PT(70), P_MATCH2 = BBMSA_PT(100);
+constexpr int P_SUB = BBMSA_PT(-127), P_SUBR = BBMSA_PT(-147), P_SUB2 = BBMSA_PT(-51), P_SUB3 = BBMSA_PT(-25);
+constexpr int P_INS = BBMSA_PT(-395), P_INS2 = BBMSA_PT(-39), P_INS3 = BBMSA_PT(-23), P_INS4 = BBMSA_PT(-8);
+constexpr int P_DEL = BBMSA_PT(-472), P_DEL2 = BBMSA_PT(-33), P_DEL3 = BBMSA_PT(-9), P_DEL4 = BBMSA_PT(-1),
+              P_DEL5 = BBMSA_PT(-1);
+constexpr int P_DEL_REF_N = BBMSA_PT(-10), P_GAP = BBMSA_PT(-2);
+constexpr int kBadOff = (-(((1 << 20) - 1) - 2000) - 1) * 2048;   // BADoff
+constexpr int kMinOffScore = (-(((1 << 20) - 1) - 2000)) * 2048;  // MINoff_SCORE
+constexpr int kNegInf = -(1 << 30);   // "no limit" for the unlimited fill; never reached by any score
+constexpr int kGapLen = 128;
+
+constexpr int kTableLen = 1024;       // delC / insC LDS tables
+
+// closed forms of calcDelScoreOffset (jni/...c:316-336) and of the cumulative
+// POINTSoff_INS_ARRAY_C table (MultiStateAligner11tsJNI.java:1582-1601)
+__host__ __device__ inline int calc_del_off(int len) {
+    if (len <= 0) return 0;
+    int s = P_DEL;
+    if (len > 80) { s += ((len - 80 + 3) / 4) * P_DEL5; len = 80; }
+    if (len > 20) { s += (len - 20) * P_DEL4; len = 20; }
+    if (len > 5) { s += (len - 5) * P_DEL3; len = 5; }
+    if (len > 1) s += (len - 1) * P_DEL2;
+    return s;
+}
+__host__ __device__ inline int calc_ins_cum_off(int len) {
+    if (len <= 0) return 0;
+    long long s = P_INS;
+    int n = len;
+    if (n > 20) { s += (long long)(n - 20) * P_INS4; n = 20; }
+    if (n > 5) { s += (long long)(n - 5) * P_INS3; n = 5; }
+    if (n > 1) s += (long long)(n - 1) * P_INS2;
+    return s < kMinOffScore ? kMinOffScore : (int)s;
+}
+
+// dna/AminoAcid.java:614-624 + :365-367: A,C,G,T,U in either case are "fully defined".
+__host__ __device__ inline bool fully_defined(int b) {
+    const int u = b & ~32;   // fold case
+    return b < 128 && (u == 'A' || u == 'C' || u == 'G' || u == 'T' || u == 'U');
+}
+
+struct FillParams {
+    const bbmsa_job *jobs;
+    const uint8_t *reads;
+    const uint8_t *refs;
+    bbmsa_result *results;
+    uint8_t *match;
+    long long njobs;
+    unsigned int *queue;          // work-queue head (zeroed before launch)
+    unsigned int *dirbuf;         // traceback direction nibbles, one slot per resident job
+    long long dir_slot_dwords;
+    int *slow_list;               // jobs the fast kernel hands to the generic kernel
+    unsigned int *slow_count;
+    int match_stride;
+    int lanesPerJob;              // 16, 32 or 64
+    int fastCols;                 // LDS capacity (columns) per job in the fast kernel
+    int tmpBytes;                 // LDS bytes per job for the reversed match string
+    int maxRows, maxColumns;      // context limits (MSA(maxRows_, maxColumns_))
+    int bandwidth;
+    float bandwidthRatio;
+};
+
+struct GenericParams {
+    const bbmsa_job *jobs;
+    const uint8_t *reads;
+    const uint8_t *refs;
+    bbmsa_result *results;
+    uint8_t *match;
+    const int *list;              // job indices to process (NULL = all)
+    const unsigned int *list_count;
+    long long njobs;
+    int *matrix;                  // per-thread-slot 3*(maxRows+1)*(maxColumns+1) ints
+    int *limits;                  // per-thread-slot vertLimit/horizLimit
+    unsigned int *queue;
+    int match_stride;
+    int maxRows, maxColumns;
+    int bandwidth;
+    float bandwidthRatio;
+};
+
+}  // namespace bbmsa

@@ -1,0 +1,250 @@
+// Host side of the MultiStateAligner11ts C ABI (include/bbmap_amd.h): context, scratch sizing,
+// launch geometry and the two launches (wavefront kernel, then the generic kernel over the jobs
+// it handed back).  No CPU compute path exists here: without a HIP device every entry fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "msa_common.h"
+
+namespace bbmsa {
+const void *fast_kernel_for(int R);
+__global__ void msa_fill_generic_kernel(const GenericParams p);
+}  // namespace bbmsa
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, const char *detail = "") {
+    snprintf(g_err, sizeof g_err, fmt, detail);
+    return code;
+}
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            snprintf(g_err, sizeof g_err, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+            return BBMAP_E_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+struct bbmsa_ctx {
+    bbmsa_config cfg;
+    int device;
+    int numCUs;
+    // fast kernel geometry
+    int G, R, fastCols, tmpBytes, blocks, ldsBytes;
+    long long dirSlotDwords;
+    unsigned int *d_dir;
+    unsigned int *d_counters;   // [0]=fast queue, [1]=slow count, [2]=generic queue
+    int *d_slowList;
+    long long slowCap;
+    // generic kernel
+    int genThreads;
+    int *d_matrix;
+    int *d_limits;
+    hipEvent_t ev[3];
+    bool timed;
+};
+
+extern "C" const char *bbmap_last_error(void) { return g_err; }
+extern "C" int bbmap_abi_version(void) { return BBMAP_AMD_ABI_VERSION; }
+
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
+    if (!cfg || !out) return fail(BBMAP_E_ARG, "bbmsa_create: null argument");
+    *out = nullptr;
+    if (cfg->maxRows < 1 || cfg->maxRows > 640 || cfg->maxColumns < 1 || cfg->maxColumns > 4096)
+        return fail(BBMAP_E_ARG, "bbmsa_create: maxRows must be 1..640 and maxColumns 1..4096");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(BBMAP_E_NODEVICE, "bbmsa_create: no HIP device (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(BBMAP_E_ARG, "bbmsa_create: bad device ordinal");
+    HIP_TRY(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(BBMAP_E_NODEVICE, "bbmsa_create: device is %s, this build targets gfx950 only", prop.gcnArchName);
+
+    bbmsa_ctx *c = new (std::nothrow) bbmsa_ctx();
+    if (!c) return fail(BBMAP_E_NOMEM, "bbmsa_create: out of host memory");
+    memset(c, 0, sizeof *c);
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    c->numCUs = prop.multiProcessorCount;
+
+    // lanes per job / rows per lane: smallest lane group whose <=10 rows per lane cover maxRows
+    int G = cfg->reserved[0];
+    if (G != 16 && G != 32 && G != 64) {
+        G = env_int("BBMSA_LANES_PER_JOB", 0);
+        if (G != 16 && G != 32 && G != 64) G = (cfg->maxRows <= 320) ? 32 : 64;
+    }
+    while (G < 64 && (cfg->maxRows + G - 1) / G > 10) G *= 2;
+    c->G = G;
+    c->R = (cfg->maxRows + G - 1) / G;
+    int fastCols = cfg->reserved[1] > 0 ? cfg->reserved[1] : env_int("BBMSA_FAST_COLS", 0);
+    if (fastCols <= 0) fastCols = cfg->maxColumns < 640 ? cfg->maxColumns : 640;
+    if (fastCols > cfg->maxColumns) fastCols = cfg->maxColumns;
+    c->fastCols = fastCols;
+    c->tmpBytes = ((G * c->R + fastCols + 8) + 3) & ~3;
+    const int jobsPerWave = 64 / G;
+    const int perJobInts = (fastCols + 2) * 2 + c->tmpBytes / 4;
+    c->ldsBytes = (2 * bbmsa::kTableLen + 4 * jobsPerWave * perJobInts) * 4;
+    if (c->ldsBytes > 160 * 1024) { delete c; return fail(BBMAP_E_ARG, "bbmsa_create: fast-path LDS budget exceeded; lower reserved[1] (fastCols)"); }
+
+    const void *kfn = bbmsa::fast_kernel_for(c->R);
+    if (!kfn) { delete c; return fail(BBMAP_E_ARG, "bbmsa_create: no kernel for this rows-per-lane"); }
+    if (c->ldsBytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, c->ldsBytes));
+    int blocksPerCU = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocksPerCU, kfn, 256, c->ldsBytes));
+    if (blocksPerCU < 1) blocksPerCU = 1;
+    const int capBlocks = env_int("BBMSA_BLOCKS_PER_CU", 0);
+    if (capBlocks > 0 && capBlocks < blocksPerCU) blocksPerCU = capBlocks;
+    c->blocks = c->numCUs * blocksPerCU;
+
+    const int maxSteps = fastCols + G - 1;
+    c->dirSlotDwords = (long long)((maxSteps >> 3) + 1) * c->R * G;
+    const long long slots = (long long)c->blocks * 4 * jobsPerWave;
+    HIP_TRY(hipMalloc(&c->d_dir, (size_t)(slots * c->dirSlotDwords * 4)));
+    HIP_TRY(hipMalloc(&c->d_counters, 64));
+    HIP_TRY(hipMemset(c->d_counters, 0, 64));
+
+    // generic kernel scratch: as many threads as a 2 GiB matrix budget allows (at least one wave)
+    const long long planeInts = (long long)(cfg->maxRows + 1) * (cfg->maxColumns + 2);
+    const long long perThread = 3 * planeInts * 4;
+    long long budget = (long long)env_int("BBMSA_GENERIC_SCRATCH_MB", 2048) << 20;
+    long long threads = budget / perThread;
+    if (threads > 16384) threads = 16384;
+    threads = (threads / 64) * 64;
+    if (threads < 64) threads = 64;
+    c->genThreads = (int)threads;
+    HIP_TRY(hipMalloc(&c->d_matrix, (size_t)(threads * perThread)));
+    HIP_TRY(hipMalloc(&c->d_limits, (size_t)(threads * (cfg->maxRows + cfg->maxColumns + 4) * 4)));
+    for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+    *out = c;
+    return BBMAP_OK;
+}
+
+extern "C" void bbmsa_destroy(bbmsa_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_dir) (void)hipFree(c->d_dir);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_slowList) (void)hipFree(c->d_slowList);
+    if (c->d_matrix) (void)hipFree(c->d_matrix);
+    if (c->d_limits) (void)hipFree(c->d_limits);
+    for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+}
+
+extern "C" int bbmsa_align_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_jobs,
+                                        const bbmsa_job *jobs, const uint8_t *reads, const uint8_t *refs,
+                                        bbmsa_result *results, uint8_t *match, int32_t match_stride) {
+    if (!c) return fail(BBMAP_E_ARG, "bbmsa_align_batch_device: null context");
+    if (n_jobs < 0 || n_jobs > 0x7fffffffLL) return fail(BBMAP_E_ARG, "bbmsa_align_batch_device: n_jobs out of range");
+    if (n_jobs == 0) return BBMAP_OK;
+    if (!jobs || !reads || !refs || !results) return fail(BBMAP_E_ARG, "bbmsa_align_batch_device: null buffer");
+    if (match && match_stride < 1) return fail(BBMAP_E_ARG, "bbmsa_align_batch_device: match_stride must be positive");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(c->device));
+    if (n_jobs > c->slowCap) {
+        if (c->d_slowList) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_slowList)); c->d_slowList = nullptr; }
+        HIP_TRY(hipMalloc(&c->d_slowList, (size_t)n_jobs * 4));
+        c->slowCap = n_jobs;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 64, stream));
+
+    bbmsa::FillParams fp;
+    fp.jobs = jobs; fp.reads = reads; fp.refs = refs; fp.results = results; fp.match = match;
+    fp.njobs = n_jobs;
+    fp.queue = c->d_counters; fp.dirbuf = c->d_dir; fp.dir_slot_dwords = c->dirSlotDwords;
+    fp.slow_list = c->d_slowList; fp.slow_count = c->d_counters + 1;
+    fp.match_stride = match_stride; fp.lanesPerJob = c->G; fp.fastCols = c->fastCols; fp.tmpBytes = c->tmpBytes;
+    fp.maxRows = c->cfg.maxRows; fp.maxColumns = c->cfg.maxColumns;
+    fp.bandwidth = c->cfg.bandwidth; fp.bandwidthRatio = c->cfg.bandwidthRatio;
+
+    const int jobsPerBlock = 4 * (64 / c->G);
+    long long blocks = (n_jobs + jobsPerBlock - 1) / jobsPerBlock;
+    if (blocks > c->blocks) blocks = c->blocks;
+    void *args[] = {&fp};
+    HIP_TRY(hipEventRecord(c->ev[0], stream));
+    HIP_TRY(hipLaunchKernel(bbmsa::fast_kernel_for(c->R), dim3((unsigned)blocks), dim3(256), args, (size_t)c->ldsBytes, stream));
+    HIP_TRY(hipEventRecord(c->ev[1], stream));
+
+    bbmsa::GenericParams gp;
+    gp.jobs = jobs; gp.reads = reads; gp.refs = refs; gp.results = results; gp.match = match;
+    gp.list = c->d_slowList; gp.list_count = c->d_counters + 1; gp.njobs = n_jobs;
+    gp.matrix = c->d_matrix; gp.limits = c->d_limits; gp.queue = c->d_counters + 2;
+    gp.match_stride = match_stride; gp.maxRows = c->cfg.maxRows; gp.maxColumns = c->cfg.maxColumns;
+    gp.bandwidth = c->cfg.bandwidth; gp.bandwidthRatio = c->cfg.bandwidthRatio;
+    hipLaunchKernelGGL(bbmsa::msa_fill_generic_kernel, dim3(c->genThreads / 64), dim3(64), 0, stream, gp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[2], stream));
+    c->timed = true;
+    return BBMAP_OK;
+}
+
+extern "C" int bbmsa_last_kernel_ms(bbmsa_ctx *c, float *ms_fast, float *ms_slow) {
+    if (!c || !c->timed) return fail(BBMAP_E_ARG, "bbmsa_last_kernel_ms: nothing launched yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[2]));
+    float a = 0, b = 0;
+    HIP_TRY(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+    if (ms_fast) *ms_fast = a;
+    if (ms_slow) *ms_slow = b;
+    return BBMAP_OK;
+}
+
+extern "C" int bbmsa_align_batch(bbmsa_ctx *c, int64_t n_jobs, const bbmsa_job *jobs,
+                                 const uint8_t *reads, int64_t reads_bytes,
+                                 const uint8_t *refs, int64_t refs_bytes,
+                                 bbmsa_result *results, uint8_t *match, int32_t match_stride) {
+    if (!c) return fail(BBMAP_E_ARG, "bbmsa_align_batch: null context");
+    if (n_jobs == 0) return BBMAP_OK;
+    if (n_jobs < 0 || !jobs || !reads || !refs || !results || reads_bytes < 0 || refs_bytes < 0)
+        return fail(BBMAP_E_ARG, "bbmsa_align_batch: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    // every job must stay inside the buffers it was given
+    for (int64_t i = 0; i < n_jobs; i++) {
+        const bbmsa_job &j = jobs[i];
+        if (j.read_len < 0 || j.read_off < 0 || j.read_off + j.read_len > reads_bytes)
+            return fail(BBMAP_E_ARG, "bbmsa_align_batch: a read lies outside the reads buffer");
+        if (j.ref_len < 0 || j.ref_off < 0 || j.ref_off + j.ref_len > refs_bytes)
+            return fail(BBMAP_E_ARG, "bbmsa_align_batch: a reference array lies outside the refs buffer");
+        if (!(j.flags & BBMSA_CLAMP_WINDOW) && (j.refStartLoc < 0 || j.refEndLoc >= j.ref_len))
+            return fail(BBMAP_E_ARG, "bbmsa_align_batch: window outside its reference array (set BBMSA_CLAMP_WINDOW to clamp)");
+    }
+    bbmsa_job *d_jobs = nullptr; uint8_t *d_reads = nullptr, *d_refs = nullptr, *d_match = nullptr; bbmsa_result *d_res = nullptr;
+    int rc = BBMAP_OK;
+#define TRY_GOTO(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(g_err, sizeof g_err, "%s failed: %s", #expr, hipGetErrorString(e_)); rc = BBMAP_E_HIP; goto done; } } while (0)
+    TRY_GOTO(hipMalloc(&d_jobs, (size_t)n_jobs * sizeof(bbmsa_job)));
+    TRY_GOTO(hipMalloc(&d_reads, (size_t)(reads_bytes > 0 ? reads_bytes : 1)));
+    TRY_GOTO(hipMalloc(&d_refs, (size_t)(refs_bytes > 0 ? refs_bytes : 1)));
+    TRY_GOTO(hipMalloc(&d_res, (size_t)n_jobs * sizeof(bbmsa_result)));
+    if (match) TRY_GOTO(hipMalloc(&d_match, (size_t)n_jobs * (size_t)match_stride));
+    TRY_GOTO(hipMemcpy(d_jobs, jobs, (size_t)n_jobs * sizeof(bbmsa_job), hipMemcpyHostToDevice));
+    TRY_GOTO(hipMemcpy(d_reads, reads, (size_t)reads_bytes, hipMemcpyHostToDevice));
+    TRY_GOTO(hipMemcpy(d_refs, refs, (size_t)refs_bytes, hipMemcpyHostToDevice));
+    TRY_GOTO(hipMemset(d_res, 0xff, (size_t)n_jobs * sizeof(bbmsa_result)));
+    rc = bbmsa_align_batch_device(c, nullptr, n_jobs, d_jobs, d_reads, d_refs, d_res, d_match, match_stride);
+    if (rc != BBMAP_OK) goto done;
+    TRY_GOTO(hipStreamSynchronize(nullptr));
+    TRY_GOTO(hipMemcpy(results, d_res, (size_t)n_jobs * sizeof(bbmsa_result), hipMemcpyDeviceToHost));
+    if (match) TRY_GOTO(hipMemcpy(match, d_match, (size_t)n_jobs * (size_t)match_stride, hipMemcpyDeviceToHost));
+done:
+    if (d_jobs) (void)hipFree(d_jobs);
+    if (d_reads) (void)hipFree(d_reads);
+    if (d_refs) (void)hipFree(d_refs);
+    if (d_res) (void)hipFree(d_res);
+    if (d_match) (void)hipFree(d_match);
+    return rc;
+#undef TRY_GOTO
+}

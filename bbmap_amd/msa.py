@@ -1,0 +1,160 @@
+"""Python binding of the batched MultiStateAligner11ts C ABI (tests / bench plumbing).
+
+Mirrors the call shapes of align2.MSA (current/align2/MSA.java:70-144) but batched: every method
+takes lists of problems and issues ONE bbmsa_align_batch call.  All compute happens in the HIP
+library; nothing here touches the oracle.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import bbmsa_config, bbmsa_job, bbmsa_result
+
+FILL_LIMITED_RAW = 0
+FILL_UNLIMITED_RAW = 1
+FILL_LIMITED = 2
+CLAMP_WINDOW = 1 << 3
+DO_SCORE = 1 << 4
+DO_TRACEBACK = 1 << 5
+FILL_AND_SCORE_LIMITED = FILL_LIMITED | CLAMP_WINDOW | DO_SCORE
+
+ST_OK, ST_NULL, ST_BAD_SHAPE = 0, 1, 2
+
+JOB_DTYPE = np.dtype([("read_off", "<i8"), ("ref_off", "<i8"), ("read_len", "<i4"), ("ref_len", "<i4"),
+                      ("refStartLoc", "<i4"), ("refEndLoc", "<i4"), ("minScore", "<i4"), ("flags", "<i4")])
+RESULT_DTYPE = np.dtype([("result", "<i4", (5,)), ("status", "<i4"), ("iterations", "<i8"),
+                         ("score", "<i4", (8,)), ("score_len", "<i4"), ("match_len", "<i4"),
+                         ("fill_kind", "<i4"), ("columns", "<i4")])
+assert JOB_DTYPE.itemsize == C.sizeof(bbmsa_job) and RESULT_DTYPE.itemsize == C.sizeof(bbmsa_result)
+
+
+class MSAContext:
+    """Owns a bbmsa_ctx (one per device and per (maxRows, maxColumns, band) setting)."""
+
+    def __init__(self, maxRows=601, maxColumns=3000, bandwidth=0, bandwidthRatio=0.0, device=0,
+                 lanes_per_job=0, fast_cols=0):
+        self.L = _lib.load()
+        cfg = bbmsa_config()
+        cfg.device, cfg.maxRows, cfg.maxColumns = device, maxRows, maxColumns
+        cfg.bandwidth, cfg.bandwidthRatio = bandwidth, bandwidthRatio
+        cfg.reserved[0], cfg.reserved[1], cfg.reserved[2] = lanes_per_job, fast_cols, 0
+        h = C.c_void_p()
+        _lib.check(self.L.bbmsa_create(C.byref(cfg), C.byref(h)), "bbmsa_create")
+        self.h = h
+        self.maxRows, self.maxColumns = maxRows, maxColumns
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bbmsa_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host buffers -------------------------------------------------------------------
+    def align_batch(self, jobs, reads, refs, match_stride=0):
+        """jobs: structured array (JOB_DTYPE); reads/refs: uint8 arrays.  Returns (results, match)."""
+        jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        refs = np.ascontiguousarray(refs, dtype=np.uint8)
+        n = len(jobs)
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        match = np.zeros((n, match_stride), np.uint8) if match_stride > 0 else None
+        rc = self.L.bbmsa_align_batch(self.h, n, jobs.ctypes.data, reads.ctypes.data, reads.size,
+                                      refs.ctypes.data, refs.size, res.ctypes.data,
+                                      match.ctypes.data if match is not None else None, match_stride)
+        _lib.check(rc, "bbmsa_align_batch")
+        return res, match
+
+    # -- device buffers (torch tensors or raw pointers) --------------------------------------
+    def align_batch_device(self, n_jobs, jobs_ptr, reads_ptr, refs_ptr, results_ptr, match_ptr=0,
+                           match_stride=0, stream=0):
+        rc = self.L.bbmsa_align_batch_device(self.h, C.c_void_p(stream), n_jobs, C.c_void_p(jobs_ptr),
+                                             C.c_void_p(reads_ptr), C.c_void_p(refs_ptr),
+                                             C.c_void_p(results_ptr),
+                                             C.c_void_p(match_ptr) if match_ptr else None, match_stride)
+        _lib.check(rc, "bbmsa_align_batch_device")
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(), C.c_float()
+        _lib.check(self.L.bbmsa_last_kernel_ms(self.h, C.byref(a), C.byref(b)), "bbmsa_last_kernel_ms")
+        return a.value, b.value
+
+
+def pack_problems(problems, flags):
+    """problems: iterable of (read_bytes, ref_bytes, refStartLoc, refEndLoc, minScore).
+    Packs them into (jobs, reads_blob, refs_blob); identical ref objects are stored once."""
+    reads, refs, jobs = bytearray(), bytearray(), []
+    ref_cache = {}
+    for k, (read, ref, a, b, ms) in enumerate(problems):
+        ro = len(reads)
+        reads += bytes(read)
+        key = id(ref)
+        if key not in ref_cache:
+            ref_cache[key] = len(refs)
+            refs += bytes(ref)
+        fo = ref_cache[key]
+        fl = flags[k] if isinstance(flags, (list, tuple, np.ndarray)) else flags
+        jobs.append((ro, fo, len(read), len(ref), a, b, ms, fl))
+    jobs = np.array(jobs, dtype=JOB_DTYPE) if jobs else np.zeros(0, JOB_DTYPE)
+    return jobs, np.frombuffer(bytes(reads) or b"\0", np.uint8), np.frombuffer(bytes(refs) or b"\0", np.uint8)
+
+
+class MultiStateAligner11ts:
+    """Batched mirror of align2.MultiStateAligner11tsJNI's public methods."""
+
+    def __init__(self, maxRows=601, maxColumns=3000, bandwidth=0, bandwidthRatio=0.0, device=0, **kw):
+        self.ctx = MSAContext(maxRows, maxColumns, bandwidth, bandwidthRatio, device, **kw)
+        self.maxRows, self.maxColumns = maxRows, maxColumns
+        self.iterationsLimited = 0
+        self.iterationsUnlimited = 0
+
+    def _run(self, problems, flags, want_match=False):
+        problems = list(problems)
+        jobs, reads, refs = pack_problems(problems, flags)
+        stride = 0
+        if want_match and problems:
+            stride = max(len(p[0]) + (p[3] - p[2] + 1) + 8 for p in problems)
+            stride = (stride + 15) & ~15
+        res, match = self.ctx.align_batch(jobs, reads, refs, stride)
+        for r in res:
+            if r["status"] == ST_BAD_SHAPE:
+                raise ValueError("alignment exceeds maxRows/maxColumns of this aligner")
+            if r["fill_kind"] == 0:
+                self.iterationsLimited += int(r["iterations"])
+            else:
+                self.iterationsUnlimited += int(r["iterations"])
+        return res, match
+
+    # MultiStateAligner11tsJNI.java:116-164 (gaps==null)
+    def fillLimited(self, problems):
+        res, _ = self._run(problems, FILL_LIMITED)
+        return [None if r["status"] == ST_NULL else r["result"][:4].tolist() for r in res]
+
+    # :166-192
+    def fillUnlimited(self, problems):
+        res, _ = self._run([(p[0], p[1], p[2], p[3], 0) for p in problems], FILL_UNLIMITED_RAW)
+        return [r["result"][:4].tolist() for r in res]
+
+    # MSA.java:103-134 (gaps==null); returns score vectors (or None)
+    def fillAndScoreLimited(self, problems):
+        res, _ = self._run(problems, FILL_AND_SCORE_LIMITED)
+        return [None if r["score_len"] == 0 else r["score"][:r["score_len"]].tolist() for r in res]
+
+    # fillLimited + score + traceback in one launch
+    def align(self, problems, flags=FILL_AND_SCORE_LIMITED | DO_TRACEBACK):
+        res, match = self._run(problems, flags, want_match=True)
+        out = []
+        for k, r in enumerate(res):
+            ms = None
+            if r["match_len"] > 0:
+                ms = match[k, :r["match_len"]].tobytes()
+            out.append({"result": r["result"].tolist(), "status": int(r["status"]),
+                        "iterations": int(r["iterations"]),
+                        "score": None if r["score_len"] == 0 else r["score"][:r["score_len"]].tolist(),
+                        "match": ms, "fill_kind": int(r["fill_kind"]), "columns": int(r["columns"])})
+        return out

@@ -1,0 +1,123 @@
+/*
+ * bbmap_amd.h -- C ABI of libbbmap_amd.so, the MI355X (gfx950) replacement for the
+ * native side of BBMap's `usejni=t` seed-and-extend path.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Every entry point names the
+ * reference interface it replaces (paths relative to the reference checkout).
+ * Return convention: 0 = ok, <0 = error (see BBMAP_E_*); the library never calls exit()
+ * (the reference's native code does: jni/MultiStateAligner11tsJNI.c:130-132).
+ *
+ * The library REQUIRES a HIP device: there is no CPU fallback.  bbmsa_create() fails with
+ * BBMAP_E_NODEVICE when no gfx950 device is usable.
+ */
+#ifndef BBMAP_AMD_H
+#define BBMAP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBMAP_AMD_ABI_VERSION 1
+
+enum {
+    BBMAP_OK = 0,
+    BBMAP_E_NODEVICE = -1,   /* no HIP device / wrong architecture */
+    BBMAP_E_ARG = -2,        /* bad argument (null pointer, negative size, shape beyond limits) */
+    BBMAP_E_NOMEM = -3,      /* device or host allocation failed */
+    BBMAP_E_HIP = -4,        /* a HIP runtime call failed; see bbmap_last_error() */
+    BBMAP_E_SHAPE = -5       /* a job exceeds maxRows/maxColumns of the context */
+};
+
+/* Human-readable text of the last error on the calling thread. */
+const char *bbmap_last_error(void);
+int bbmap_abi_version(void);
+
+/* =====================================================================================
+ * MultiStateAligner11ts (affine-gap multi-state DP)
+ *   replaces jni/MultiStateAligner11tsJNI.c (fillUnlimited :100-314, fillLimitedX :361-704)
+ *   and fuses the Java-side walkers that read its `packed` matrix:
+ *   current/align2/MultiStateAligner11tsJNI.java traceback2 :376-495, score2 :537-658,
+ *   plus the call shape of current/align2/MSA.java fillAndScoreLimited :103-134.
+ * ===================================================================================== */
+
+/* job.flags: low 3 bits = fill mode, the rest are option bits */
+enum {
+    BBMSA_FILL_LIMITED_RAW   = 0, /* == C fillLimitedX(): minScore used as given, result[5]        */
+    BBMSA_FILL_UNLIMITED_RAW = 1, /* == C fillUnlimited(): result[0..3]                             */
+    BBMSA_FILL_LIMITED       = 2, /* == Java fillLimited(gaps==null): unlimited fallback gate +     */
+                                  /*    minScore-=120 (MultiStateAligner11tsJNI.java:132-164)       */
+    BBMSA_MODE_MASK          = 7,
+    BBMSA_CLAMP_WINDOW = 1 << 3,  /* a=max(0,start), b=min(ref_len-1,end), MSA.java:104-105,118-121 */
+    BBMSA_DO_SCORE     = 1 << 4,  /* run score2 on a non-null fill                                  */
+    BBMSA_DO_TRACEBACK = 1 << 5   /* run traceback2 on a non-null fill, write the match string      */
+};
+/* the composite the mapper calls most: MSA.fillAndScoreLimited(read, ref, start, stop, minScore, null) */
+#define BBMSA_FILL_AND_SCORE_LIMITED (BBMSA_FILL_LIMITED | BBMSA_CLAMP_WINDOW | BBMSA_DO_SCORE)
+
+typedef struct bbmsa_job {
+    int64_t read_off;     /* byte offset of read[0] inside the `reads` buffer                       */
+    int64_t ref_off;      /* byte offset of ref[0] (the array refStartLoc/refEndLoc index into)     */
+    int32_t read_len;     /* rows                                                                    */
+    int32_t ref_len;      /* ref.length, used by BBMSA_CLAMP_WINDOW                                  */
+    int32_t refStartLoc;
+    int32_t refEndLoc;
+    int32_t minScore;
+    int32_t flags;
+} bbmsa_job;              /* 40 bytes */
+
+/* status values */
+enum {
+    BBMSA_ST_OK = 0,
+    BBMSA_ST_NULL = 1,        /* the Java call would have returned null (below minScore)            */
+    BBMSA_ST_BAD_SHAPE = 2    /* rows/columns outside the context limits: nothing was computed      */
+};
+
+typedef struct bbmsa_result {
+    int32_t result[5];    /* {rows, maxCol, maxState, maxScore, belowMin} exactly as the C fills it  */
+    int32_t status;
+    int64_t iterations;   /* cells visited (what the C adds to iterationsLimited / ...Unlimited)     */
+    int32_t score[8];     /* score2: {score,bestRefStart,bestRefStop,maxRow,maxCol,maxState,padL,padR} */
+    int32_t score_len;    /* 0 (not run / null), 6 or 8                                              */
+    int32_t match_len;    /* bytes of match string written (0 = none, -1 = slot too small)           */
+    int32_t fill_kind;    /* 0 = limited fill ran, 1 = unlimited fill ran                            */
+    int32_t columns;      /* columns actually aligned (after clamping)                               */
+} bbmsa_result;           /* 80 bytes */
+
+typedef struct bbmsa_ctx bbmsa_ctx;
+
+typedef struct bbmsa_config {
+    int32_t device;          /* HIP device ordinal                                                   */
+    int32_t maxRows;         /* like MSA(maxRows_, maxColumns_), MSA.java:66-69; <= 640              */
+    int32_t maxColumns;      /* <= 4096                                                              */
+    int32_t bandwidth;       /* MSA.bandwidth (static in the reference, MSA.java:864)                */
+    float   bandwidthRatio;  /* MSA.bandwidthRatio (MSA.java:865)                                    */
+    int32_t reserved[3];
+} bbmsa_config;
+
+int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out);
+void bbmsa_destroy(bbmsa_ctx *ctx);
+
+/* Device-resident batch: every pointer is a device pointer valid on cfg->device; the call only
+ * enqueues work on `stream` (a hipStream_t passed as void*, NULL = default stream) and returns.
+ * `match` receives one slot of `match_stride` bytes per job (may be NULL when no job asks for
+ * BBMSA_DO_TRACEBACK). */
+int bbmsa_align_batch_device(bbmsa_ctx *ctx, void *stream, int64_t n_jobs,
+                             const bbmsa_job *jobs, const uint8_t *reads, const uint8_t *refs,
+                             bbmsa_result *results, uint8_t *match, int32_t match_stride);
+
+/* Host-buffer batch: copies in, runs, copies out, synchronises. */
+int bbmsa_align_batch(bbmsa_ctx *ctx, int64_t n_jobs, const bbmsa_job *jobs,
+                      const uint8_t *reads, int64_t reads_bytes,
+                      const uint8_t *refs, int64_t refs_bytes,
+                      bbmsa_result *results, uint8_t *match, int32_t match_stride);
+
+/* Timing of the last bbmsa_align_batch_device launch sequence on this context, measured with
+ * HIP events on the launch stream.  Valid after the stream has been synchronised. */
+int bbmsa_last_kernel_ms(bbmsa_ctx *ctx, float *ms_fast, float *ms_slow);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

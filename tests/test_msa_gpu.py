@@ -1,0 +1,173 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit for bit."""
+import random
+
+import numpy as np
+import pytest
+
+from bbmap_amd import msa as M
+from oracle.oracle import OracleMSA
+from tests.problems import mixed_problems, survey_problem_stream, max_quality, rand_seq
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_align(om, read, ref, a, b, ms, flags):
+    """What the reference would produce for one job with these flags (oracle restatement)."""
+    mode = flags & 7
+    out = {"score": None, "match": None, "status": 0}
+    if flags & M.CLAMP_WINDOW:
+        a = max(0, a)
+        b = min(len(ref) - 1, b)
+    it_l0, it_u0 = om.iterationsLimited, om.iterationsUnlimited
+    if mode == M.FILL_LIMITED_RAW:
+        res, _ = om.fill_limited_raw(read, ref, a, b, ms)
+        om.s.rows, om.s.columns = len(read), b - a + 1
+        null = res[4] == 1
+    elif mode == M.FILL_UNLIMITED_RAW:
+        res, _ = om.fill_unlimited_raw(read, ref, a, b)
+        res = res + [0]
+        om.s.rows, om.s.columns = len(read), b - a + 1
+        null = False
+    else:
+        r4 = om.fillLimited(read, ref, a, b, ms)
+        null = r4 is None
+        res = None if null else r4 + [0]
+        if null:
+            out["status"] = 1
+    out["iterations"] = (om.iterationsLimited - it_l0) + (om.iterationsUnlimited - it_u0)
+    out["fill_kind"] = 1 if om.iterationsUnlimited != it_u0 else 0
+    out["result"] = res
+    if not null:
+        if flags & M.DO_SCORE:
+            out["score"] = om.score(read, ref, a, b, res[0], res[1], res[2])
+        if flags & M.DO_TRACEBACK:
+            out["match"] = om.traceback(read, ref, a, b, res[0], res[1], res[2])
+    return out
+
+
+def check_batch(problems, flags, maxRows=601, maxColumns=3000, bandwidth=0, bandwidthRatio=0.0, **kw):
+    al = M.MultiStateAligner11ts(maxRows, maxColumns, bandwidth, bandwidthRatio, **kw)
+    got = al.align(problems, flags)
+    om = OracleMSA(maxRows, maxColumns, bandwidth, bandwidthRatio)
+    n_null = 0
+    for k, (p, g) in enumerate(zip(problems, got)):
+        exp = oracle_align(om, p[0], p[1], p[2], p[3], p[4], flags)
+        ctx = "job %d rows=%d cols=%d ms=%d" % (k, len(p[0]), p[3] - p[2] + 1, p[4])
+        if exp["result"] is not None:
+            assert g["result"] == exp["result"], ctx
+        else:
+            assert g["status"] == M.ST_NULL, ctx
+            n_null += 1
+        assert g["status"] == exp["status"], ctx
+        assert g["iterations"] == exp["iterations"], ctx
+        assert g["fill_kind"] == exp["fill_kind"], ctx
+        assert g["score"] == exp["score"], ctx
+        assert g["match"] == exp["match"], ctx
+    al.ctx.close()
+    return n_null
+
+
+ALL = M.FILL_AND_SCORE_LIMITED | M.DO_TRACEBACK
+
+
+def test_known_answers_from_survey():
+    ref = b"NNNNACGTTGCAAGCTTAGGCTTACGGATCCGATTACAGGCATTAGCCGTAAGCTTGCAATGCNNNN"
+    read = b"GCTTAGGCTTACGGATCGATTACAGGCATTAGCC"
+    al = M.MultiStateAligner11ts()
+    g = al.align([(read, ref, 0, 66, 0)], M.FILL_UNLIMITED_RAW)[0]
+    assert g["result"][:4] == [34, 48, 0, 2868] and g["iterations"] == 2278
+    random.seed(7)
+    gen = "".join(random.choice("ACGT") for _ in range(400)).encode()
+    rd = bytearray(gen[100:250])
+    rd[40] = ord("A") if rd[40] != ord("A") else ord("C")
+    del rd[90:92]
+    g = al.align([(bytes(rd), gen, 96, 253, 8151)], M.FILL_LIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK)[0]
+    assert g["result"] == [148, 154, 0, 13978, 0] and g["iterations"] == 12688
+    assert g["score"] == [13978, 100, 249, 148, 154, 0]
+    assert g["match"] == b"m" * 40 + b"S" + b"m" * 49 + b"DD" + b"m" * 58
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_mixed_problems_fill_score_traceback(seed):
+    probs = mixed_problems(seed, 300)
+    n_null = check_batch(probs, ALL)
+    assert 0 < n_null < len(probs)
+
+
+def test_raw_limited_and_unlimited_modes():
+    probs = mixed_problems(17, 200)
+    check_batch(probs, M.FILL_LIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK)
+    check_batch(probs, M.FILL_UNLIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK)
+
+
+def test_survey_stream_including_banded():
+    """The survey's 400-problem stream; one third of it is banded (bw=40, bwr=0.18)."""
+    groups = {}
+    for rd, G, a, b, ms, bw, bwr in survey_problem_stream():
+        groups.setdefault((bw, bwr), []).append((rd, G, a, b, ms))
+    assert len(groups) == 2
+    for (bw, bwr), probs in groups.items():
+        check_batch(probs, M.FILL_LIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK, bandwidth=bw, bandwidthRatio=bwr)
+
+
+@pytest.mark.parametrize("lanes,maxRows", [(16, 160), (32, 160), (64, 160), (32, 320), (64, 601), (16, 48), (64, 64)])
+def test_every_lane_geometry(lanes, maxRows):
+    lens = tuple(x for x in (40, 60, 100, 150, 250, 300, 500, 600) if x <= maxRows)[-3:]
+    probs = mixed_problems(100 + lanes + maxRows, 120, read_lens=lens, ref_len=1600)
+    probs = [p for p in probs if len(p[0]) <= maxRows]
+    check_batch(probs, ALL, maxRows=maxRows, maxColumns=1024, lanes_per_job=lanes)
+
+
+def test_generic_kernel_handles_wide_windows():
+    # fast_cols=128 forces every wider window through the per-thread generic kernel
+    probs = mixed_problems(23, 80)
+    check_batch(probs, ALL, fast_cols=128)
+
+
+def test_edge_cases():
+    rng = random.Random(4)
+    ref = rand_seq(rng, 500)
+    probs = []
+    probs.append((ref[100:101], ref, 100, 100, 0))                      # 1 x 1
+    probs.append((ref[100:103], ref, 98, 106, 0))                        # tiny
+    probs.append((b"N" * 50, ref, 100, 160, 100))                        # all-N read
+    probs.append((ref[200:350], b"N" * 500, 190, 360, 100))              # all-N reference
+    probs.append((ref[200:350], ref, -5, 170, 5000))                     # window clipped at the left end
+    probs.append((ref[400:500], ref, 390, 520, 3000))                    # window clipped at the right end
+    gapped = ref[:250] + b"-" * 3 + ref[250:]
+    probs.append((ref[150:350], gapped, 140, 365, 8000))                 # gap symbols in the reference
+    probs.append((ref[150:300].lower(), ref, 146, 303, 2000))            # lower-case read never matches
+    probs.append((ref[150:300], ref, 146, 303, max_quality(150)))        # perfect, minScore = max
+    probs.append((ref[150:300], ref, 146, 303, max_quality(150) + 121))  # unreachable minScore
+    check_batch(probs, ALL)
+    check_batch(probs[:4] + probs[6:], M.FILL_LIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK)
+    check_batch(probs[:4] + probs[6:], M.FILL_UNLIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK)
+
+
+def test_bad_shape_reported_not_computed():
+    rng = random.Random(8)
+    ref = rand_seq(rng, 800)
+    ctx = M.MSAContext(maxRows=100, maxColumns=200)
+    jobs, reads, refs = M.pack_problems([(ref[100:250], ref, 96, 253, 100), (ref[100:150], ref, 96, 400, 100),
+                                         (ref[100:150], ref, 96, 160, 100)], M.FILL_LIMITED)
+    res, _ = ctx.align_batch(jobs, reads, refs)
+    assert res["status"].tolist() == [M.ST_BAD_SHAPE, M.ST_BAD_SHAPE, M.ST_OK]
+
+
+def test_full_size_batch_properties():
+    """BASELINE-sized shapes (150-bp reads, window = read + 2*4 pad): size-independent properties."""
+    rng = random.Random(77)
+    ref = rand_seq(rng, 200000)
+    probs = []
+    for _ in range(20000):
+        st = rng.randrange(100, len(ref) - 300)
+        probs.append((ref[st:st + 150], ref, st - 4, st + 153, int(0.56 * max_quality(150))))
+    al = M.MultiStateAligner11ts(maxRows=160, maxColumns=256)
+    got = al.align(probs, ALL)
+    for p, g in zip(probs, got):
+        assert g["score"][0] == max_quality(150)                # a perfect read scores maxQuality
+        assert g["score"][1] == p[2] + 4 and g["score"][2] == p[2] + 4 + 149
+        assert g["match"] == b"m" * 150
+    # idempotence: a second pass gives identical records
+    got2 = al.align(probs, ALL)
+    assert got == got2
