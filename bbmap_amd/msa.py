@@ -118,7 +118,9 @@ class MultiStateAligner11ts:
         jobs, reads, refs = pack_problems(problems, flags)
         stride = 0
         if want_match and problems:
-            stride = max(len(p[0]) + (p[3] - p[2] + 1) + 8 for p in problems)
+            # rows + columns symbols at most, and every '-' gap symbol expands to 128 'D'
+            stride = max(len(p[0]) + (p[3] - p[2] + 1) + 8 +
+                         127 * bytes(p[1][max(0, p[2]):max(0, p[3] + 1)]).count(b"-") for p in problems)
             stride = (stride + 15) & ~15
         res, match = self.ctx.align_batch(jobs, reads, refs, stride)
         for r in res:
