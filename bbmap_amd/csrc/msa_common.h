@@ -24,7 +24,8 @@ constexpr int kMinOffScore = (-(((1 << 20) - 1) - 2000)) * 2048;  // MINoff_SCOR
 constexpr int kNegInf = -(1 << 30);   // "no limit" for the unlimited fill; never reached by any score
 constexpr int kGapLen = 128;
 
-constexpr int kTableLen = 1024;       // delC / insC LDS tables
+constexpr int kTableLen = 3072;       // delC / insC LDS tables: index time (<2048) + rows (<=640), never clamped
+constexpr int kLdsTableInts = 2 * kTableLen + 256;   // + delExt[128], insExt[32], subExt[8] (padded)
 
 // closed forms of calcDelScoreOffset (jni/...c:316-336) and of the cumulative
 // POINTSoff_INS_ARRAY_C table (MultiStateAligner11tsJNI.java:1582-1601)

@@ -59,15 +59,21 @@ __device__ __forceinline__ unsigned load_coherent(const unsigned *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int R>
+template <int R, bool BANDED>
 __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) {
     extern __shared__ int lds[];
     int *delC = lds;
     int *insC = lds + kTableLen;
+    int *delExt = lds + 2 * kTableLen;       // jni/...c:229-233 as a table of the streak (index <= 83)
+    int *insExt = delExt + 128;               // POINTSoff_INS_ARRAY[streak+1], index min(streak,20)
+    int *subExt = insExt + 32;                // POINTSoff_SUB_ARRAY[streak+1], index min(streak,5)
     for (int i = threadIdx.x; i < kTableLen; i += blockDim.x) {
         delC[i] = calc_del_off(i);
         insC[i] = calc_ins_cum_off(i);
     }
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) delExt[i] = del_extend(i);
+    if (threadIdx.x < 32) insExt[threadIdx.x] = ins_extend(threadIdx.x);
+    if (threadIdx.x < 8) subExt[threadIdx.x] = sub_extend(threadIdx.x);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) 
     const int groupBase = sub * G;           // first wave lane of my job group
 
     const int perJobLds = (p.fastCols + 2) * 2 + (p.tmpBytes + 3) / 4;   // ints
-    int *myLds = lds + 2 * kTableLen + (wave * jobsPerWave + sub) * perJobLds;
+    int *myLds = lds + kLdsTableInts + (wave * jobsPerWave + sub) * perJobLds;
     int2 *colinfo = reinterpret_cast<int2 *>(myLds);                      // [c] = {horizLimit[c], ref byte of column c}
     uint8_t *tmp = reinterpret_cast<uint8_t *>(myLds + (p.fastCols + 2) * 2);
 
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) 
             int h = minScoreOff;
             bool prevDef = false;
             for (int i = columns - 1; i >= 0; i--) {
-                colinfo[i + 1].x = limited ? h : kNegInf;               // horizLimit[i+1]
+                colinfo[i + 1].x = (limited ? h : kNegInf) + 2048;      // horizLimit[i+1] + 2048 (see the fill loop)
                 const int cb = colinfo[i + 1].y;                         // ref[refStartLoc+i]
                 const bool def = fully_defined(cb);
                 const int cost = def ? (prevDef ? P_MATCH2 : P_MATCH) : ((prevDef && cb == '-') ? P_DEL : 0);
@@ -221,162 +227,193 @@ __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) 
         __builtin_amdgcn_wave_barrier();
 
         // ------------------------------------------------------------------ fill
+        // The loop body is written branch-free (selects only) so that the R rows of a lane form one basic block
+        // the scheduler can interleave.  Tricks that keep it exact:
+        //  * a packed cell p = score|time (score a multiple of 2048, time < 2048) satisfies
+        //    score <= L  <=>  p < L + 2048 for any multiple-of-2048 bound L, so prune tests run on packed values
+        //    against "limit + 2048" (suffix P below) without masking;
+        //  * prevMatch(row, col) is match(row-1, col-1): the bit computed one step earlier for the row above;
+        //  * the predecessor traceback2 would pick for a DEL/INS cell is exactly "the extension won the fill's
+        //    own comparison" (extension costs are never below the opening cost), so those two record bits are free.
         const int nl = (rows + R - 1) / R;                               // lanes in use
         int steps = run ? columns + nl - 1 : 0;
         for (int d = 32; d >= 1; d >>= 1) steps = max(steps, __shfl_xor(steps, d, 64));
 
         int pM[R], pD[R], pI[R];         // my rows' cells at the previous column
+        int col0[R];                     // column-0 value of each row (cumulative insertion cost, time 0)
         int minGood[R], maxGood[R];      // first / last good column of each row (-1 / -2 = none)
+        int vlimP[R];                    // vertLimit + 2048; INT_MAX for rows beyond the read (prunes everything)
+        int delForce[R];                 // INT_MAX where the deletion barrier applies (row<3 || row>rows-3), else INT_MIN
+        int insHiForce[R];               // INT_MAX where row > rows-2 (insertion barrier near the end), else INT_MIN
         unsigned dacc[R];
+        int mPrev[R];                    // match(row k, previous column) as 0/1 (kept in a VGPR: SGPR masks are scarce)
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            const int v = insC[min(r0 + k, kTableLen - 1)];              // column 0: cumulative insertion cost, time 0
-            pM[k] = v; pD[k] = v; pI[k] = v;
+            const int row = r0 + k;
+            col0[k] = insC[min(row, kTableLen - 1)];
+            pM[k] = col0[k]; pD[k] = col0[k]; pI[k] = col0[k];
             minGood[k] = -1; maxGood[k] = -2; dacc[k] = 0;
+            vlimP[k] = rowValid[k] ? vlim[k] + 2048 : (1 << 30);     // above every reachable packed value
+            mPrev[k] = (call1[k] == '!') ? 1 : 0;                        // ref0 of column 1 is '!' (jni/...c:463)
+            delForce[k] = (row < 3 || row > rows - 3) ? INT_MAX : INT_MIN;
+            insHiForce[k] = (row > rows - 2) ? INT_MAX : INT_MIN;
         }
+        const bool rowOne = (r0 == 1);                                   // slot 0 of lane 0 is DP row 1
+        const bool notLimited = !limited;
+        const bool groupLead = (gl == 0);
+        const int floorP = floorv + 2048;
         int svM = 0, svD = 0, svI = 0;   // row above at the previous column (diag for my first row)
         int lastRef = '!';
-        // last-row argmax (first strict maximum per state)
-        int bestM = 0, bestD = 0, bestI = 0, bestMs = INT_MIN, bestDs = INT_MIN, bestIs = INT_MIN;
-        int bestMc = -1, bestDc = -1, bestIc = -1;
-
-        const int insBarHi = rows - 2, insBarCol = columns - 1, delBarHi = rows - 3;
+        // last-row argmax (first strict maximum per state); kept by the lane/slot that owns row `rows`
+        const int lastSlot = (max(rows, 1) - 1) % R;
+        const bool ownerLaneFlag = gl == (max(rows, 1) - 1) / R;
+        int bestM = 0, bestD = 0, bestI = 0, bestMc = -1, bestDc = -1, bestIc = -1;
 
         for (int t = 1; t <= steps; t++) {
             const int c = t - gl;
             const bool inRange = run && c >= 1 && c <= columns;
+            const bool atCol0 = (c == 0);
             const int cc = min(max(c, 1), max(columns, 1));
             const int2 ci = colinfo[cc];
-            const int hl = ci.x, ref1 = ci.y;
+            const int hlP = ci.x, ref1 = ci.y;                           // ci.x holds horizLimit + 2048
             const int ref0 = c < 2 ? '!' : lastRef;
             const bool gap = ref1 == '-';
             const bool refN = ref1 == 'N';
+            const int refPen = refN ? P_DEL_REF_N : (gap ? P_GAP : 0);
             const int insNeededBase = (columns - c) + 1;                 // insNeeded = (rows-row) - this
+            const bool cGt1 = c > 1;
+            const int cLtLastForce = (c < columns - 1) ? INT_MAX : INT_MIN;
+            const unsigned sh = (unsigned)(t & 7) * 4u;
 
             // row above, same column (lane gl-1 finished it one step ago); row 0 is all zero
             int upM = lane_up(pM[R - 1], 0);
             int upD = lane_up(pD[R - 1], 0);
             int upI = lane_up(pI[R - 1], 0);
-            int upStarted = lane_up(minGood[R - 1], 1);                  // >=0 once the row above has a good cell
-            int upMaxG = lane_up(maxGood[R - 1], 0);                     // last good column of the row above so far
-            if (gl == 0) { upM = 0; upD = 0; upI = 0; upStarted = 1; upMaxG = min(columns, 2 * halfband); }
+            int upMin = lane_up(minGood[R - 1], 1);                      // >=0 once the row above has a good cell
+            upM = groupLead ? 0 : upM; upD = groupLead ? 0 : upD; upI = groupLead ? 0 : upI;
+            upMin = groupLead ? 1 : upMin;
+            int upMaxG = 0;
+            if (BANDED) {
+                upMaxG = lane_up(maxGood[R - 1], 0);                     // last good column of the row above so far
+                upMaxG = groupLead ? min(columns, 2 * halfband) : upMaxG;
+            }
             int dgM = svM, dgD = svD, dgI = svI;
             svM = upM; svD = upD; svI = upI;
-            bool started = upStarted >= 0;
-            int call0 = call0First;
+            bool started = upMin >= 0;
+            bool prevMatch = (call0First == ref0) && (ref0 != 'N');
 
 #pragma unroll
             for (int k = 0; k < R; k++) {
                 const int row = r0 + k;
-                const bool bandOK = !banded || (c >= row - halfband && c <= upMaxG + 1);
-                const bool act = inRange && rowValid[k] && (started || !limited) && bandOK;
+                bool act = inRange && (started || notLimited);              // rows beyond the read prune through vlimP
+                if (BANDED) act = act && (!banded || (c >= row - halfband && c <= upMaxG + 1));
                 const int cl1 = call1[k];
                 const bool match = (cl1 == ref1) && !refN;
-                const bool prevMatch = (call0 == ref0) && (ref0 != 'N');
-                const int limit = max(vlim[k], hl);
-                const int limit3 = max(floorv, match ? limit - P_MATCH2 : limit - P_SUB3);
+                const int limitP = max(vlimP[k], hlP);
+                const int limit = limitP - 2048;
                 const int delNeeded = max(0, row - c - 1);
                 const int insNeeded = max(0, (rows - row) - insNeededBase);
-                const int delPen = delC[min(delNeeded, kTableLen - 1)];
-                const int insPen = insC[min(insNeeded, kTableLen - 1)];
+                int delPen = delC[delNeeded];
+                int insPen = insC[insNeeded];
+                const bool needDel = delNeeded > 0, needIns = insNeeded > 0;
+                const int pruneVal = atCol0 ? col0[k] : subfloor;       // what an unvisited cell reads as
 
                 // ---- match / substitution plane
-                const int sdm = dgM & kScoreMask, sdd = dgD & kScoreMask, sdi = dgI & kScoreMask;
                 const int streakM = dgM & kTimeMask;
-                int nM;
-                bool goodM = false;
-                {
-                    const bool prune = !act || gap || (max(sdm, max(sdd, sdi)) <= limit3);
-                    int addA;
-                    if (match) addA = prevMatch ? P_MATCH2 : P_MATCH;
-                    else if (refN || cl1 == 'N') addA = 0;
-                    else addA = prevMatch ? (streakM <= 1 ? P_SUBR : P_SUB) : sub_extend(streakM);
-                    const int sa = sdm + addA;
-                    const int sbc = max(sdd, sdi) + (match ? P_MATCH : P_SUB);
-                    const bool aWins = sa >= sbc;
-                    int score = aWins ? sa : sbc;
-                    int time = (aWins && (match == prevMatch)) ? streakM + 1 : 1;
-                    const int limit2 = delNeeded > 0 ? limit - delPen : (insNeeded > 0 ? limit - insPen : limit);
-                    goodM = !prune && score >= limit2;
-                    score = goodM ? score : subfloor;
-                    nM = prune ? subfloor : (score | clamp_time(time));
-                }
+                const int sdm = dgM & kScoreMask;
+                const int mDI = max(dgD, dgI) & kScoreMask;
+                const int t3 = max(floorP, limitP - (match ? P_MATCH2 : P_SUB3));
+                const bool pruneM = !act || gap || (max(dgM, max(dgD, dgI)) < t3);
+                int subx = subExt[min(streakM, 5)];
+                asm volatile("" : "+v"(subx), "+v"(delPen), "+v"(insPen));
+                int addA = prevMatch ? (streakM <= 1 ? P_SUBR : P_SUB) : subx;
+                addA = (refN || cl1 == 'N') ? 0 : addA;
+                addA = match ? (prevMatch ? P_MATCH2 : P_MATCH) : addA;
+                const int sa = sdm + addA;
+                const int sbc = mDI + (match ? P_MATCH : P_SUB);
+                const bool aWinsM = sa >= sbc;
+                const int scoreM = max(sa, sbc);
+                const int timeM = (aWinsM && (match == prevMatch)) ? streakM + 1 : 1;
+                const int penM = needDel ? delPen : insPen;
+                const bool goodM = !pruneM && (scoreM + penM >= limit);
+                const int nM = goodM ? (scoreM | timeM) : pruneVal;
+
                 // ---- deletion plane (same row, previous column)
-                const int slm = pM[k] & kScoreMask, sld = pD[k] & kScoreMask;
                 const int streakD = pD[k] & kTimeMask;
-                int nD;
-                bool goodD = false;
-                {
-                    const bool prune = !act || row < 3 || row > delBarHi || (max(slm, sld) <= limit);
-                    const int sa = slm + P_DEL;
-                    const int sb = sld + del_extend(streakD);
-                    const int refPen = refN ? P_DEL_REF_N : (gap ? P_GAP : 0);
-                    const bool aWins = sa >= sb;
-                    int score = (aWins ? sa : sb) + refPen;
-                    const int time = aWins ? 1 : streakD + 1;
-                    int limit2 = limit;
-                    if (insNeeded > 0) limit2 = limit - insPen;
-                    else if (delNeeded > 0)
-                        limit2 = limit - delC[min(time + delNeeded, kTableLen - 1)] + delC[min(time, kTableLen - 1)];
-                    goodD = !prune && score >= limit2;
-                    score = goodD ? score : subfloor;
-                    nD = prune ? subfloor : (score | clamp_time(time));
-                }
+                const int slm = pM[k] & kScoreMask, sld = pD[k] & kScoreMask;
+                const bool pruneD = !act || (max(pM[k], pD[k]) < max(limitP, delForce[k]));
+                int dext = delExt[min(streakD, 80 | (streakD & 3))];
+                asm volatile("" : "+v"(dext));
+                const int dsa = slm + P_DEL;
+                const int dsb = sld + dext;
+                const bool aWinsD = dsa >= dsb;
+                const int scoreD = max(dsa, dsb) + refPen;
+                const int timeD = aWinsD ? 1 : streakD + 1;
+                int d2 = delC[timeD + delNeeded] - delC[timeD];          // 0 when no deletion is still needed
+                asm volatile("" : "+v"(d2));
+                const int penD = needIns ? insPen : d2;
+                const bool goodD = !pruneD && (scoreD + penD >= limit);
+                const int nD = goodD ? (scoreD | (timeD > kMaxTime ? kMaxTime - 3 : timeD)) : pruneVal;
+
                 // ---- insertion plane (row above, same column)
-                const int sum = upM & kScoreMask, sui = upI & kScoreMask;
                 const int streakI = upI & kTimeMask;
-                int nI;
-                bool goodI = false;
-                {
-                    const bool prune = !act || gap || (row < 2 && c > 1) || (row > insBarHi && c < insBarCol) ||
-                                       (max(sum, sui) <= limit);
-                    const int sa = sum + P_INS;
-                    const int sb = sui + ins_extend(streakI);
-                    const bool aWins = sa >= sb;
-                    int score = aWins ? sa : sb;
-                    const int time = aWins ? 1 : streakI + 1;
-                    int limit2 = limit;
-                    if (delNeeded > 0) limit2 = limit - delPen;
-                    else if (insNeeded > 0)
-                        limit2 = limit - insC[min(time + insNeeded, kTableLen - 1)] + insC[min(time, kTableLen - 1)];
-                    goodI = !prune && score >= limit2;
-                    score = goodI ? score : subfloor;
-                    nI = prune ? subfloor : (score | clamp_time(time));
-                }
+                const int sum = upM & kScoreMask, sui = upI & kScoreMask;
+                const int insForce = (k == 0) ? ((rowOne && cGt1) ? INT_MAX : min(insHiForce[k], cLtLastForce))
+                                              : min(insHiForce[k], cLtLastForce);
+                const bool pruneI = !act || gap || (max(upM, upI) < max(limitP, insForce));
+                int iext = insExt[min(streakI, 20)];
+                asm volatile("" : "+v"(iext));
+                const int isa = sum + P_INS;
+                const int isb = sui + iext;
+                const bool aWinsI = isa >= isb;
+                const int scoreI = max(isa, isb);
+                const int timeI = aWinsI ? 1 : streakI + 1;
+                int i2 = insC[timeI + insNeeded] - insC[timeI];          // 0 when no insertion is still needed
+                asm volatile("" : "+v"(i2));
+                const int penI = needDel ? delPen : i2;
+                const bool goodI = !pruneI && (scoreI + penI >= limit);
+                const int nI = goodI ? (scoreI | timeI) : pruneVal;
 
                 // ---- traceback record (MultiStateAligner11tsJNI.java:389-443): what traceback2 would decide here
-                unsigned nib;
-                {
-                    const unsigned msPrev = ((nM & kTimeMask) > 1) ? 0u
-                        : ((sdm >= sdd && sdm >= sdi) ? 0u : (sdd >= sdi ? 1u : 2u));
-                    const unsigned delPrev = ((nD & kTimeMask) > 1) ? 1u : (slm >= sld ? 0u : 1u);
-                    const unsigned insPrev = ((nI & kTimeMask) > 1) ? 1u : (sum >= sui ? 0u : 1u);
-                    nib = msPrev | (delPrev << 2) | (insPrev << 3);
-                }
-                dacc[k] |= (act ? nib : 0u) << ((t & 7) * 4);
+                const bool msStay = (timeM > 1) || (sdm >= mDI);
+                const unsigned nibM = msStay ? 0u : (((dgD | kTimeMask) >= dgI) ? 1u : 2u);
+                const unsigned nib = nibM | (aWinsD ? 0u : 4u) | (aWinsI ? 0u : 8u);
+                dacc[k] |= nib << sh;
 
                 // ---- bookkeeping
                 const bool good = goodM || goodD || goodI;
-                if (good) {
-                    if (banded && minGood[k] >= 0 && c - maxGood[k] >= 3 && row < rows) bandViolation = 1;
-                    maxGood[k] = c; if (minGood[k] < 0) minGood[k] = c;
+                if (BANDED) {
+                    if (good && banded && minGood[k] >= 0 && c - maxGood[k] >= 3 && row < rows) bandViolation = 1;
                 }
-                if (act && row == rows) {
-                    const int xm = nM & kScoreMask, xd = nD & kScoreMask, xi = nI & kScoreMask;
-                    if (bestMc < 0 || xm > bestMs) { bestMs = xm; bestM = nM; bestMc = c; }
-                    if (bestDc < 0 || xd > bestDs) { bestDs = xd; bestD = nD; bestDc = c; }
-                    if (bestIc < 0 || xi > bestIs) { bestIs = xi; bestI = nI; bestIc = c; }
-                }
+                minGood[k] = (good && minGood[k] < 0) ? c : minGood[k];
+                maxGood[k] = good ? c : maxGood[k];
                 // next row of this lane: diag = my previous-column cell, up = my new cell
-                const int ndM = pM[k], ndD = pD[k], ndI = pI[k];
-                if (inRange) { pM[k] = nM; pD[k] = nD; pI[k] = nI; }
-                dgM = ndM; dgD = ndD; dgI = ndI;
+                dgM = pM[k]; dgD = pD[k]; dgI = pI[k];
+                pM[k] = nM; pD[k] = nD; pI[k] = nI;
                 upM = nM; upI = nI;
                 started = minGood[k] >= 0;
-                upMaxG = maxGood[k];
-                call0 = cl1;
+                if (BANDED) upMaxG = maxGood[k];
+                const int mp = mPrev[k];
+                mPrev[k] = inRange ? (match ? 1 : 0) : mp;
+                prevMatch = mp != 0;
             }
-            if (inRange) lastRef = ref1;
+            lastRef = inRange ? ref1 : lastRef;
+
+            // last row: first strict maximum per plane, ascending column
+            {
+                int lm = pM[0], ld = pD[0], li = pI[0];
+#pragma unroll
+                for (int k = 1; k < R; k++) {
+                    lm = (lastSlot == k) ? pM[k] : lm; ld = (lastSlot == k) ? pD[k] : ld; li = (lastSlot == k) ? pI[k] : li;
+                }
+                const bool track = ownerLaneFlag && inRange;
+                const bool um = track && (bestMc < 0 || (lm & kScoreMask) > (bestM & kScoreMask));
+                const bool ud = track && (bestDc < 0 || (ld & kScoreMask) > (bestD & kScoreMask));
+                const bool ui = track && (bestIc < 0 || (li & kScoreMask) > (bestI & kScoreMask));
+                bestM = um ? lm : bestM; bestMc = um ? c : bestMc;
+                bestD = ud ? ld : bestD; bestDc = ud ? c : bestDc;
+                bestI = ui ? li : bestI; bestIc = ui ? c : bestIc;
+            }
 
             if ((t & 7) == 7) {
                 const long long o = (long long)(t >> 3) * R * G + gl;
@@ -431,9 +468,9 @@ __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) 
         const int ownerLane = groupBase + (max(rows, 1) - 1) / R;
         int bScore, bCol, bState, bPacked;
         {
-            int s = bestMs, cbest = bestMc, st = 0, pk = bestM;
-            if (bestDc >= 0 && bestDs > s) { s = bestDs; cbest = bestDc; st = 1; pk = bestD; }
-            if (bestIc >= 0 && bestIs > s) { s = bestIs; cbest = bestIc; st = 2; pk = bestI; }
+            int s = bestMc >= 0 ? (bestM & kScoreMask) : INT_MIN, cbest = bestMc, st = 0, pk = bestM;
+            if (bestDc >= 0 && (bestD & kScoreMask) > s) { s = bestD & kScoreMask; cbest = bestDc; st = 1; pk = bestD; }
+            if (bestIc >= 0 && (bestI & kScoreMask) > s) { s = bestI & kScoreMask; cbest = bestIc; st = 2; pk = bestI; }
             bScore = __shfl(s, ownerLane, 64);
             bCol = __shfl(cbest, ownerLane, 64);
             bState = __shfl(st, ownerLane, 64);
@@ -580,23 +617,18 @@ __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) 
     }
 }
 
-// explicit instantiations used by the host side (msa_host.cpp)
-#define BBMSA_INST(R) template __global__ void msa_fill_fast_kernel<R>(const FillParams);
+// explicit instantiations used by the host side (msa_host.hip)
+#define BBMSA_INST(R)                                                               \
+    template __global__ void msa_fill_fast_kernel<R, false>(const FillParams);      \
+    template __global__ void msa_fill_fast_kernel<R, true>(const FillParams);
 BBMSA_INST(1) BBMSA_INST(2) BBMSA_INST(3) BBMSA_INST(4) BBMSA_INST(5)
 BBMSA_INST(6) BBMSA_INST(7) BBMSA_INST(8) BBMSA_INST(9) BBMSA_INST(10)
 
-const void *fast_kernel_for(int R) {
+#define BBMSA_CASE(R) case R: return banded ? (const void *)msa_fill_fast_kernel<R, true> : (const void *)msa_fill_fast_kernel<R, false>;
+const void *fast_kernel_for(int R, bool banded) {
     switch (R) {
-        case 1: return (const void *)msa_fill_fast_kernel<1>;
-        case 2: return (const void *)msa_fill_fast_kernel<2>;
-        case 3: return (const void *)msa_fill_fast_kernel<3>;
-        case 4: return (const void *)msa_fill_fast_kernel<4>;
-        case 5: return (const void *)msa_fill_fast_kernel<5>;
-        case 6: return (const void *)msa_fill_fast_kernel<6>;
-        case 7: return (const void *)msa_fill_fast_kernel<7>;
-        case 8: return (const void *)msa_fill_fast_kernel<8>;
-        case 9: return (const void *)msa_fill_fast_kernel<9>;
-        case 10: return (const void *)msa_fill_fast_kernel<10>;
+        BBMSA_CASE(1) BBMSA_CASE(2) BBMSA_CASE(3) BBMSA_CASE(4) BBMSA_CASE(5)
+        BBMSA_CASE(6) BBMSA_CASE(7) BBMSA_CASE(8) BBMSA_CASE(9) BBMSA_CASE(10)
     }
     return nullptr;
 }

@@ -11,7 +11,7 @@
 #include "msa_common.h"
 
 namespace bbmsa {
-const void *fast_kernel_for(int R);
+const void *fast_kernel_for(int R, bool banded);
 __global__ void msa_fill_generic_kernel(const GenericParams p);
 }  // namespace bbmsa
 
@@ -47,6 +47,7 @@ struct bbmsa_ctx {
     int *d_limits;
     hipEvent_t ev[3];
     bool timed;
+    bool banded;
 };
 
 extern "C" const char *bbmap_last_error(void) { return g_err; }
@@ -95,10 +96,11 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     c->tmpBytes = ((G * c->R + fastCols + 8) + 3) & ~3;
     const int jobsPerWave = 64 / G;
     const int perJobInts = (fastCols + 2) * 2 + c->tmpBytes / 4;
-    c->ldsBytes = (2 * bbmsa::kTableLen + 4 * jobsPerWave * perJobInts) * 4;
+    c->ldsBytes = (bbmsa::kLdsTableInts + 4 * jobsPerWave * perJobInts) * 4;
     if (c->ldsBytes > 160 * 1024) { delete c; return fail(BBMAP_E_ARG, "bbmsa_create: fast-path LDS budget exceeded; lower reserved[1] (fastCols)"); }
 
-    const void *kfn = bbmsa::fast_kernel_for(c->R);
+    c->banded = !(cfg->bandwidth < 1 && cfg->bandwidthRatio <= 0.0f);
+    const void *kfn = bbmsa::fast_kernel_for(c->R, c->banded);
     if (!kfn) { delete c; return fail(BBMAP_E_ARG, "bbmsa_create: no kernel for this rows-per-lane"); }
     if (c->ldsBytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, c->ldsBytes));
@@ -175,7 +177,7 @@ extern "C" int bbmsa_align_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_j
     if (blocks > c->blocks) blocks = c->blocks;
     void *args[] = {&fp};
     HIP_TRY(hipEventRecord(c->ev[0], stream));
-    HIP_TRY(hipLaunchKernel(bbmsa::fast_kernel_for(c->R), dim3((unsigned)blocks), dim3(256), args, (size_t)c->ldsBytes, stream));
+    HIP_TRY(hipLaunchKernel(bbmsa::fast_kernel_for(c->R, c->banded), dim3((unsigned)blocks), dim3(256), args, (size_t)c->ldsBytes, stream));
     HIP_TRY(hipEventRecord(c->ev[1], stream));
 
     bbmsa::GenericParams gp;

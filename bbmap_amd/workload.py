@@ -1,0 +1,101 @@
+"""Synthetic references, reads and slow-align job lists shaped like BASELINE.json's configs.
+
+No real genome ships with the repository, so the configs are rebuilt from seeds:
+ * reference: uniform ACGT of the named length with N padding at both ends
+   (current/dna/FastaToChromArrays2.java:565-575 pads chromosomes the same way);
+ * reads: the "mutated" mix of the reference's read simulator (current/align2/RandomReads3.java:74-79,
+   sh/randomreads.sh:64-78): half the reads perfect, the rest with SNPs / short insertions /
+   deletions / N calls;
+ * jobs: one slow-align call per read at its true site, window = site +- SLOW_ALIGN_PADDING (4)
+   (current/align2/BBMapThread.java:309), minScore = 0.56 * maxQuality (BBMap.java:45-65).
+Everything is vectorised numpy so that a million reads build in seconds.
+"""
+import numpy as np
+
+from .msa import JOB_DTYPE, FILL_AND_SCORE_LIMITED, DO_TRACEBACK
+
+ECOLI_K12_LEN = 4641652
+START_PAD = 8000
+BASES = np.frombuffer(b"ACGT", np.uint8)
+
+
+def make_reference(length, seed, pad=START_PAD):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    body = BASES[rng.integers(0, 4, size=length, dtype=np.uint8)]
+    ref = np.full(length + 2 * pad, ord("N"), np.uint8)
+    ref[pad:pad + length] = body
+    return ref
+
+
+def make_reads_and_jobs(ref, n_reads, read_len=150, seed=2, pad=START_PAD, align_pad=4,
+                        min_ratio=0.56, perfect_frac=0.5, flags=FILL_AND_SCORE_LIMITED | DO_TRACEBACK,
+                        chunk=131072, max_del=40, max_ins=12):
+    """Returns (reads_blob uint8[n*read_len... variable], jobs structured array, truth dict)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = n_reads
+    body = len(ref) - 2 * pad
+    start = rng.integers(pad, pad + body - read_len - max_del - 8, size=n, dtype=np.int64)
+    imperfect = rng.random(n) >= perfect_frac
+    # event draws (only applied to imperfect reads)
+    n_snp = np.where(imperfect & (rng.random(n) < 0.4), rng.integers(1, 4, size=n), 0)
+    has_del = imperfect & (rng.random(n) < 0.2)
+    has_ins = imperfect & (rng.random(n) < 0.2) & ~has_del
+    has_n = imperfect & (rng.random(n) < 0.2)
+    # geometric-ish indel lengths, short ones most common
+    del_len = np.where(has_del, np.minimum(max_del, rng.geometric(0.25, size=n)), 0).astype(np.int64)
+    ins_len = np.where(has_ins, np.minimum(max_ins, rng.geometric(0.4, size=n)), 0).astype(np.int64)
+    ev_pos = rng.integers(10, read_len - 10 - max_ins, size=n, dtype=np.int64)
+
+    reads = np.empty((n, read_len), np.uint8)
+    ar = np.arange(read_len, dtype=np.int64)[None, :]
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        s = start[lo:hi, None]
+        p = ev_pos[lo:hi, None]
+        d = del_len[lo:hi, None]
+        il = ins_len[lo:hi, None]
+        # read index i -> reference offset: deletion skips d bases at p, insertion stalls for il bases at p
+        after = ar >= p
+        shift = np.where(after, d, 0) - np.where(ar >= p + il, il, np.where(after, ar - p, 0))
+        idx = s + ar + shift
+        block = ref[idx]
+        ins_mask = after & (ar < p + il)
+        nins = int(ins_mask.sum())
+        if nins:
+            block[ins_mask] = BASES[rng.integers(0, 4, size=nins, dtype=np.uint8)]
+        # SNPs: up to 3 per read at random positions, always a different base
+        m = hi - lo
+        for k in range(3):
+            rows = np.nonzero(n_snp[lo:hi] > k)[0]
+            if rows.size:
+                cols = rng.integers(0, read_len, size=rows.size)
+                old = block[rows, cols]
+                new = BASES[(np.searchsorted(BASES, old) + rng.integers(1, 4, size=rows.size)) % 4]
+                new = np.where(old == ord("N"), old, new)
+                block[rows, cols] = new
+        rows = np.nonzero(has_n[lo:hi])[0]
+        if rows.size:
+            block[rows, rng.integers(0, read_len, size=rows.size)] = ord("N")
+        reads[lo:hi] = block
+        del idx, block, shift, after, ins_mask
+
+    span = read_len + del_len - ins_len            # reference bases covered by the read
+    jobs = np.zeros(n, JOB_DTYPE)
+    jobs["read_off"] = np.arange(n, dtype=np.int64) * read_len
+    jobs["ref_off"] = 0
+    jobs["read_len"] = read_len
+    jobs["ref_len"] = len(ref)
+    jobs["refStartLoc"] = start - align_pad
+    jobs["refEndLoc"] = start + span - 1 + align_pad
+    max_q = 70 + 100 * (read_len - 1)
+    jobs["minScore"] = int(min_ratio * max_q)
+    jobs["flags"] = flags
+    truth = {"start": start, "span": span, "imperfect": imperfect}
+    return reads.reshape(-1), jobs, truth
+
+
+def algorithmic_bytes(jobs):
+    """SURVEY.md 8(d), fused-traceback DP: per job rows + cols + 20 + 8 + 32 + (rows + cols - 1)."""
+    rows = jobs["read_len"].astype(np.int64)
+    cols = (jobs["refEndLoc"].astype(np.int64) - jobs["refStartLoc"].astype(np.int64) + 1)
+    return int((2 * (rows + cols) + 59).sum())
