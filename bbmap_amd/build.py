@@ -32,7 +32,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + sources() + ["-o", OUT]
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("BBMSA_CXXFLAGS", "").split() \
+        + sources() + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -59,8 +59,13 @@ __device__ __forceinline__ unsigned load_coherent(const unsigned *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// waves per SIMD the register allocator must leave room for (measured on MI355X: 3 waves beats 2 by 27% at R=5)
+#ifndef BBMSA_MIN_WAVES
+#define BBMSA_MIN_WAVES(R) ((R) <= 5 ? 3 : ((R) <= 7 ? 2 : 1))
+#endif
+
 template <int R, bool BANDED>
-__global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) {
+__global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(const FillParams p) {
     extern __shared__ int lds[];
     int *delC = lds;
     int *insC = lds + kTableLen;
@@ -240,7 +245,6 @@ __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) 
         for (int d = 32; d >= 1; d >>= 1) steps = max(steps, __shfl_xor(steps, d, 64));
 
         int pM[R], pD[R], pI[R];         // my rows' cells at the previous column
-        int col0[R];                     // column-0 value of each row (cumulative insertion cost, time 0)
         int minGood[R], maxGood[R];      // first / last good column of each row (-1 / -2 = none)
         int vlimP[R];                    // vertLimit + 2048; INT_MAX for rows beyond the read (prunes everything)
         int delForce[R];                 // INT_MAX where the deletion barrier applies (row<3 || row>rows-3), else INT_MIN
@@ -250,8 +254,8 @@ __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) 
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const int row = r0 + k;
-            col0[k] = insC[min(row, kTableLen - 1)];
-            pM[k] = col0[k]; pD[k] = col0[k]; pI[k] = col0[k];
+            const int c0v = insC[row];                                   // column 0: cumulative insertion cost, time 0
+            pM[k] = c0v; pD[k] = c0v; pI[k] = c0v;
             minGood[k] = -1; maxGood[k] = -2; dacc[k] = 0;
             vlimP[k] = rowValid[k] ? vlim[k] + 2048 : (1 << 30);     // above every reachable packed value
             mPrev[k] = (call1[k] == '!') ? 1 : 0;                        // ref0 of column 1 is '!' (jni/...c:463)
@@ -262,7 +266,8 @@ __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) 
         const bool notLimited = !limited;
         const bool groupLead = (gl == 0);
         const int floorP = floorv + 2048;
-        int svM = 0, svD = 0, svI = 0;   // row above at the previous column (diag for my first row)
+        // row above at the previous column (diag for my first row); starts as its column-0 value
+        int svM = insC[r0 - 1], svD = svM, svI = svM;
         int lastRef = '!';
         // last-row argmax (first strict maximum per state); kept by the lane/slot that owns row `rows`
         const int lastSlot = (max(rows, 1) - 1) % R;
@@ -271,9 +276,12 @@ __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) 
 
         for (int t = 1; t <= steps; t++) {
             const int c = t - gl;
-            const bool inRange = run && c >= 1 && c <= columns;
-            const bool atCol0 = (c == 0);
-            const int cc = min(max(c, 1), max(columns, 1));
+            // Lanes that have not reached column 1 yet sit this step out under EXEC (their registers keep the
+            // column-0 state); lanes past the last column keep running with everything pruned, because the
+            // lane below still has to read their final cells through DPP.
+            if (c >= 1 && run) {
+            const bool inRange = c <= columns;
+            const int cc = min(c, columns);
             const int2 ci = colinfo[cc];
             const int hlP = ci.x, ref1 = ci.y;                           // ci.x holds horizLimit + 2048
             const int ref0 = c < 2 ? '!' : lastRef;
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) 
                 int delPen = delC[delNeeded];
                 int insPen = insC[insNeeded];
                 const bool needDel = delNeeded > 0, needIns = insNeeded > 0;
-                const int pruneVal = atCol0 ? col0[k] : subfloor;       // what an unvisited cell reads as
+                const int pruneVal = subfloor;                          // what an unvisited cell reads as
 
                 // ---- match / substitution plane
                 const int streakM = dgM & kTimeMask;
@@ -394,10 +402,10 @@ __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) 
                 started = minGood[k] >= 0;
                 if (BANDED) upMaxG = maxGood[k];
                 const int mp = mPrev[k];
-                mPrev[k] = inRange ? (match ? 1 : 0) : mp;
+                mPrev[k] = match ? 1 : 0;
                 prevMatch = mp != 0;
             }
-            lastRef = inRange ? ref1 : lastRef;
+            lastRef = ref1;
 
             // last row: first strict maximum per plane, ascending column
             {
@@ -414,6 +422,7 @@ __global__ __launch_bounds__(256) void msa_fill_fast_kernel(const FillParams p) 
                 bestD = ud ? ld : bestD; bestDc = ud ? c : bestDc;
                 bestI = ui ? li : bestI; bestIc = ui ? c : bestIc;
             }
+            }   // c >= 1
 
             if ((t & 7) == 7) {
                 const long long o = (long long)(t >> 3) * R * G + gl;

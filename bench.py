@@ -25,6 +25,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(jobs, reads, ref, max_rows, max_cols, target_seconds=15.0):
     """Times the CPU oracle (a port of the reference's C + Java walkers) on a bounded sample."""
     from oracle import oracle as orc
@@ -32,7 +54,7 @@ def cpu_baseline(jobs, reads, ref, max_rows, max_cols, target_seconds=15.0):
     L.orc_bench_align.restype = C.c_double
     L.orc_bench_align.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     jobs = np.ascontiguousarray(jobs)
     cells, chk = C.c_int64(), C.c_int64()
 
