@@ -14,6 +14,7 @@ EXPORTS = [
     "bbmap_last_error", "bbmap_abi_version",
     "bbmsa_create", "bbmsa_destroy", "bbmsa_align_batch_device", "bbmsa_align_batch",
     "bbmsa_last_kernel_ms",
+    "bbband_create", "bbband_destroy", "bbband_align_batch_device", "bbband_align_batch",
 ]
 
 
@@ -35,7 +36,22 @@ class bbmsa_config(C.Structure):
                 ("bandwidth", C.c_int32), ("bandwidthRatio", C.c_float), ("reserved", C.c_int32 * 3)]
 
 
+class bbband_job(C.Structure):
+    _fields_ = [("query_off", C.c_int64), ("ref_off", C.c_int64), ("query_len", C.c_int32), ("ref_len", C.c_int32),
+                ("qstart", C.c_int32), ("rstart", C.c_int32), ("maxEdits", C.c_int32), ("flags", C.c_int32)]
+
+
+class bbband_result(C.Structure):
+    _fields_ = [("edits", C.c_int32), ("lastQueryLoc", C.c_int32), ("lastRefLoc", C.c_int32), ("lastRow", C.c_int32),
+                ("lastEdits", C.c_int32), ("lastOffset", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+class bbband_config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("width", C.c_int32), ("semantics", C.c_int32), ("reserved", C.c_int32)]
+
+
 assert C.sizeof(bbmsa_job) == 40 and C.sizeof(bbmsa_result) == 80
+assert C.sizeof(bbband_job) == 40 and C.sizeof(bbband_result) == 32
 
 _lib = None
 
@@ -68,6 +84,14 @@ def load():
     L.bbmsa_align_batch.restype = C.c_int
     L.bbmsa_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.bbmsa_last_kernel_ms.restype = C.c_int
+    L.bbband_create.argtypes = [C.POINTER(bbband_config), C.POINTER(C.c_void_p)]
+    L.bbband_create.restype = C.c_int
+    L.bbband_destroy.argtypes = [C.c_void_p]
+    L.bbband_destroy.restype = None
+    L.bbband_align_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bbband_align_batch_device.restype = C.c_int
+    L.bbband_align_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.bbband_align_batch.restype = C.c_int
     _lib = L
     return L
 

@@ -51,6 +51,7 @@ struct bbmsa_ctx {
 };
 
 extern "C" const char *bbmap_last_error(void) { return g_err; }
+void bbmap_set_error(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
 extern "C" int bbmap_abi_version(void) { return BBMAP_AMD_ABI_VERSION; }
 
 static int env_int(const char *name, int dflt) {

@@ -117,6 +117,61 @@ int bbmsa_align_batch(bbmsa_ctx *ctx, int64_t n_jobs, const bbmsa_job *jobs,
  * HIP events on the launch stream.  Valid after the stream has been synchronised. */
 int bbmsa_last_kernel_ms(bbmsa_ctx *ctx, float *ms_fast, float *ms_slow);
 
+/* =====================================================================================
+ * BandedAligner (unit-cost edit distance in a diagonal band)
+ *   replaces jni/BandedAlignerJNI.c (alignForward :123-239, alignForwardRC :241-355,
+ *   alignReverse :357-470, alignReverseRC :472-585; JNI glue :588-757, header
+ *   jni/align2_BandedAlignerJNI.h:17-41).  The reference ships two semantics that disagree
+ *   (its Java class current/align2/BandedAlignerConcrete.java:100-551 is the live one,
+ *   BandedAligner.java:18-22); the context selects which one is reproduced.
+ * ===================================================================================== */
+enum {
+    BBBAND_FORWARD = 0, BBBAND_FORWARD_RC = 1, BBBAND_REVERSE = 2, BBBAND_REVERSE_RC = 3,
+    BBBAND_DIR_MASK = 3,
+    BBBAND_EXACT = 1 << 2       /* the `exact` argument: undefined bases only match themselves */
+};
+enum {
+    BBBAND_SEMANTICS_JNI_C = 0,       /* big=999, width=min(maxWidth,2*maxEdits+1), off-centre penalty +i        */
+    BBBAND_SEMANTICS_JAVA = 1         /* big=99999999, width also capped by 2*max(len)+2 and |1, penalty max(i,x) */
+};
+
+typedef struct bbband_job {
+    int64_t query_off;    /* byte offsets into the `seqs` buffer */
+    int64_t ref_off;
+    int32_t query_len;
+    int32_t ref_len;
+    int32_t qstart;
+    int32_t rstart;
+    int32_t maxEdits;
+    int32_t flags;        /* direction | BBBAND_EXACT */
+} bbband_job;             /* 40 bytes */
+
+typedef struct bbband_result {
+    int32_t edits;        /* the function's return value */
+    int32_t lastQueryLoc; /* returnVals[0..4] of the JNI call, jni/BandedAlignerJNI.c:604-630 */
+    int32_t lastRefLoc;
+    int32_t lastRow;
+    int32_t lastEdits;
+    int32_t lastOffset;
+    int32_t status;       /* 0 ok, 2 bad shape (index outside its sequence) */
+    int32_t reserved;
+} bbband_result;          /* 32 bytes */
+
+typedef struct bbband_ctx bbband_ctx;
+typedef struct bbband_config {
+    int32_t device;
+    int32_t width;        /* constructor argument of BandedAligner: maxWidth = max(width,3)|1, <= 1023 */
+    int32_t semantics;    /* BBBAND_SEMANTICS_* */
+    int32_t reserved;
+} bbband_config;
+
+int bbband_create(const bbband_config *cfg, bbband_ctx **out);
+void bbband_destroy(bbband_ctx *ctx);
+int bbband_align_batch_device(bbband_ctx *ctx, void *stream, int64_t n_jobs, const bbband_job *jobs,
+                              const uint8_t *seqs, bbband_result *results);
+int bbband_align_batch(bbband_ctx *ctx, int64_t n_jobs, const bbband_job *jobs,
+                       const uint8_t *seqs, int64_t seq_bytes, bbband_result *results);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,3 +190,14 @@ def calc_affine_score(locArray, baseScores, minContig=0):
     la = np.asarray(locArray, np.int32).copy()
     bs = np.asarray(baseScores, np.int8).copy()
     return L.orc_calc_affine_score(_p(la, c_i32p), len(la), _p(bs, c_i8p), minContig)
+
+
+def banded_align(direction, query, ref, qstart, rstart, maxEdits, exact, maxWidth, variant=0):
+    """direction: 0 forward, 1 forwardRC, 2 reverse, 3 reverseRC; variant 0 = JNI C, 1 = Java concrete.
+    Returns (edits, [lastQueryLoc, lastRefLoc, lastRow, lastEdits, lastOffset])."""
+    L = lib()
+    q, r = _u8(query), _u8(ref)
+    out = np.zeros(5, np.int32)
+    e = L.orc_banded_align(direction, _p(q, c_u8p), len(query), _p(r, c_u8p), len(ref), qstart, rstart,
+                           maxEdits, 1 if exact else 0, maxWidth, variant, _p(out, c_i32p))
+    return e, out.tolist()
