@@ -1,0 +1,893 @@
+// k-mer index probe (align2.BBIndex.findAdvanced) on gfx950.
+//
+// Layout in HBM: per block the CSR arrays of the reference (starts[4^k+1], sites[]; current/align2/Block.java:
+// 162-165), COUNTS[4^k], the 1001-entry length histogram, and every chromosome's byte array; all uploaded once by
+// bbidx_create and shared by every launch.
+//
+// Mapping: ONE READ PER LANE.  BBIndex.find is an order-dependent state machine per read (cutoffs, the
+// bestScores[6] array and the previous-site subsumption are carried across strands and blocks),
+// so the parallelism is across reads; a lane's working arrays (keys, list cursors, the per-base location array)
+// live in its private (scratch) memory, which the hardware interleaves across lanes.  The reference's binary heap
+// (QuadHeap) only ever exposes its minimum under the total order (site, column), so it is replaced by a scan
+// over the list heads with the same tie-break.
+//
+// Functions follow, in this order, current/align2/BBIndex.java: calcApproxHitsCutoff :3267-3294, maxScoreZ
+// :2948-2964, maxQuickScore :2473-2487, scoreZ2 :2882-2914, scoreLeft/Right :2967-3035, quickScore :2490-2511
+// (+ AbstractIndex.scoreY, AbstractIndex.java:52-78), findMaxQscore2 :2294-2450, extendScore :2558-2833
+// (+ MultiStateAligner11tsJNI.calcAffineScore :871-1027), makeGapArray :2837-2878, SiteScore.setPerfect
+// (current/stream/SiteScore.java:239-292), slowWalk3 :1219-1706, trimExcessHitListsByGreedy :266-350
+// (+ Solver.valueOfElement/findWorstGreedy, current/align2/Solver.java:46-151), find :403-639,
+// prescanAllBlocks :642-741.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "bbmap_amd.h"
+
+void bbmap_set_error(const char *msg);   // msa_host.hip
+
+namespace bbidx {
+
+constexpr int KB = BBIDX_MAX_KEYS;
+constexpr int MAXLEN = BBIDX_MAX_READ_LEN;
+constexpr int BASE_HIT_SCORE = 100, Z_MULT = 20, Y_MULT = 10, SMALL_LIST = 20, MIN_LISTS_RETAIN = 6, MINGAP = 256;
+constexpr float HIT_FRACTION_TO_RETAIN = 0.85f, MIN_SCORE_MULT = 0.15f, MIN_QSCORE_MULT = 0.025f, MIN_QSCORE_MULT2 = 0.1f;
+constexpr float DYN_SCORE = 0.84f, DYN_QSCORE = 0.6f, DYN_QSCORE_PERFECT = 0.8f;
+#define PRESCAN_QSCORE_THRESH (DYN_QSCORE * .95f)
+
+struct DevIndex {
+    bbidx_params p;
+    int nblocks, nchroms;
+    const int *const *starts;
+    const int *const *sites;
+    const int *counts;
+    const int *lengthHistogram;
+    const uint8_t *const *chromArr;
+    const int *chromArrLen;
+    const int *chromLengths;
+};
+
+struct Params {
+    DevIndex ix;
+    const bbidx_read *reads;
+    const uint8_t *bases;
+    const int8_t *baseScores;
+    const int *keyinfo;
+    bbidx_site *sites;
+    int *nsites;
+    long long nreads;
+    int maxSites;
+    unsigned int *queue;
+};
+
+__device__ inline int base_num(int b) {
+    switch (b) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2;
+                 case 'T': case 't': case 'U': case 'u': return 3; default: return -1; }
+}
+__device__ inline int rc_key(int kmer, int k) {
+    int out = 0;
+    for (int i = 0; i < k; i++) { out = (out << 2) | ((~kmer) & 3); kmer >>= 2; }
+    return out;
+}
+// dna/AminoAcid.java:633-645 (baseToComplementExtended); 0xFF where the reference holds -1
+__device__ inline int complement_extended(int b) {
+    switch (b) {
+        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+        case 'M': return 'K'; case 'R': return 'Y'; case 'S': return 'W'; case 'V': return 'B';
+        case 'W': return 'S'; case 'Y': return 'R'; case 'H': return 'D'; case 'K': return 'M';
+        case 'D': return 'H'; case 'B': return 'V'; case 'N': return 'N'; case 'X': return 'X';
+        case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
+        case 'm': return 'k'; case 'r': return 'y'; case 's': return 'w'; case 'v': return 'b';
+        case 'w': return 's'; case 'y': return 'r'; case 'h': return 'd'; case 'k': return 'm';
+        case 'd': return 'h'; case 'b': return 'v'; case 'n': return 'n'; case 'x': return 'x';
+        case 'U': return 'A'; case 'u': return 'a';
+        case '?': return '?'; case ' ': return ' '; case '-': return '-'; case '*': return '*'; case '.': return '.';
+    }
+    return 0xFF;
+}
+__device__ inline int absdif(int a, int b) { return a > b ? a - b : b - a; }
+
+// the read as one strand sees it: plus = bytes as given; minus = reverse complement, base scores reversed
+struct Strand {
+    const uint8_t *b; const int8_t *q; int len; bool minus;
+    __device__ inline int base(int i) const { return minus ? complement_extended(b[len - 1 - i]) : b[i]; }
+    __device__ inline int bscore(int i) const { return minus ? q[len - 1 - i] : q[i]; }
+};
+
+struct Codec {
+    int shift, siteMask, lowMask, highMask, cpb;
+    __device__ inline int toNumber(int site, int chrom) const { return ((chrom & lowMask) << shift) | site; }
+    __device__ inline int chromOf(int number, int baseChrom) const { return (int)((unsigned)number >> shift) + (baseChrom & highMask); }
+    __device__ inline int siteOf(int number) const { return number & siteMask; }
+    __device__ inline int baseChrom(int chrom) const { return max(0, chrom & highMask); }
+};
+
+struct Walker {
+    const DevIndex *ix;
+    Codec c;
+    int k, baseKeyHitScore, indelPenalty, indelPenaltyMult, maxPenalty, scoreZ1Key;
+};
+
+struct Lists {
+    int n, nlive;
+    int row[KB], stop[KB], value[KB], offs[KB], kscore[KB];
+    bool live[KB];
+    const int *sites;
+};
+
+__device__ int calcApproxHitsCutoff(const bbidx_params &p, int keys, int hits, int currentCutoff, bool perfect) {
+    const int reduction = min(max(hits / p.hitReductionDiv, p.maxHitsReduction2), max(p.maximumMaxHitsReduction, keys / 8));
+    int r = max(p.minApproxHitsToKeep, max(currentCutoff, hits - reduction));
+    if (perfect) r = max(r, keys);
+    return r;
+}
+__device__ int maxScoreZ(const Walker &w, const int *offsets, int n) {
+    int score = 0, a0 = -1, b0 = -1;
+    for (int i = 0; i < n; i++) { const int a = offsets[i]; if (b0 < a) { score += b0 - a0; a0 = a; } b0 = a + w.k; }
+    return (score + b0 - a0) * Z_MULT;
+}
+__device__ int maxQuickScore(const Walker &w, const int *offsets, const int *keyScores, int n) {
+    int x = 0;
+    for (int i = 0; i < n; i++) x += keyScores[i];
+    return x + maxScoreZ(w, offsets, n) + Y_MULT * (offsets[n - 1] - offsets[0]);
+}
+__device__ int scoreZ2(const Walker &w, const int *locs, int centerIndex, const int *offsets, int numApproxHits, int numHits) {
+    if (numApproxHits == 1) return w.scoreZ1Key;
+    const int center = locs[centerIndex];
+    const int maxLoc = center + w.ix->p.maxIndel2, minLoc = max(0, center - w.ix->p.maxIndel);
+    int score = 0, a0 = -1, b0 = -1;
+    for (int i = 0; i < numHits; i++) {
+        const int loc = locs[i];
+        if (loc >= minLoc && loc <= maxLoc) { const int a = offsets[i]; if (b0 < a) { score += b0 - a0; a0 = a; } b0 = a + w.k; }
+    }
+    return (score + b0 - a0) * Z_MULT;
+}
+__device__ int scoreSide(const Walker &w, const int *locs, const int *keyScores, int centerIndex, int numHits, int dir) {
+    int score = 0, prev, loc = locs[centerIndex];
+    for (int i = centerIndex + dir; i >= 0 && i < numHits; i += dir) {
+        if (locs[i] >= 0) {
+            prev = loc; loc = locs[i];
+            const int offset = absdif(loc, prev);
+            if (offset <= w.ix->p.maxIndel) {
+                score += keyScores[i];
+                if (offset != 0) score -= min(w.indelPenalty + w.indelPenaltyMult * offset, w.maxPenalty);
+            } else loc = prev;
+        }
+    }
+    return score;
+}
+__device__ int quickScore(const Walker &w, const int *locs, const int *keyScores, int centerIndex, const int *offsets,
+                          int numApproxHits, int numHits) {
+    if (numApproxHits == 1) return keyScores[centerIndex];
+    const int x = keyScores[centerIndex] + scoreSide(w, locs, keyScores, centerIndex, numHits, -1)
+                + scoreSide(w, locs, keyScores, centerIndex, numHits, +1) - centerIndex;
+    const int center = locs[centerIndex];
+    int rightIndex = -1;
+    for (int i = numHits - 1; rightIndex < centerIndex; i--) if (locs[i] == center) rightIndex = i;
+    return x + Y_MULT * (offsets[rightIndex] - offsets[centerIndex]);
+}
+
+__device__ inline int adjustSite(const Walker &w, int a, int offset, int baseChrom) {
+    if ((a & w.c.siteMask) >= offset) return a - offset;
+    const int ch = w.c.chromOf(a, baseChrom), st = w.c.siteOf(a);
+    return w.c.toNumber(max(st - offset, 0), ch);
+}
+__device__ void listsInit(const Walker &w, Lists &L, int block, const int *starts, const int *stops, const int *offsets,
+                          const int *keyScores, int n, int baseChrom) {
+    L.n = 0; L.sites = w.ix->sites[block];
+    for (int i = 0; i < n; i++) {
+        if (starts[i] < 0) continue;
+        const int j = L.n++;
+        L.row[j] = starts[i]; L.stop[j] = stops[i]; L.offs[j] = offsets[i]; L.kscore[j] = keyScores[i];
+        L.value[j] = adjustSite(w, L.sites[starts[i]], offsets[i], baseChrom);
+        L.live[j] = true;
+    }
+    L.nlive = L.n;
+}
+__device__ inline int listsPeek(const Lists &L) {      // QuadHeap.peek(): minimum under (site, column)
+    int best = -1;
+    for (int i = 0; i < L.n; i++) if (L.live[i] && (best < 0 || L.value[i] < L.value[best])) best = i;
+    return best;
+}
+
+__device__ void findMaxQscore2(const Walker &w, Lists &L, int baseChrom, int prevMaxHits, bool perfectOnly, int &outQ, int &outHits) {
+    const bbidx_params &p = w.ix->p;
+    const int numHits = L.n;
+    const int mqs = maxQuickScore(w, L.offs, L.kscore, numHits);
+    int topQscore = -999999999, maxHits = 0, approxHitsCutoff, indelCutoff;
+    if (perfectOnly) { approxHitsCutoff = numHits; indelCutoff = 0; }
+    else { approxHitsCutoff = max(prevMaxHits, min(p.minApproxHitsToKeep, numHits - 1)); indelCutoff = p.maxIndel2; }
+    while (L.nlive > 0) {
+        const int centerIndex = listsPeek(L);
+        const int site = L.value[centerIndex];
+        int approxHits = 0;
+        {
+            const int minsite = site - min(p.maxIndel, indelCutoff), maxsite = site + p.maxIndel2;
+            for (int column = 0, chances = numHits - approxHitsCutoff; column < numHits && chances >= 0; column++) {
+                const int x = L.value[column];
+                if (x >= minsite && x <= maxsite) approxHits++; else chances--;
+            }
+        }
+        if (approxHits >= approxHitsCutoff) {
+            const int qscore = quickScore(w, L.value, L.kscore, centerIndex, L.offs, approxHits, numHits)
+                             + scoreZ2(w, L.value, centerIndex, L.offs, approxHits, numHits);
+            if (qscore > topQscore) {
+                maxHits = max(approxHits, maxHits);
+                approxHitsCutoff = max(approxHitsCutoff, approxHits - 1);
+                topQscore = qscore;
+                if (qscore >= mqs) { outQ = topQscore; outHits = maxHits; return; }
+            }
+        }
+        for (;;) {
+            const int col = listsPeek(L);
+            if (col < 0 || L.value[col] != site) break;
+            const int row = L.row[col] + 1;
+            if (row < L.stop[col]) { L.row[col] = row; L.value[col] = adjustSite(w, L.sites[row], L.offs[col], baseChrom); }
+            else {
+                L.live[col] = false; L.nlive--;
+                if (perfectOnly || L.nlive < approxHitsCutoff) { outQ = topQscore; outHits = maxHits; return; }
+            }
+            if (L.nlive == 0) break;
+        }
+    }
+    outQ = topQscore; outHits = maxHits;
+}
+
+// MultiStateAligner11tsJNI.calcAffineScore(locArray, baseScores, bases[, minContig]) in plain points
+__device__ inline int calcDelScoreApprox(int len) {      // MultiStateAligner11tsJNI.java:1347-1376 with approximateGaps
+    if (len <= 0) return 0;
+    int score = -472;
+    if (len > MINGAP) { const int rem = len % 128, div = (len - 128) / 128; score += div * -2; len = rem + 128; }
+    if (len > 80) { score += ((len - 80 + 3) / 4) * -1; len = 80; }
+    if (len > 20) { score += (len - 20) * -1; len = 20; }
+    if (len > 5) { score += (len - 5) * -9; len = 5; }
+    if (len > 1) score += (len - 1) * -33;
+    return score;
+}
+__device__ inline int insCum(int n) {                    // POINTS_INS_ARRAY_C[n], n in 1..5
+    return -395 + (n > 1 ? (n - 1) * -39 : 0);
+}
+__device__ inline int subArr(int t) { return t > 5 ? -25 : (t > 1 ? -51 : -127); }   // POINTS_SUB_ARRAY[t]
+__device__ int calcAffineScore(const int *locArray, int n, const Strand &rd, int minContig) {
+    int contig = 0, maxContig = 0, score = 0, lastLoc = -3, lastValue = -1, timeInMode = 0;
+    for (int i = 0; i < n; i++) {
+        const int loc = locArray[i];
+        if (loc > 0) {
+            if (loc == lastValue) { contig++; score += 100 + rd.bscore(i); }
+            else if (loc == lastLoc || lastLoc < 0) { maxContig = max(maxContig, contig); contig = 1; score += 70 + rd.bscore(i); }
+            else if (loc < lastLoc) {
+                maxContig = max(maxContig, contig); contig = 0;
+                score += 70 + rd.bscore(i) + calcDelScoreApprox(lastLoc - loc + 1);
+                timeInMode = 1;
+            } else {
+                maxContig = max(maxContig, contig); contig = 0;
+                score += 70 + rd.bscore(i) + insCum(min(loc - lastLoc, 5));
+                timeInMode = 1;
+            }
+            lastLoc = loc;
+        } else if (loc == -1) {
+            if (lastValue < 0 && timeInMode > 0) { timeInMode++; score += subArr(timeInMode); }
+            else { score += -127; timeInMode = 1; }
+        } else { timeInMode = 0; }
+        lastValue = loc;
+    }
+    if (minContig > 1 && max(contig, maxContig) < minContig) score = min(score, -50 * n);
+    return score;
+}
+
+__device__ int extendScore(const Walker &w, const Strand &rd, const int *offsets, const int *values, int chrom, int centerIndex,
+                           int *locArray, int numHits) {
+    const bbidx_params &p = w.ix->p;
+    const int blen = rd.len;
+    const int centerVal = values[centerIndex], centerLoc = w.c.siteOf(centerVal);
+    const int minVal = centerVal - p.maxIndel, maxVal = centerVal + p.maxIndel2;
+    const uint8_t *ref = w.ix->chromArr[chrom];
+    const int reflen = w.ix->chromArrLen[chrom];
+    for (int i = 0; i < blen; i++) locArray[i] = -1;
+    for (int i = 0, keynum = 0; i < numHits; i++) {
+        const int value = values[i];
+        if (value >= minVal && value <= maxVal) {
+            const int refbase = w.c.siteOf(value);
+            keynum++;
+            int misses = 0;
+            for (int cloc = offsets[i] + w.k - 1, rloc = refbase + cloc; cloc >= 0 && rloc >= 0 && rloc < reflen; cloc--, rloc--) {
+                const int old = locArray[cloc];
+                if (old == refbase) break;
+                if (misses > 0 && old >= 0) break;
+                if (rd.base(cloc) == ref[rloc]) { if (old < 0 || refbase == centerLoc) locArray[cloc] = refbase; }
+                else { misses++; if (old >= 0 || keynum > 1) break; }
+            }
+        }
+    }
+    for (int i = 0; i < numHits; i++) {
+        const int value = values[i];
+        if (value >= minVal && value <= maxVal) {
+            const int refbase = w.c.siteOf(value);
+            int misses = 0;
+            for (int cloc = offsets[i] + w.k, rloc = refbase + cloc; cloc < blen && rloc < reflen; cloc++, rloc++) {
+                const int old = locArray[cloc];
+                if (old == refbase) break;
+                if (misses > 0 && old >= 0) break;
+                if (rd.base(cloc) == ref[rloc]) { if (old < 0 || refbase == centerLoc) locArray[cloc] = refbase; }
+                else { misses++; if (old >= 0) break; }
+            }
+        }
+    }
+    for (int i = 0; i < blen; i++) if (rd.base(i) == 'N') locArray[i] = -2;
+    return calcAffineScore(locArray, blen, rd, p.kfilter);
+}
+
+__device__ int makeGapArray(int *locArray, int n, int minLoc, int minGap, int *out, int cap) {
+    int gaps = 0; bool doSort = false;
+    if (locArray[0] < 0) locArray[0] = minLoc;
+    for (int i = 1; i < n; i++) {
+        if (locArray[i] < 0) locArray[i] = locArray[i - 1] + 1; else locArray[i] += i;
+        if (locArray[i] < locArray[i - 1]) doSort = true;
+    }
+    if (doSort) {                                        // Arrays.sort: insertion sort is enough for <=600 nearly sorted ints
+        for (int i = 1; i < n; i++) { const int v = locArray[i]; int j = i - 1; while (j >= 0 && locArray[j] > v) { locArray[j + 1] = locArray[j]; j--; } locArray[j + 1] = v; }
+    }
+    for (int i = 1; i < n; i++) if (locArray[i] - locArray[i - 1] > minGap) gaps++;
+    if (gaps < 1) return 0;
+    const int len = 2 + gaps * 2;
+    if (len > cap) return -1;
+    out[0] = locArray[0]; out[len - 1] = locArray[n - 1];
+    for (int i = 1, j = 1; i < n; i++) if (locArray[i] - locArray[i - 1] > minGap) { out[j] = locArray[i - 1]; out[j + 1] = locArray[i]; j += 2; }
+    return len;
+}
+
+__device__ void setPerfect(const DevIndex &ix, bbidx_site &ss, const Strand &rd) {
+    const int blen = rd.len;
+    if (blen != ss.stop - ss.start + 1) { ss.perfect = 0; ss.semiperfect = 0; return; }
+    const uint8_t *ref = ix.chromArr[ss.chrom];
+    const int reflen = ix.chromArrLen[ss.chrom];
+    bool perfect = true, semiperfect = true;
+    int refloc = ss.start, readloc = 0, N = 0;
+    const int mx = min(ss.stop, reflen - 1), nlimit = blen / 2;
+    if (ss.start < 0) { N -= ss.start; readloc -= ss.start; refloc -= ss.start; perfect = false; }
+    if (ss.stop >= reflen) { N += (ss.stop - reflen + 1); perfect = false; }
+    if (N > nlimit) { ss.perfect = ss.semiperfect = 0; return; }
+    for (; refloc <= mx; refloc++, readloc++) {
+        const int c = rd.base(readloc), r = ref[refloc];
+        if (c != r || c == 'N') {
+            perfect = false;
+            if (c == 'N') semiperfect = false;
+            if (r != 'N' || (N = N + 1) > nlimit) { ss.perfect = perfect; ss.semiperfect = 0; return; }
+        }
+    }
+    semiperfect = semiperfect && (N <= nlimit);
+    perfect = perfect && semiperfect && (N == 0);
+    ss.perfect = perfect; ss.semiperfect = semiperfect;
+}
+__device__ inline bool overlap(int a1, int b1, int a2, int b2) { return a2 <= b1 && b2 >= a1; }
+
+struct SiteList { bbidx_site *v; int n, cap; bool overflow; };
+
+__device__ void slowWalk3(const Walker &w, Lists &L, int *locArray, int block, const int *starts, const int *stops,
+                          const Strand &rd, const int *keyScores, const int *offsets, int numKeys, int baseChrom_, int strand,
+                          SiteList &ssl, int *bestScores, bool allBasesCovered, int maxScore, bool fullyDefined) {
+    const bbidx_params &p = w.ix->p;
+    const int blen = rd.len;
+    const int mqs = maxQuickScore(w, offsets, keyScores, numKeys);
+    const int baseChrom = w.c.baseChrom(baseChrom_);
+    listsInit(w, L, block, starts, stops, offsets, keyScores, numKeys, baseChrom);
+    const int numHits = L.n;
+    const bool filter_by_qscore = numKeys >= 5;
+    const int minScore = (int)(MIN_SCORE_MULT * maxScore);
+    const int minQuickScore = (int)(MIN_QSCORE_MULT * mqs);
+    int currentTopScore = bestScores[0];
+    int cutoff = max(minScore, (int)(currentTopScore * DYN_SCORE));
+    int qcutoff = max(bestScores[2], minQuickScore);
+    int bestqscore = bestScores[3], maxHits = bestScores[1], perfectsFound = bestScores[5];
+    int approxHitsCutoff = calcApproxHitsCutoff(p, numKeys, maxHits, p.minApproxHitsToKeep, currentTopScore >= maxScore);
+    if (approxHitsCutoff > numHits) return;
+    const bool shortCircuit = allBasesCovered && numKeys == numHits && filter_by_qscore;
+    if (currentTopScore >= maxScore) qcutoff = max(qcutoff, (int)(mqs * DYN_QSCORE_PERFECT));
+
+    int prevIdx = -1;
+    bool finished = false;
+    while (L.nlive > 0 && !finished) {
+        const int centerIndex = listsPeek(L);
+        const int site = L.value[centerIndex];
+        int maxNearbySite = site, approxHits = 0;
+        {
+            const int minsite = site - p.maxIndel, maxsite = site + p.maxIndel2;
+            for (int column = 0, chances = numHits - approxHitsCutoff; column < numHits && chances >= 0; column++) {
+                const int x = L.value[column];
+                if (x >= minsite && x <= maxsite) { if (x > maxNearbySite) maxNearbySite = x; approxHits++; } else chances--;
+            }
+        }
+        if (approxHits >= approxHitsCutoff) {
+            int score;
+            int qscore = filter_by_qscore ? quickScore(w, L.value, L.kscore, centerIndex, L.offs, approxHits, numHits) : qcutoff;
+            qscore += scoreZ2(w, L.value, centerIndex, L.offs, approxHits, numHits);
+            int mapStart = site, mapStop = maxNearbySite;
+            bool locArrayValid = false;
+            if (qscore < qcutoff) score = -1;
+            else {
+                const int chrom = w.c.chromOf(site, baseChrom);
+                if (shortCircuit && qscore == mqs) score = maxScore;
+                else {
+                    score = extendScore(w, rd, L.offs, L.value, chrom, centerIndex, locArray, numHits);
+                    locArrayValid = true;
+                    int mn = INT_MAX, mx = INT_MIN;
+                    for (int i = 0; i < blen; i++) { const int x = locArray[i]; if (x > -1) { if (x < mn) mn = x; if (x > mx) mx = x; } }
+                    if (mn < 0 || mx < 0) score = -99999;
+                    mapStart = w.c.toNumber(mn, chrom);
+                    mapStop = w.c.toNumber(mx, chrom);
+                }
+                if (score == maxScore) {
+                    qcutoff = max(qcutoff, (int)(mqs * DYN_QSCORE_PERFECT));
+                    approxHitsCutoff = calcApproxHitsCutoff(p, numKeys, maxHits, p.minApproxHitsToKeep, true);
+                }
+                if (score >= cutoff) { qcutoff = max(qcutoff, (int)(qscore * DYN_QSCORE)); bestqscore = max(qscore, bestqscore); }
+            }
+            if (score >= cutoff) {
+                if (score > currentTopScore) {
+                    maxHits = max(approxHits, maxHits);
+                    approxHitsCutoff = calcApproxHitsCutoff(p, numKeys, maxHits, approxHitsCutoff, currentTopScore >= maxScore);
+                    cutoff = max(cutoff, (int)(score * DYN_SCORE));
+                    if (score >= maxScore) cutoff = max(cutoff, (int)(score * 0.95f));
+                    currentTopScore = score;
+                }
+                const int chrom = w.c.chromOf(mapStart, baseChrom);
+                const int site2 = w.c.siteOf(mapStart);
+                const int site3 = w.c.siteOf(mapStop) + blen - 1;
+                int gapArr[BBIDX_MAX_GAPS]; int ngaps = 0;
+                if (site3 - site2 >= MINGAP + blen && locArrayValid) {
+                    ngaps = makeGapArray(locArray, blen, site2, MINGAP, gapArr, BBIDX_MAX_GAPS);
+                    if (ngaps < 0) ngaps = 0;
+                    if (ngaps > 0) { gapArr[0] = min(gapArr[0], site2); gapArr[ngaps - 1] = max(gapArr[ngaps - 1], site3); }
+                }
+                bbidx_site ss; bool haveSS = false;
+                const bool perfect1 = (score == maxScore && fullyDefined);
+                const bool inbounds = (site2 >= 0 && site3 < w.ix->chromLengths[chrom]);
+                bbidx_site *prevSS = prevIdx >= 0 ? &ssl.v[prevIdx] : nullptr;
+                auto newSite = [&](bool withGaps) {
+                    ss.chrom = chrom; ss.strand = strand; ss.start = site2; ss.stop = site3; ss.hits = approxHits; ss.score = score;
+                    ss.perfect = ss.semiperfect = perfect1 ? 1 : 0;
+                    ss.ngaps = 0;
+                    for (int g = 0; g < BBIDX_MAX_GAPS; g++) ss.gaps[g] = 0;
+                    if (!perfect1) setPerfect(*w.ix, ss, rd);
+                    if (withGaps) { ss.ngaps = ngaps; for (int g = 0; g < ngaps; g++) ss.gaps[g] = gapArr[g]; }
+                    haveSS = true;
+                };
+                if (inbounds && ngaps == 0 && prevSS && prevSS->chrom == chrom && prevSS->strand == strand &&
+                    overlap(prevSS->start, prevSS->stop, site2, site3)) {
+                    const int betterScore = max(score, prevSS->score);
+                    const int minStart = min(prevSS->start, site2), maxStop = max(prevSS->stop, site3);
+                    const bool perfect2 = (prevSS->score == maxScore && fullyDefined);
+                    const bool shortEnough = (maxStop - minStart < 2 * blen);
+                    if (prevSS->start == site2 && prevSS->stop == site3) {
+                        prevSS->score = betterScore;
+                        prevSS->perfect = (prevSS->perfect || perfect1 || perfect2) ? 1 : 0;
+                        if (prevSS->perfect) prevSS->semiperfect = 1;
+                    } else if (shortEnough && prevSS->start == site2 && !prevSS->semiperfect) {
+                        if (perfect2) { }
+                        else if (perfect1) {
+                            prevSS->stop = site3; if (prevSS->ngaps) prevSS->gaps[prevSS->ngaps - 1] = site3;
+                            if (!prevSS->perfect) perfectsFound++;
+                            prevSS->perfect = prevSS->semiperfect = 1;
+                        } else {
+                            prevSS->stop = maxStop; if (prevSS->ngaps) prevSS->gaps[prevSS->ngaps - 1] = maxStop;
+                            setPerfect(*w.ix, *prevSS, rd);
+                        }
+                        prevSS->score = betterScore;
+                    } else if (shortEnough && prevSS->stop == site3 && !prevSS->semiperfect) {
+                        if (perfect2) { }
+                        else if (perfect1) {
+                            prevSS->start = site2; if (prevSS->ngaps) prevSS->gaps[0] = site2;
+                            if (!prevSS->perfect) perfectsFound++;
+                            prevSS->perfect = prevSS->semiperfect = 1;
+                        } else {
+                            prevSS->start = minStart; if (prevSS->ngaps) prevSS->gaps[0] = minStart;
+                            setPerfect(*w.ix, *prevSS, rd);
+                        }
+                        prevSS->score = betterScore;
+                    } else newSite(false);
+                } else if (inbounds) newSite(true);
+                if (haveSS) {
+                    if (ssl.n >= ssl.cap) { ssl.overflow = true; finished = true; }
+                    else {
+                        ssl.v[ssl.n] = ss;
+                        const int idx = ssl.n++;
+                        if (ss.perfect) {
+                            const bbidx_site *pv = prevIdx >= 0 ? &ssl.v[prevIdx] : nullptr;
+                            if (!pv || !pv->perfect || !(pv->chrom == ss.chrom && pv->strand == ss.strand && overlap(ss.start, ss.stop, pv->start, pv->stop))) {
+                                perfectsFound++;
+                                if (p.quitAfterTwoPerfects && perfectsFound >= 2) { prevIdx = idx; break; }
+                            }
+                        }
+                        prevIdx = idx;
+                    }
+                }
+            }
+        }
+        for (;;) {
+            const int col = listsPeek(L);
+            if (col < 0 || L.value[col] != site) break;
+            const int row = L.row[col] + 1;
+            if (row < L.stop[col]) { L.row[col] = row; L.value[col] = adjustSite(w, L.sites[row], L.offs[col], baseChrom); }
+            else {
+                L.live[col] = false; L.nlive--;
+                if (L.nlive < approxHitsCutoff) { finished = true; break; }
+            }
+            if (L.nlive == 0) break;
+        }
+    }
+    bestScores[0] = max(bestScores[0], currentTopScore);
+    bestScores[1] = max(bestScores[1], maxHits);
+    bestScores[2] = max(bestScores[2], qcutoff);
+    bestScores[3] = max(bestScores[3], bestqscore);
+    bestScores[4] = mqs;
+    bestScores[5] = perfectsFound;
+}
+
+__device__ long long valueOfElement(const int *offsets, int noffsets, const int *lengths, float keyWeight, int chunk,
+                                    const int *lists, int numlists, int index, long long pointsPerSite) {
+    const long long PPL = 30000, PPB1 = 6000, BONUS_END = 40000, WIDTH = 5500, SPACING = -30;
+    if (numlists < 1) return 0;
+    const int prospect = lists[index];
+    if (lengths[prospect] == 0) return -999999;
+    long long valuep = PPL + (PPL * 2 / numlists) + ((PPL * 10) / lengths[prospect]);
+    const long long valuem = pointsPerSite * lengths[prospect];
+    if (prospect == 0 || prospect == noffsets - 1) valuep += BONUS_END;
+    if (numlists == 1) { valuep += (WIDTH + PPB1) * chunk; return ((long long)__fmul_rn((float)valuep, keyWeight)) + valuem; }
+    const int first = lists[0], last = lists[numlists - 1];
+    const int offL = (prospect == first ? -1 : offsets[lists[index - 1]]);
+    const int offP = offsets[prospect];
+    const int offR = (prospect == last ? offsets[noffsets - 1] + 1 : offsets[lists[index + 1]]);
+    const int oldL = offP - offL, oldR = offR - offP, newS = offR - offL;
+    valuep += (long long)((oldL * oldL + oldR * oldR) - (newS * newS)) * SPACING;
+    int uniquelyCovered;
+    if (prospect == first) uniquelyCovered = offR - offP;
+    else if (prospect == last) uniquelyCovered = offP - offL;
+    else { const int b = offR - (offL + chunk); uniquelyCovered = b > 0 ? b : 0; }
+    if (prospect == first || prospect == last) valuep += (PPB1 + WIDTH) * uniquelyCovered;
+    else valuep += PPB1 * uniquelyCovered;
+    return ((long long)__fmul_rn((float)valuep, keyWeight)) + valuem;
+}
+
+__device__ int trimByGreedy(const DevIndex &ix, const int *offsets, const int *keyScores, int n, int maxHitLists, int *keys,
+                            int baseKeyHitScore, int *lengths, int *lists) {
+    const bbidx_params &p = ix.p;
+    const float inv = __fdiv_rn(1.0f, (float)baseKeyHitScore);
+    const int limit = max(SMALL_LIST, ix.lengthHistogram[p.maxAverageListToSearch]) * n;
+    const int limit2 = max(SMALL_LIST, ix.lengthHistogram[p.maxAverageListToSearch2]);
+    const int limit3 = max(SMALL_LIST, ix.lengthHistogram[p.maxShortestListToSearch]);
+    int sum = 0, initialHitCount = 0, shortest = INT_MAX - 1, shortest2 = INT_MAX;
+    for (int i = 0; i < n; i++) {
+        const int x = ix.counts[keys[i]];
+        lengths[i] = x; sum += x; initialHitCount += (x == 0 ? 0 : 1);
+        if (x > 0 && x < shortest2) { shortest2 = x; if (shortest2 < shortest) { shortest2 = shortest; shortest = x; } }
+    }
+    if (initialHitCount < p.minApproxHitsToKeep) return initialHitCount;
+    if (shortest > limit3 && !p.slow) { for (int i = 0; i < n; i++) keys[i] = -1; return 0; }
+    int hitsCount = initialHitCount;
+    const long long EARLY = -50LL * 2000;
+    while (hitsCount >= p.minApproxHitsToKeep && (sum > limit || sum / initialHitCount > limit2 || hitsCount > maxHitLists)) {
+        for (int i = 0, j = 0; j < hitsCount; i++) if (lengths[i] > 0) lists[j++] = i;
+        long long mn = LLONG_MAX, worstValue64 = 0; int worstIndex = -1; bool early = false;
+        for (int i = 0; i < hitsCount; i++) {
+            const float kw = __fmul_rn((float)keyScores[i], inv);          // weights[i]: indexed by list position, as in the reference
+            const long long value = valueOfElement(offsets, n, lengths, kw, p.k, lists, hitsCount, i, p.pointsPerSite);
+            if (value < mn) {
+                if (mn < EARLY && i != 0) { worstIndex = i; worstValue64 = value; early = true; break; }
+                mn = value; worstIndex = i;
+            }
+        }
+        if (!early) worstValue64 = mn;
+        const int worstValue = worstValue64 < INT_MIN ? INT_MIN : (worstValue64 > INT_MAX ? INT_MAX : (int)worstValue64);
+        const int worst = lists[worstIndex];
+        sum -= lengths[worst];
+        if (worstValue > 0 || lengths[worst] < SMALL_LIST) return hitsCount;
+        hitsCount--; lengths[worst] = 0; keys[worst] = -1;
+    }
+    return hitsCount;
+}
+
+__device__ int countHits(const DevIndex &ix, int *keys, int n, int maxLen) {
+    int numHits = 0;
+    for (int i = 0; i < n; i++) {
+        const int key = keys[i];
+        if (key >= 0) { const int len = ix.counts[key]; if (len > 0 && len < maxLen) numHits++; else keys[i] = -1; }
+    }
+    return numHits;
+}
+__device__ int shrink2(int *offsets, int *keys, int *keyScores, int n) {
+    int j = 0;
+    for (int i = 0; i < n; i++) if (keys[i] >= 0) { offsets[j] = offsets[i]; keys[j] = keys[i]; keyScores[j] = keyScores[i]; j++; }
+    return j;
+}
+__device__ int getHits(const DevIndex &ix, const int *keys, int n, int block, int *starts, int *stops) {
+    int numHits = 0;
+    const int *bs = ix.starts[block], *st = ix.sites[block];
+    for (int i = 0; i < n; i++) {
+        const int key = keys[i];
+        starts[i] = -1; stops[i] = -1;
+        if (key >= 0 && ix.counts[key] > 0) {
+            const int s0 = bs[key], x = bs[key + 1] - s0;
+            if (x > 0 && st[s0] != -1) { starts[i] = s0; stops[i] = s0 + x; numHits++; }
+        }
+    }
+    return numHits;
+}
+
+__global__ __launch_bounds__(64) void probe_kernel(const Params P) {
+    const DevIndex &ix = P.ix;
+    const bbidx_params &p = ix.p;
+    Walker w;
+    w.ix = &ix;
+    w.c.shift = 31 - p.chromBits; w.c.siteMask = (int)(0xFFFFFFFFu >> (p.chromBits + 1));
+    w.c.cpb = 1 << p.chromBits; w.c.lowMask = w.c.cpb - 1; w.c.highMask = ~w.c.lowMask;
+    w.k = p.k; w.baseKeyHitScore = BASE_HIT_SCORE * p.k;
+    w.indelPenalty = (w.baseKeyHitScore / 2) - 1; w.indelPenaltyMult = 20;
+    w.maxPenalty = w.baseKeyHitScore - (1 + w.baseKeyHitScore / 8);
+    w.scoreZ1Key = Z_MULT * p.k;
+
+    int keysOriginal[KB], keysP[KB], offsetsP[KB], keyScoresP[KB];
+    int offsetsM[KB], keysM[KB], keyScoresM[KB];
+    int starts[KB], stops[KB];
+    int locArray[MAXLEN];
+    Lists L;
+
+    for (;;) {
+        const long long r = (long long)atomicAdd(P.queue, 1u);
+        if (r >= P.nreads) break;
+        const bbidx_read rr = P.reads[r];
+        const int blen = rr.len;
+        int n = rr.nkeys;
+        bbidx_site *out = P.sites + r * (long long)P.maxSites;
+        if (n < 1 || n > KB || blen < p.k || blen > MAXLEN) { P.nsites[r] = (n < 1 || blen < p.k) ? 0 : -2; continue; }
+        const uint8_t *bP = P.bases + rr.bases_off;
+        const int8_t *qP = P.baseScores + rr.bases_off;
+        const int *koff = P.keyinfo + rr.keys_off, *kscore = koff + n;
+
+        for (int i = 0; i < n; i++) {                                   // KeyRing.makeKeys
+            int key = 0;
+            for (int q = koff[i]; q < koff[i] + p.k; q++) { const int x = base_num(bP[q]); if (x < 0) { key = -1; break; } key = (key << 2) | x; }
+            keysOriginal[i] = keysP[i] = key; offsetsP[i] = koff[i]; keyScoresP[i] = kscore[i];
+        }
+        const int maxLen = p.maxUsableLength;
+        int numHits = countHits(ix, keysP, n, maxLen);
+        if (numHits > 0) {
+            const int trigger = (3 * n) / 4;
+            if (numHits < 4 && numHits < trigger) { for (int i = 0; i < n; i++) keysP[i] = keysOriginal[i]; numHits = countHits(ix, keysP, n, (maxLen * 3) / 2); }
+            if (numHits < 3 && numHits < trigger) { for (int i = 0; i < n; i++) keysP[i] = keysOriginal[i]; numHits = countHits(ix, keysP, n, maxLen * 2); }
+            if (numHits < 3 && numHits < trigger) { for (int i = 0; i < n; i++) keysP[i] = keysOriginal[i]; numHits = countHits(ix, keysP, n, maxLen * 3); }
+            if (numHits < 2 && numHits < trigger) { for (int i = 0; i < n; i++) keysP[i] = keysOriginal[i]; numHits = countHits(ix, keysP, n, maxLen * 5); }
+        }
+        const int nOriginal = n;
+        if (numHits < n) n = shrink2(offsetsP, keysP, keyScoresP, n);
+        if (p.trimByGreedy) {
+            const int maxLists = max((int)(HIT_FRACTION_TO_RETAIN * n), MIN_LISTS_RETAIN);
+            numHits = trimByGreedy(ix, offsetsP, keyScoresP, n, maxLists, keysP, w.baseKeyHitScore, starts, stops);
+        }
+        if (numHits < p.minApproxHitsToKeep) { P.nsites[r] = 0; continue; }
+        if (numHits < n) n = shrink2(offsetsP, keysP, keyScoresP, n);
+        for (int i = 0; i < n; i++) {
+            offsetsM[i] = blen - (offsetsP[n - 1 - i] + p.k);
+            keysM[i] = rc_key(keysP[n - 1 - i], p.k);
+            keyScoresM[i] = keyScoresP[n - 1 - i];
+        }
+        const int mqs = maxQuickScore(w, offsetsP, keyScoresP, n);
+        int bestScores[6] = {0, 0, 0, 0, 0, 0};
+        const bool prescan = p.prescanQscore && numHits >= 5;
+        int hitsCutoff = 0, qscoreCutoff = (int)(MIN_QSCORE_MULT * mqs);
+        bool allBasesCovered = true;
+        if (offsetsP[0] != 0) allBasesCovered = false;
+        else if (offsetsP[n - 1] != (blen - p.k)) allBasesCovered = false;
+        else for (int i = 1; i < n; i++) if (offsetsP[i] > offsetsP[i - 1] + p.k) { allBasesCovered = false; break; }
+        const bool pretend = allBasesCovered || n >= nOriginal - 4 ||
+                             (n >= 9 && (offsetsP[n - 1] - offsetsP[0] + p.k) > max(40, (int)(blen * .75f)));
+
+        // prescanAllBlocks keeps one (count, score) pair per (block, strand); only the comparison against the cutoffs is
+        // needed later, so up to 64 cycles are kept in two 64-bit masks plus the two running maxima.
+        const int cpb = w.c.cpb;
+        int precounts[64], prescores[64];
+        int ncycles = 0;
+        for (int chrom = p.minChrom; chrom <= p.maxChrom; chrom = ((chrom & w.c.highMask) + cpb)) ncycles += 2;
+        if (ncycles > 64) { P.nsites[r] = -2; continue; }
+        bool dead = false;
+        if (prescan) {
+            for (int i = 0; i < ncycles; i++) { precounts[i] = n; prescores[i] = mqs; }
+            int bestqscore = 0, maxHits = 0, minHitsToScore = p.minApproxHitsToKeep, cycle = 0; bool earlyOut = false;
+            for (int chrom = p.minChrom; chrom <= p.maxChrom && !earlyOut; chrom = ((chrom & w.c.highMask) + cpb)) {
+                const int baseChrom = w.c.baseChrom(chrom);
+                const int block = baseChrom >> p.chromBits;
+                for (int pmi = 0; pmi < 2 && !earlyOut; pmi++, cycle++) {
+                    const int *keys = pmi ? keysM : keysP, *ksc = pmi ? keyScoresM : keyScoresP, *offs = pmi ? offsetsM : offsetsP;
+                    const int nh = getHits(ix, keys, n, block, starts, stops);
+                    if (nh < minHitsToScore) { prescores[cycle] = -9999; precounts[cycle] = 0; }
+                    else {
+                        listsInit(w, L, block, starts, stops, offs, ksc, n, baseChrom);
+                        int tq, th;
+                        findMaxQscore2(w, L, baseChrom, minHitsToScore, bestqscore >= mqs && pretend, tq, th);
+                        prescores[cycle] = tq; precounts[cycle] = th;
+                        bestqscore = max(tq, bestqscore); maxHits = max(maxHits, th);
+                        if (bestqscore >= mqs && pretend) { minHitsToScore = max(minHitsToScore, maxHits); earlyOut = true; }
+                    }
+                }
+            }
+            bestScores[1] = max(bestScores[1], maxHits);
+            bestScores[3] = max(bestScores[3], bestqscore);
+            if (bestScores[1] < p.minApproxHitsToKeep) dead = true;
+            else if ((float)bestScores[3] < __fmul_rn((float)mqs, MIN_QSCORE_MULT2)) dead = true;
+            else if (bestScores[3] >= mqs && pretend) {
+                hitsCutoff = calcApproxHitsCutoff(p, n, bestScores[1], p.minApproxHitsToKeep, true);
+                qscoreCutoff = max(qscoreCutoff, (int)(bestScores[3] * DYN_QSCORE_PERFECT));
+            } else {
+                hitsCutoff = calcApproxHitsCutoff(p, n, bestScores[1], p.minApproxHitsToKeep, false);
+                qscoreCutoff = max(qscoreCutoff, (int)(bestScores[3] * PRESCAN_QSCORE_THRESH));
+            }
+        }
+        if (dead) { P.nsites[r] = 0; continue; }
+
+        int sumBS = 0;
+        bool fullyDefined = true;
+        for (int i = 0; i < blen; i++) { sumBS += qP[i]; if (bP[i] >= 128 || base_num(bP[i]) < 0) fullyDefined = false; }
+        const int maxScore = 70 + (blen - 1) * 100 + sumBS;               // msa.maxQuality(baseScores)
+        SiteList ssl; ssl.v = out; ssl.n = 0; ssl.cap = P.maxSites; ssl.overflow = false;
+        int cycle = 0; bool quit = false;
+        for (int chrom = p.minChrom; chrom <= p.maxChrom && !quit; chrom = ((chrom & w.c.highMask) + cpb)) {
+            const int block = w.c.baseChrom(chrom) >> p.chromBits;
+            for (int strand = 0; strand < 2 && !quit; strand++, cycle++) {
+                if (!prescan || precounts[cycle] >= hitsCutoff || prescores[cycle] >= qscoreCutoff) {
+                    const int *keys = strand ? keysM : keysP, *ksc = strand ? keyScoresM : keyScoresP, *offs = strand ? offsetsM : offsetsP;
+                    const int nh = getHits(ix, keys, n, block, starts, stops);
+                    if (nh >= p.minApproxHitsToKeep) {
+                        Strand rd; rd.b = bP; rd.q = qP; rd.len = blen; rd.minus = (strand == 1);
+                        slowWalk3(w, L, locArray, block, starts, stops, rd, ksc, offs, n, chrom, strand, ssl, bestScores,
+                                  allBasesCovered, maxScore, fullyDefined);
+                    }
+                }
+                if (p.quitAfterTwoPerfects && bestScores[5] >= 2) quit = true;
+            }
+        }
+        P.nsites[r] = ssl.overflow ? -1 : ssl.n;
+    }
+}
+
+}  // namespace bbidx
+
+// ------------------------------------------------------------------------------------------------ host side
+struct bbidx_ctx {
+    int device;
+    bbidx::DevIndex dev;
+    std::vector<void *> allocs;
+    unsigned int *d_queue;
+    int blocks;
+};
+
+static thread_local char g_ierr[256];
+#define IHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(g_ierr, sizeof g_ierr, "%s failed: %s", #expr, hipGetErrorString(e_)); bbmap_set_error(g_ierr); return BBMAP_E_HIP; } } while (0)
+static int ifail(int code, const char *m) { bbmap_set_error(m); return code; }
+
+template <typename T>
+static int upload(bbidx_ctx *c, const T *host, size_t count, const T **dev) {
+    void *d = nullptr;
+    IHIP(hipMalloc(&d, (count > 0 ? count : 1) * sizeof(T)));
+    c->allocs.push_back(d);
+    if (count > 0) IHIP(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *dev = (const T *)d;
+    return BBMAP_OK;
+}
+
+extern "C" int bbidx_create(int32_t device, const bbidx_index_desc *d, bbidx_ctx **out) {
+    if (!d || !out) return ifail(BBMAP_E_ARG, "bbidx_create: null argument");
+    *out = nullptr;
+    const bbidx_params &p = d->params;
+    if (p.k < 8 || p.k > 15 || p.chromBits < 0 || p.chromBits > 16 || d->nblocks < 1 || d->nchroms < 1)
+        return ifail(BBMAP_E_ARG, "bbidx_create: bad index geometry (k must be 8..15)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ifail(BBMAP_E_NODEVICE, "bbidx_create: no HIP device (no CPU path)");
+    if (device < 0 || device >= ndev) return ifail(BBMAP_E_ARG, "bbidx_create: bad device ordinal");
+    IHIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    IHIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ifail(BBMAP_E_NODEVICE, "bbidx_create: this build targets gfx950 only");
+    bbidx_ctx *c = new (std::nothrow) bbidx_ctx();
+    if (!c) return ifail(BBMAP_E_NOMEM, "bbidx_create: out of memory");
+    c->device = device;
+    c->blocks = prop.multiProcessorCount * 8;
+    const size_t keyspace = (size_t)1 << (2 * p.k);
+    int rc = BBMAP_OK;
+    std::vector<const int *> hs((size_t)d->nblocks), hsi((size_t)d->nblocks);
+    std::vector<const uint8_t *> hc((size_t)d->nchroms + 1, nullptr);
+    c->dev.p = p; c->dev.nblocks = d->nblocks; c->dev.nchroms = d->nchroms;
+    for (int b = 0; b < d->nblocks && rc == BBMAP_OK; b++) {
+        rc = upload(c, d->starts[b], keyspace + 1, &hs[(size_t)b]);
+        if (rc == BBMAP_OK) rc = upload(c, d->sites[b], (size_t)d->numSites[b], &hsi[(size_t)b]);
+    }
+    for (int ch = 1; ch <= d->nchroms && rc == BBMAP_OK; ch++) rc = upload(c, d->chromArr[ch], (size_t)d->chromArrLen[ch], &hc[(size_t)ch]);
+    if (rc == BBMAP_OK) rc = upload(c, hs.data(), hs.size(), (const int *const **)&c->dev.starts);
+    if (rc == BBMAP_OK) rc = upload(c, hsi.data(), hsi.size(), (const int *const **)&c->dev.sites);
+    if (rc == BBMAP_OK) rc = upload(c, hc.data(), hc.size(), (const uint8_t *const **)&c->dev.chromArr);
+    if (rc == BBMAP_OK) rc = upload(c, d->counts, keyspace, &c->dev.counts);
+    if (rc == BBMAP_OK) rc = upload(c, d->lengthHistogram, (size_t)1001, &c->dev.lengthHistogram);
+    if (rc == BBMAP_OK) rc = upload(c, d->chromArrLen, (size_t)d->nchroms + 1, &c->dev.chromArrLen);
+    if (rc == BBMAP_OK) rc = upload(c, d->chromLengths, (size_t)d->nchroms + 1, &c->dev.chromLengths);
+    if (rc == BBMAP_OK && hipMalloc(&c->d_queue, 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
+    if (rc != BBMAP_OK) { bbidx_destroy(c); return rc; }
+    *out = c;
+    return BBMAP_OK;
+}
+
+extern "C" void bbidx_destroy(bbidx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (void *p : c->allocs) (void)hipFree(p);
+    if (c->d_queue) (void)hipFree(c->d_queue);
+    delete c;
+}
+
+extern "C" int bbidx_find_batch_device(bbidx_ctx *c, void *stream_, int64_t n, const bbidx_read *reads,
+                                       const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo,
+                                       bbidx_site *sites, int32_t max_sites, int32_t *nsites) {
+    if (!c) return ifail(BBMAP_E_ARG, "bbidx_find_batch_device: null context");
+    if (n < 0 || n > 0x7fffffffLL || max_sites < 1) return ifail(BBMAP_E_ARG, "bbidx_find_batch_device: bad size");
+    if (n == 0) return BBMAP_OK;
+    if (!reads || !bases || !baseScores || !keyinfo || !sites || !nsites) return ifail(BBMAP_E_ARG, "bbidx_find_batch_device: null buffer");
+    hipStream_t stream = (hipStream_t)stream_;
+    IHIP(hipSetDevice(c->device));
+    IHIP(hipMemsetAsync(c->d_queue, 0, 64, stream));
+    bbidx::Params P;
+    P.ix = c->dev; P.reads = reads; P.bases = bases; P.baseScores = baseScores; P.keyinfo = keyinfo;
+    P.sites = sites; P.nsites = nsites; P.nreads = n; P.maxSites = max_sites; P.queue = c->d_queue;
+    long long blocks = (n + 63) / 64;
+    if (blocks > c->blocks) blocks = c->blocks;
+    hipLaunchKernelGGL(bbidx::probe_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, P);
+    IHIP(hipGetLastError());
+    return BBMAP_OK;
+}
+
+extern "C" int bbidx_find_batch(bbidx_ctx *c, int64_t n, const bbidx_read *reads, const uint8_t *bases, const int8_t *baseScores,
+                                int64_t bases_bytes, const int32_t *keyinfo, int64_t keyinfo_ints,
+                                bbidx_site *sites, int32_t max_sites, int32_t *nsites) {
+    if (!c) return ifail(BBMAP_E_ARG, "bbidx_find_batch: null context");
+    if (n == 0) return BBMAP_OK;
+    if (n < 0 || !reads || !bases || !baseScores || !keyinfo || !sites || !nsites || max_sites < 1)
+        return ifail(BBMAP_E_ARG, "bbidx_find_batch: bad argument");
+    for (int64_t i = 0; i < n; i++) {
+        const bbidx_read &r = reads[i];
+        if (r.len < 0 || r.nkeys < 0 || r.bases_off < 0 || r.keys_off < 0 || r.bases_off + r.len > bases_bytes ||
+            r.keys_off + 2LL * r.nkeys > keyinfo_ints)
+            return ifail(BBMAP_E_ARG, "bbidx_find_batch: a read lies outside its buffers");
+        for (int q = 0; q < r.nkeys && q < BBIDX_MAX_KEYS; q++) {
+            const int o = keyinfo[r.keys_off + q];
+            if (o < 0 || o + c->dev.p.k > r.len) return ifail(BBMAP_E_ARG, "bbidx_find_batch: a key offset lies outside its read");
+        }
+    }
+    IHIP(hipSetDevice(c->device));
+    bbidx_read *dr = nullptr; uint8_t *db = nullptr; int8_t *dq = nullptr; int32_t *dk = nullptr, *dn = nullptr; bbidx_site *ds = nullptr;
+    int rc = BBMAP_OK;
+#define IGO(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(g_ierr, sizeof g_ierr, "%s failed: %s", #expr, hipGetErrorString(e_)); bbmap_set_error(g_ierr); rc = BBMAP_E_HIP; goto done; } } while (0)
+    IGO(hipMalloc(&dr, (size_t)n * sizeof(bbidx_read)));
+    IGO(hipMalloc(&db, (size_t)(bases_bytes > 0 ? bases_bytes : 1)));
+    IGO(hipMalloc(&dq, (size_t)(bases_bytes > 0 ? bases_bytes : 1)));
+    IGO(hipMalloc(&dk, (size_t)(keyinfo_ints > 0 ? keyinfo_ints : 1) * 4));
+    IGO(hipMalloc(&dn, (size_t)n * 4));
+    IGO(hipMalloc(&ds, (size_t)n * (size_t)max_sites * sizeof(bbidx_site)));
+    IGO(hipMemcpy(dr, reads, (size_t)n * sizeof(bbidx_read), hipMemcpyHostToDevice));
+    IGO(hipMemcpy(db, bases, (size_t)bases_bytes, hipMemcpyHostToDevice));
+    IGO(hipMemcpy(dq, baseScores, (size_t)bases_bytes, hipMemcpyHostToDevice));
+    IGO(hipMemcpy(dk, keyinfo, (size_t)keyinfo_ints * 4, hipMemcpyHostToDevice));
+    rc = bbidx_find_batch_device(c, nullptr, n, dr, db, dq, dk, ds, max_sites, dn);
+    if (rc != BBMAP_OK) goto done;
+    IGO(hipStreamSynchronize(nullptr));
+    IGO(hipMemcpy(nsites, dn, (size_t)n * 4, hipMemcpyDeviceToHost));
+    IGO(hipMemcpy(sites, ds, (size_t)n * (size_t)max_sites * sizeof(bbidx_site), hipMemcpyDeviceToHost));
+done:
+    if (dr) (void)hipFree(dr);
+    if (db) (void)hipFree(db);
+    if (dq) (void)hipFree(dq);
+    if (dk) (void)hipFree(dk);
+    if (dn) (void)hipFree(dn);
+    if (ds) (void)hipFree(ds);
+    return rc;
+#undef IGO
+}

@@ -172,6 +172,68 @@ int bbband_align_batch_device(bbband_ctx *ctx, void *stream, int64_t n_jobs, con
 int bbband_align_batch(bbband_ctx *ctx, int64_t n_jobs, const bbband_job *jobs,
                        const uint8_t *seqs, int64_t seq_bytes, bbband_result *results);
 
+/* =====================================================================================
+ * k-mer index probe (align2.BBIndex.findAdvanced)
+ *   The reference has NO native boundary for the index: BBIndex is pure Java.  This is the new seam
+ *   SURVEY.md section 0/R3 proposes: AbstractIndex.findAdvanced(basesP, basesM, qual, baseScoresP,
+ *   keyScoresP, offsets, id) -> ArrayList<SiteScore>  (current/align2/AbstractIndex.java:83; sole call
+ *   site current/align2/AbstractMapThread.java:736), batched over reads.  The index itself
+ *   (Block.sites/starts, current/align2/Block.java:162-165; AbstractIndex.COUNTS; the chromosome byte
+ *   arrays) is uploaded once and stays resident in HBM.
+ * ===================================================================================== */
+typedef struct bbidx_params {   /* the reference's mutable statics, BBIndex.java:3168-3305, AbstractIndex.java:100-160 */
+    int32_t k, chromBits, minChrom, maxChrom;
+    int32_t maxIndel, maxIndel2, minApproxHitsToKeep, kfilter;
+    int32_t maxUsableLength, maxUsableLength2;
+    int32_t maxHitsReduction2, maximumMaxHitsReduction, hitReductionDiv;
+    int32_t quitAfterTwoPerfects, prescanQscore, trimByGreedy, slow;
+    int32_t maxAverageListToSearch, maxAverageListToSearch2, maxShortestListToSearch;
+    int64_t pointsPerSite;      /* Solver.POINTS_PER_SITE after analyzeIndex */
+} bbidx_params;                 /* 88 bytes */
+
+typedef struct bbidx_index_desc {   /* host pointers; everything is copied to the device by bbidx_create */
+    bbidx_params params;
+    int32_t nblocks;                /* blocks are index[baseChrom]; block b holds chromosomes b<<chromBits .. */
+    int32_t nchroms;                /* chromosomes are numbered 1..nchroms */
+    const int32_t *const *starts;   /* per block: 4^k + 1 ints */
+    const int32_t *const *sites;    /* per block */
+    const int64_t *numSites;        /* per block */
+    const int32_t *counts;          /* AbstractIndex.COUNTS, 4^k ints */
+    const int32_t *lengthHistogram; /* 1001 ints */
+    const uint8_t *const *chromArr; /* [nchroms+1], entry 0 unused */
+    const int32_t *chromArrLen;     /* array length of each chromosome */
+    const int32_t *chromLengths;    /* Data.chromLengths[chrom] */
+} bbidx_index_desc;
+
+typedef struct bbidx_read {
+    int64_t bases_off;      /* offset of basesP in `bases`; baseScoresP sits at the same offset in `baseScores` */
+    int64_t keys_off;       /* offset (in ints) into `keyinfo`: offsets[nkeys] followed by keyScoresP[nkeys]   */
+    int32_t len;
+    int32_t nkeys;
+} bbidx_read;               /* 24 bytes */
+
+#define BBIDX_MAX_GAPS 16
+typedef struct bbidx_site { /* stream.SiteScore as the probe emits it (current/stream/SiteScore.java:999-1011) */
+    int32_t chrom, strand, start, stop, hits, score, perfect, semiperfect;
+    int32_t ngaps;
+    int32_t gaps[BBIDX_MAX_GAPS];
+} bbidx_site;               /* 100 bytes */
+
+enum { BBIDX_MAX_KEYS = 128, BBIDX_MAX_READ_LEN = 600 };
+
+typedef struct bbidx_ctx bbidx_ctx;
+int bbidx_create(int32_t device, const bbidx_index_desc *desc, bbidx_ctx **out);
+void bbidx_destroy(bbidx_ctx *ctx);
+/* Device-resident batch.  sites: n_reads x max_sites records; nsites[i] = sites found for read i, or -1 when
+ * max_sites was too small, -2 when the read exceeds BBIDX_MAX_KEYS / BBIDX_MAX_READ_LEN. */
+int bbidx_find_batch_device(bbidx_ctx *ctx, void *stream, int64_t n_reads, const bbidx_read *reads,
+                            const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo,
+                            bbidx_site *sites, int32_t max_sites, int32_t *nsites);
+int bbidx_find_batch(bbidx_ctx *ctx, int64_t n_reads, const bbidx_read *reads,
+                     const uint8_t *bases, const int8_t *baseScores, int64_t bases_bytes,
+                     const int32_t *keyinfo, int64_t keyinfo_ints,
+                     bbidx_site *sites, int32_t max_sites, int32_t *nsites);
+
 #ifdef __cplusplus
 }
 #endif

@@ -201,3 +201,116 @@ def banded_align(direction, query, ref, qstart, rstart, maxEdits, exact, maxWidt
     e = L.orc_banded_align(direction, _p(q, c_u8p), len(query), _p(r, c_u8p), len(ref), qstart, rstart,
                            maxEdits, 1 if exact else 0, maxWidth, variant, _p(out, c_i32p))
     return e, out.tolist()
+
+
+# ---------------------------------------------------------------------------------------------- index probe
+class IndexParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "k", "chromBits", "minChrom", "maxChrom", "maxIndel", "maxIndel2", "minApproxHitsToKeep", "kfilter",
+        "maxUsableLength", "maxUsableLength2", "maxHitsReduction2", "maximumMaxHitsReduction", "hitReductionDiv",
+        "quitAfterTwoPerfects", "prescanQscore", "trimByGreedy", "slow",
+        "maxAverageListToSearch", "maxAverageListToSearch2", "maxShortestListToSearch")] + [("_pad", C.c_int32 * 0), ("pointsPerSite", C.c_int64)]
+
+
+class IndexStruct(C.Structure):
+    _fields_ = [("p", IndexParams), ("nblocks", C.c_int32), ("starts", C.POINTER(c_i32p)), ("sites", C.POINTER(c_i32p)),
+                ("numSites", C.POINTER(C.c_int64)), ("counts", c_i32p), ("lengthHistogram", C.c_int32 * 1001),
+                ("nchroms", C.c_int32), ("chromArr", C.POINTER(c_u8p)), ("chromArrLen", c_i32p), ("chromLengths", c_i32p)]
+
+
+class SiteStruct(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("chrom", "strand", "start", "stop", "hits", "score", "perfect", "semiperfect", "ngaps")] + \
+               [("gaps", C.c_int32 * 16)]
+
+
+def small_genome_tuning(ix_struct, defined_bases):
+    """BBMap.loadIndex's genome-size adjustments (current/align2/BBMap.java:367-381), applied before analyzeIndex."""
+    p = ix_struct.p
+    if defined_bases < 300000000:
+        p.maxHitsReduction2 += 1
+        p.maximumMaxHitsReduction += 1
+        if defined_bases < 30000000:
+            p.maximumMaxHitsReduction += 1
+            p.hitReductionDiv = max(p.hitReductionDiv - 1, 3)
+
+
+def fraction_to_exclude(defined_bases):
+    f = np.float32(0.03)
+    if defined_bases < 30000000:
+        return float(f * np.float32(0.5))
+    if defined_bases < 100000000:
+        return float(f * np.float32(0.6))
+    if defined_bases < 300000000:
+        return float(f * np.float32(0.75))
+    return float(f)
+
+
+class OracleIndex:
+    """Index + probe of the CPU oracle.  chroms: list of bytes-like (chromosome 1..n), already padded with N."""
+
+    def __init__(self, chroms, k=13, chromBits=None):
+        self.L = lib()
+        self.chroms = [np.frombuffer(bytes(c), np.uint8).copy() for c in chroms]
+        n = len(self.chroms)
+        maxlen = max(len(c) for c in self.chroms)
+        if chromBits is None:
+            chromBits = min(16, (32 - int(maxlen).bit_length()) - 1)        # AUTO_CHROMBITS, BBMap.java:317-321
+        self.k, self.chromBits = k, chromBits
+        arr = (c_u8p * (n + 1))()
+        lens = (C.c_int32 * (n + 1))()
+        for i, c in enumerate(self.chroms):
+            arr[i + 1] = c.ctypes.data_as(c_u8p)
+            lens[i + 1] = len(c)
+        defined = sum(int(np.isin(c, np.frombuffer(b"ACGT", np.uint8)).sum()) for c in self.chroms)
+        self.defined_bases = defined
+        self.L.orc_index_build.restype = C.c_void_p
+        self.L.orc_index_build.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(c_u8p), c_i32p, C.c_float]
+        self.h = self.L.orc_index_build(k, chromBits, n, arr, lens, fraction_to_exclude(defined))
+        self.s = IndexStruct.from_address(self.h)
+        small_genome_tuning(self.s, defined)
+        self._keep = (arr, lens)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_index_free.argtypes = [C.c_void_p]
+                self.L.orc_index_free(C.c_void_p(self.h))
+                self.h = None
+        except Exception:
+            pass
+
+    def block_arrays(self, b=0):
+        ks = 1 << (2 * self.k)
+        starts = np.ctypeslib.as_array(self.s.starts[b], shape=(ks + 1,))
+        ns = int(self.s.numSites[b])
+        sites = np.ctypeslib.as_array(self.s.sites[b], shape=(max(ns, 1),))[:ns]
+        return starts, sites
+
+    def counts(self):
+        return np.ctypeslib.as_array(self.s.counts, shape=(1 << (2 * self.k),))
+
+    def find(self, basesP, basesM, baseScoresP, keyScoresP, offsets, cap=64, want_stats=False):
+        bp, bm = _u8(basesP), _u8(basesM)
+        bs = np.asarray(baseScoresP, np.int8).copy()
+        ks = np.asarray(keyScoresP, np.int32).copy()
+        of = np.asarray(offsets, np.int32).copy()
+        out = (SiteStruct * cap)()
+        st = np.zeros(4, np.int64)
+        self.L.orc_index_find.argtypes = [C.c_void_p, c_u8p, c_u8p, C.c_int, c_i8p, c_i32p, c_i32p, C.c_int,
+                                          C.POINTER(SiteStruct), C.c_int, C.POINTER(C.c_int64)]
+        n = self.L.orc_index_find(C.c_void_p(self.h), _p(bp, c_u8p), _p(bm, c_u8p), len(basesP), _p(bs, c_i8p),
+                                  _p(ks, c_i32p), _p(of, c_i32p), len(of), out, cap,
+                                  st.ctypes.data_as(C.POINTER(C.c_int64)))
+        if n < 0:
+            raise RuntimeError("site list overflow")
+        res = [dict(chrom=o.chrom, strand=o.strand, start=o.start, stop=o.stop, hits=o.hits, score=o.score,
+                    perfect=o.perfect, semiperfect=o.semiperfect, gaps=list(o.gaps[:o.ngaps])) for o in out[:n]]
+        return (res, st.tolist()) if want_stats else res
+
+
+def make_offsets(readlen, k, density=1.9, min_keys=2):
+    L = lib()
+    out = np.zeros(256, np.int32)
+    L.orc_make_offsets.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, c_i32p, C.c_int]
+    n = L.orc_make_offsets(readlen, k, density, min_keys, _p(out, c_i32p), 256)
+    return out[:n].tolist()
