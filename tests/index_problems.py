@@ -36,6 +36,7 @@ def make_reads(seed, genomes, n, read_len=150, k=13, density=1.9):
         ci = rng.randrange(len(genomes))
         G = genomes[ci]
         L = rng.choice([read_len, read_len, 100, 75]) if read_len >= 100 else read_len
+        lo, hi = min(20, L // 3), max(L - 20, L // 3 + 1)
         st = rng.randrange(300, len(G) - L - 700)
         rd = bytearray(G[st:st + L + 40])
         kind = rng.random()
@@ -46,17 +47,17 @@ def make_reads(seed, genomes, n, read_len=150, k=13, density=1.9):
                 p = rng.randrange(L)
                 rd[p] = rng.choice(b"ACGT")
         elif kind < 0.72:
-            p = rng.randrange(20, L - 20)
+            p = rng.randrange(lo, hi)
             del rd[p:p + rng.randint(1, 8)]
         elif kind < 0.84:
-            p = rng.randrange(20, L - 20)
+            p = rng.randrange(lo, hi)
             rd[p:p] = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 5)))
         elif kind < 0.9:
             rd[rng.randrange(L)] = ord("N")
         elif kind < 0.95:
             rd = bytearray(rng.choice(b"ACGT") for _ in range(L + 40))      # junk read
         else:
-            p = rng.randrange(30, L - 30)                                    # long deletion: gap arrays
+            p = rng.randrange(lo, hi)                                        # long deletion: gap arrays
             extra = bytearray(G[st + L + 40: st + L + 40 + 700])
             rd = rd[:p] + (rd + extra)[p + rng.randint(300, 600):]
         rd = bytes(rd[:L])
