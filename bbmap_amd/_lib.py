@@ -15,7 +15,8 @@ EXPORTS = [
     "bbmsa_create", "bbmsa_destroy", "bbmsa_align_batch_device", "bbmsa_align_batch",
     "bbmsa_last_kernel_ms",
     "bbband_create", "bbband_destroy", "bbband_align_batch_device", "bbband_align_batch",
-    "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch",
+    "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch", "bbidx_last_stats",
+    "bbpipe_revcomp_device", "bbpipe_select_jobs_device",
 ]
 
 
@@ -93,6 +94,12 @@ def load():
     L.bbband_align_batch_device.restype = C.c_int
     L.bbband_align_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.bbband_align_batch.restype = C.c_int
+    L.bbpipe_revcomp_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bbpipe_revcomp_device.restype = C.c_int
+    L.bbpipe_select_jobs_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bbpipe_select_jobs_device.restype = C.c_int
     _lib = L
     return L
 

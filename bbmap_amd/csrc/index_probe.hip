@@ -62,6 +62,7 @@ struct Params {
     long long nreads;
     int maxSites;
     unsigned int *queue;
+    unsigned long long *stats;     // [4] totals of the Walker counters + [4] = site records written
 };
 
 __device__ inline int base_num(int b) {
@@ -110,6 +111,9 @@ struct Walker {
     const DevIndex *ix;
     Codec c;
     int k, baseKeyHitScore, indelPenalty, indelPenaltyMult, maxPenalty, scoreZ1Key;
+    // work counters of the current read: list entries consumed by the prescan / by the walk,
+    // extendScore calls, reference bytes compared
+    mutable unsigned cPrescan, cWalk, cExtend, cRefBytes;
 };
 
 struct Lists {
@@ -225,6 +229,7 @@ __device__ void findMaxQscore2(const Walker &w, Lists &L, int baseChrom, int pre
         for (;;) {
             const int col = listsPeek(L);
             if (col < 0 || L.value[col] != site) break;
+            w.cPrescan++;
             const int row = L.row[col] + 1;
             if (row < L.stop[col]) { L.row[col] = row; L.value[col] = adjustSite(w, L.sites[row], L.offs[col], baseChrom); }
             else {
@@ -287,6 +292,7 @@ __device__ int extendScore(const Walker &w, const Strand &rd, const int *offsets
     const int minVal = centerVal - p.maxIndel, maxVal = centerVal + p.maxIndel2;
     const uint8_t *ref = w.ix->chromArr[chrom];
     const int reflen = w.ix->chromArrLen[chrom];
+    w.cExtend++;
     for (int i = 0; i < blen; i++) locArray[i] = -1;
     for (int i = 0, keynum = 0; i < numHits; i++) {
         const int value = values[i];
@@ -298,6 +304,7 @@ __device__ int extendScore(const Walker &w, const Strand &rd, const int *offsets
                 const int old = locArray[cloc];
                 if (old == refbase) break;
                 if (misses > 0 && old >= 0) break;
+                w.cRefBytes++;
                 if (rd.base(cloc) == ref[rloc]) { if (old < 0 || refbase == centerLoc) locArray[cloc] = refbase; }
                 else { misses++; if (old >= 0 || keynum > 1) break; }
             }
@@ -312,6 +319,7 @@ __device__ int extendScore(const Walker &w, const Strand &rd, const int *offsets
                 const int old = locArray[cloc];
                 if (old == refbase) break;
                 if (misses > 0 && old >= 0) break;
+                w.cRefBytes++;
                 if (rd.base(cloc) == ref[rloc]) { if (old < 0 || refbase == centerLoc) locArray[cloc] = refbase; }
                 else { misses++; if (old >= 0) break; }
             }
@@ -510,6 +518,7 @@ __device__ void slowWalk3(const Walker &w, Lists &L, int *locArray, int block, c
         for (;;) {
             const int col = listsPeek(L);
             if (col < 0 || L.value[col] != site) break;
+            w.cWalk++;
             const int row = L.row[col] + 1;
             if (row < L.stop[col]) { L.row[col] = row; L.value[col] = adjustSite(w, L.sites[row], L.offs[col], baseChrom); }
             else {
@@ -628,6 +637,8 @@ __global__ __launch_bounds__(64) void probe_kernel(const Params P) {
     w.indelPenalty = (w.baseKeyHitScore / 2) - 1; w.indelPenaltyMult = 20;
     w.maxPenalty = w.baseKeyHitScore - (1 + w.baseKeyHitScore / 8);
     w.scoreZ1Key = Z_MULT * p.k;
+    w.cPrescan = w.cWalk = w.cExtend = w.cRefBytes = 0;
+    unsigned cSites = 0;
 
     int keysOriginal[KB], keysP[KB], offsetsP[KB], keyScoresP[KB];
     int offsetsM[KB], keysM[KB], keyScoresM[KB];
@@ -749,6 +760,12 @@ __global__ __launch_bounds__(64) void probe_kernel(const Params P) {
             }
         }
         P.nsites[r] = ssl.overflow ? -1 : ssl.n;
+        cSites += (unsigned)ssl.n;
+    }
+    if (P.stats) {
+        atomicAdd(&P.stats[0], (unsigned long long)w.cPrescan); atomicAdd(&P.stats[1], (unsigned long long)w.cWalk);
+        atomicAdd(&P.stats[2], (unsigned long long)w.cExtend); atomicAdd(&P.stats[3], (unsigned long long)w.cRefBytes);
+        atomicAdd(&P.stats[4], (unsigned long long)cSites);
     }
 }
 
@@ -760,7 +777,10 @@ struct bbidx_ctx {
     bbidx::DevIndex dev;
     std::vector<void *> allocs;
     unsigned int *d_queue;
+    unsigned long long *d_stats;
     int blocks;
+    hipEvent_t ev[2];
+    bool timed;
 };
 
 static thread_local char g_ierr[256];
@@ -812,6 +832,8 @@ extern "C" int bbidx_create(int32_t device, const bbidx_index_desc *d, bbidx_ctx
     if (rc == BBMAP_OK) rc = upload(c, d->chromArrLen, (size_t)d->nchroms + 1, &c->dev.chromArrLen);
     if (rc == BBMAP_OK) rc = upload(c, d->chromLengths, (size_t)d->nchroms + 1, &c->dev.chromLengths);
     if (rc == BBMAP_OK && hipMalloc(&c->d_queue, 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
+    if (rc == BBMAP_OK && hipMalloc(&c->d_stats, 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
+    if (rc == BBMAP_OK && (hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess)) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipEventCreate failed");
     if (rc != BBMAP_OK) { bbidx_destroy(c); return rc; }
     *out = c;
     return BBMAP_OK;
@@ -822,6 +844,8 @@ extern "C" void bbidx_destroy(bbidx_ctx *c) {
     (void)hipSetDevice(c->device);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->d_queue) (void)hipFree(c->d_queue);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    for (int i = 0; i < 2; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
 
@@ -835,13 +859,18 @@ extern "C" int bbidx_find_batch_device(bbidx_ctx *c, void *stream_, int64_t n, c
     hipStream_t stream = (hipStream_t)stream_;
     IHIP(hipSetDevice(c->device));
     IHIP(hipMemsetAsync(c->d_queue, 0, 64, stream));
+    IHIP(hipMemsetAsync(c->d_stats, 0, 64, stream));
     bbidx::Params P;
+    P.stats = c->d_stats;
     P.ix = c->dev; P.reads = reads; P.bases = bases; P.baseScores = baseScores; P.keyinfo = keyinfo;
     P.sites = sites; P.nsites = nsites; P.nreads = n; P.maxSites = max_sites; P.queue = c->d_queue;
     long long blocks = (n + 63) / 64;
     if (blocks > c->blocks) blocks = c->blocks;
+    IHIP(hipEventRecord(c->ev[0], stream));
     hipLaunchKernelGGL(bbidx::probe_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, P);
     IHIP(hipGetLastError());
+    IHIP(hipEventRecord(c->ev[1], stream));
+    c->timed = true;
     return BBMAP_OK;
 }
 
@@ -890,4 +919,16 @@ done:
     if (ds) (void)hipFree(ds);
     return rc;
 #undef IGO
+}
+
+// Work counters and duration of the last bbidx_find_batch_device launch (valid once its stream has been synchronised):
+// stats[0..4] = list entries consumed by the prescan, by the walk, extendScore calls, reference bytes compared,
+// site records written.
+extern "C" int bbidx_last_stats(bbidx_ctx *c, int64_t *stats5, float *kernel_ms) {
+    if (!c || !c->timed) return ifail(BBMAP_E_ARG, "bbidx_last_stats: nothing launched yet");
+    IHIP(hipSetDevice(c->device));
+    IHIP(hipEventSynchronize(c->ev[1]));
+    if (kernel_ms) IHIP(hipEventElapsedTime(kernel_ms, c->ev[0], c->ev[1]));
+    if (stats5) IHIP(hipMemcpy(stats5, c->d_stats, 5 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return BBMAP_OK;
 }

@@ -1,0 +1,104 @@
+"""Device-resident read pipeline: reverse complement -> index probe -> site filter -> slow-align DP.
+
+Everything between the upload of a read batch and the download of its results stays in HBM; the only host
+round trip per step is the 16-byte counter block that tells the host how many DP jobs the filter produced.
+Used by bench.py and the pipeline tests.  Needs torch (device buffers, stream) and the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import msa as M
+from .index import READ_DTYPE, SITE_DTYPE, DeviceIndex
+
+
+class MapPipeline:
+    def __init__(self, host_index, n_reads, read_len, offsets, key_scores, device=0, max_sites=8,
+                 max_columns=256, pad=4, min_ratio=0.56):
+        self.L = _lib.load()
+        self.dev = torch.device("cuda", device)
+        self.hi = host_index
+        self.di = DeviceIndex(host_index, device)
+        self.n, self.read_len, self.max_sites, self.pad, self.min_ratio = n_reads, read_len, max_sites, pad, min_ratio
+        self.max_columns = max_columns
+        max_rows = ((read_len + 31) // 32) * 32
+        self.msa = M.MSAContext(maxRows=max_rows, maxColumns=max_columns, device=device)
+        # reference blob = chromosomes back to back; chrom_off[c] = offset of chromosome c
+        offs, total = [0], 0
+        for c in host_index.chroms:
+            offs.append(total)
+            total += len(c)
+        self.refs = torch.from_numpy(np.concatenate(host_index.chroms)).to(self.dev)
+        self.chrom_off = torch.tensor(offs, dtype=torch.int64, device=self.dev)
+        self.chrom_len = torch.tensor([0] + [len(c) for c in host_index.chroms], dtype=torch.int32, device=self.dev)
+        # reads: plus strand in the first half of `bases`, reverse complements in the second half
+        self.total_bytes = n_reads * read_len
+        self.bases = torch.zeros(2 * self.total_bytes, dtype=torch.uint8, device=self.dev)
+        self.base_scores = torch.zeros(self.total_bytes, dtype=torch.int8, device=self.dev)
+        recs = np.zeros(n_reads, READ_DTYPE)
+        recs["bases_off"] = np.arange(n_reads, dtype=np.int64) * read_len
+        recs["keys_off"] = 0                       # every read uses the same offsets / key scores
+        recs["len"] = read_len
+        recs["nkeys"] = len(offsets)
+        self.reads = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(self.dev)
+        self.keyinfo = torch.tensor(list(offsets) + list(key_scores), dtype=torch.int32, device=self.dev)
+        self.sites = torch.zeros(n_reads * max_sites * SITE_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
+        self.nsites = torch.zeros(n_reads, dtype=torch.int32, device=self.dev)
+        cap = n_reads * max_sites
+        self.jobs = torch.zeros(cap * M.JOB_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
+        self.job_src = torch.zeros(cap, dtype=torch.int32, device=self.dev)
+        self.counters = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self.no_indel = torch.zeros(cap, dtype=torch.int32, device=self.dev)
+        self.match_stride = ((max_rows + max_columns + 15) // 16) * 16
+        self.results = torch.zeros(cap * M.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
+        self.match = torch.zeros(cap * self.match_stride, dtype=torch.uint8, device=self.dev)
+        self.last_counters = None
+        self.last_ms = {}
+
+    def load_reads(self, reads_u8):
+        assert reads_u8.size == self.total_bytes
+        self.bases[: self.total_bytes].copy_(torch.from_numpy(np.ascontiguousarray(reads_u8)))
+
+    def step(self):
+        """One pass of the hot path over the resident batch.  Returns the number of DP jobs."""
+        L, n = self.L, self.n
+        stream = torch.cuda.current_stream().cuda_stream
+        plus = self.bases.data_ptr()
+        _lib.check(L.bbpipe_revcomp_device(C.c_void_p(stream), n, self.reads.data_ptr(), plus, plus + self.total_bytes),
+                   "bbpipe_revcomp_device")
+        _lib.check(L.bbidx_find_batch_device(self.di.h, C.c_void_p(stream), n, self.reads.data_ptr(), plus,
+                                             self.base_scores.data_ptr(), self.keyinfo.data_ptr(), self.sites.data_ptr(),
+                                             self.max_sites, self.nsites.data_ptr()), "bbidx_find_batch_device")
+        _lib.check(L.bbpipe_select_jobs_device(C.c_void_p(stream), n, self.reads.data_ptr(), plus, self.total_bytes,
+                                               self.nsites.data_ptr(), self.sites.data_ptr(), self.max_sites,
+                                               self.chrom_off.data_ptr(), self.chrom_len.data_ptr(), self.refs.data_ptr(),
+                                               self.pad, self.max_columns, self.min_ratio, self.jobs.data_ptr(),
+                                               self.job_src.data_ptr(), self.counters.data_ptr(), self.no_indel.data_ptr()),
+                   "bbpipe_select_jobs_device")
+        cnt = self.counters.cpu().numpy()                     # the one host round trip: how many DP jobs
+        njobs = int(cnt[0])
+        if njobs:
+            self.msa.align_batch_device(njobs, self.jobs.data_ptr(), plus, self.refs.data_ptr(), self.results.data_ptr(),
+                                        self.match.data_ptr(), self.match_stride, stream)
+        self.last_counters = cnt
+        return njobs
+
+    def probe_stats(self):
+        st = (C.c_int64 * 5)()
+        ms = C.c_float()
+        self.L.bbidx_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_float)]
+        _lib.check(self.L.bbidx_last_stats(self.di.h, st, C.byref(ms)), "bbidx_last_stats")
+        return list(st), ms.value
+
+    def fetch(self, njobs):
+        """Host copies of everything a step produced (for tests / parity sampling)."""
+        sites = self.sites.cpu().numpy().view(SITE_DTYPE).reshape(self.n, self.max_sites)
+        nsites = self.nsites.cpu().numpy()
+        jobs = self.jobs[: njobs * M.JOB_DTYPE.itemsize].cpu().numpy().view(M.JOB_DTYPE)
+        src = self.job_src[:njobs].cpu().numpy()
+        res = self.results[: njobs * M.RESULT_DTYPE.itemsize].cpu().numpy().view(M.RESULT_DTYPE)
+        match = self.match[: njobs * self.match_stride].cpu().numpy().reshape(njobs, self.match_stride)
+        no_indel = self.no_indel.cpu().numpy().reshape(self.n, self.max_sites)
+        return dict(sites=sites, nsites=nsites, jobs=jobs, src=src, results=res, match=match, no_indel=no_indel)

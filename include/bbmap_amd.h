@@ -234,6 +234,32 @@ int bbidx_find_batch(bbidx_ctx *ctx, int64_t n_reads, const bbidx_read *reads,
                      const int32_t *keyinfo, int64_t keyinfo_ints,
                      bbidx_site *sites, int32_t max_sites, int32_t *nsites);
 
+/* Work counters and HIP-event duration of the last bbidx_find_batch_device launch; valid once its
+ * stream has been synchronised.  stats5 = {list entries consumed by the prescan, by the walk, extendScore calls,
+ * reference bytes compared, site records written}. */
+int bbidx_last_stats(bbidx_ctx *ctx, int64_t *stats5, float *kernel_ms);
+
+/* =====================================================================================
+ * Pipeline glue (device-resident): which probe sites need a slow alignment.
+ *   Mirrors the host logic between the two hot kernels: AbstractMapThread.scoreNoIndels
+ *   (current/align2/AbstractMapThread.java:762-856) and the site filter at the top of
+ *   BBMapThread.scoreSlow (current/align2/BBMapThread.java:252-309); see bbmap_amd/csrc/pipeline.hip
+ *   for what is and is not carried over.  All pointers are device pointers.
+ * ===================================================================================== */
+/* bases_out[read] = reverse complement of bases_in[read] (AminoAcid.reverseComplementBases) */
+int bbpipe_revcomp_device(void *stream, int64_t n_reads, const bbidx_read *reads,
+                          const uint8_t *bases_in, uint8_t *bases_out);
+/* Scores every probe site without indels (MSA.scoreNoIndels), updates the site records in place, and appends one
+ * bbmsa_job per site that still needs DP.  counters[4] (zeroed by the call): jobs written, reads finished without
+ * DP, sites skipped because they carry a gap array, reads with no site.  `bases + minus_delta` must hold the
+ * reverse-complemented reads at the same offsets.  no_indel_score (optional) receives the ungapped score of every
+ * (read, site). */
+int bbpipe_select_jobs_device(void *stream, int64_t n_reads, const bbidx_read *reads, const uint8_t *bases,
+                              int64_t minus_delta, const int32_t *nsites, bbidx_site *sites, int32_t max_sites,
+                              const int64_t *chrom_off, const int32_t *chrom_len, const uint8_t *refs,
+                              int32_t pad, int32_t max_columns, float min_ratio,
+                              bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score);
+
 #ifdef __cplusplus
 }
 #endif

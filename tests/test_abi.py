@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "bbmap_amd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(bb(?:map|msa|band|idx)_[a-z0-9_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(bb(?:map|msa|band|idx|pipe)_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():

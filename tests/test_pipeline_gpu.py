@@ -1,0 +1,83 @@
+"""GPU test of the device-resident pipeline (revcomp -> probe -> site filter -> DP) against an emulation
+built from the oracle's pieces."""
+import numpy as np
+import pytest
+
+from bbmap_amd import msa as M
+from bbmap_amd.index import HostIndex
+from bbmap_amd.pipeline import MapPipeline
+from bbmap_amd import workload as W
+from oracle.oracle import OracleIndex, OracleMSA, make_offsets, score_no_indels
+from tests.index_problems import revcomp
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pipeline_matches_emulation():
+    k, L, n = 12, 150, 3000
+    ref = W.make_reference(300000, seed=5, pad=2000)
+    reads, _, truth = W.make_reads_and_jobs(ref, n, read_len=L, seed=9, pad=2000)
+    hi = HostIndex([ref], k=k)
+    offs = make_offsets(L, k, 1.9)
+    ks = [100 * k] * len(offs)
+    pipe = MapPipeline(hi, n, L, offs, ks, max_sites=8, max_columns=256)
+    pipe.load_reads(reads)
+    njobs = pipe.step()
+    out = pipe.fetch(njobs)
+    cnt = pipe.last_counters
+    assert njobs == cnt[0] and njobs > 0.05 * n          # the mutated mix sends a good share of reads to DP
+    assert cnt[1] > 0.5 * n                               # and finishes most reads without DP
+
+    oi = OracleIndex([ref], k=k)
+    om = OracleMSA(160, 256)
+    refb = ref.tobytes()
+    maxSw = 70 + (L - 1) * 100
+    maxImp = maxSw - 495
+    minMsaLimit = -258 + int(np.float32(0.56) * np.float32(maxSw))
+    by_src = {int(s): i for i, s in enumerate(out["src"])}
+    assert len(by_src) == njobs
+    checked_jobs = 0
+    for r in range(600):
+        bp = reads[r * L:(r + 1) * L].tobytes()
+        bm = revcomp(bp)
+        exp_sites = oi.find(bp, bm, [0] * L, ks, offs, cap=8)
+        ns = int(out["nsites"][r])
+        assert ns == len(exp_sites)
+        near, force, sws = 0, False, []
+        for s, e in enumerate(exp_sites):
+            g = out["sites"][r, s]
+            assert (int(g["chrom"]), int(g["strand"]), int(g["start"]), int(g["hits"])) == (e["chrom"], e["strand"], e["start"], e["hits"])
+            bases = bm if e["strand"] else bp
+            if e["perfect"]:
+                sw = maxSw
+                near += 1
+            else:
+                sw = score_no_indels(bases, refb, e["start"])
+                if sw >= maxImp:
+                    near += 1
+                elif e["score"] >= maxImp:
+                    force = True
+            sws.append(sw)
+            assert int(out["no_indel"][r, s]) == sw
+        num_near = -near if force else near
+        for s, e in enumerate(exp_sites):
+            src = r * 8 + s
+            semip = bool(out["sites"][r, s]["semiperfect"])
+            needs = num_near < 1 and sws[s] < maxImp and not semip and not e["gaps"]
+            assert (src in by_src) == needs, (r, s, e, sws[s], num_near)
+            if needs:
+                i = by_src[src]
+                j = out["jobs"][i]
+                stop = int(out["sites"][r, s]["stop"])
+                assert (int(j["refStartLoc"]), int(j["refEndLoc"])) == (e["start"] - 4, stop + 4)
+                assert int(j["minScore"]) == max(sws[s], minMsaLimit)
+                bases = bm if e["strand"] else bp
+                sv, mx = om.fillAndScoreLimited(bases, refb, int(j["refStartLoc"]), int(j["refEndLoc"]), int(j["minScore"]))
+                res = out["results"][i]
+                gs = None if res["score_len"] == 0 else res["score"][: res["score_len"]].tolist()
+                assert gs == sv
+                if sv is not None:
+                    tb = om.traceback(bases, refb, max(0, int(j["refStartLoc"])), int(j["refEndLoc"]), mx[0], mx[1], mx[2])
+                    assert out["match"][i, : res["match_len"]].tobytes() == tb
+                checked_jobs += 1
+    assert checked_jobs > 20
