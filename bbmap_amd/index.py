@@ -25,10 +25,23 @@ def rc_keys(keys, k):
     return out
 
 
-class HostIndex:
-    """The arrays BBIndex reads: per-block CSR (starts, sites), COUNTS, the length histogram, the tunables."""
+def _rc_keys_torch(keys, k):
+    import torch
+    out = torch.zeros_like(keys)
+    x = keys.clone()
+    for _ in range(k):
+        out = (out << 2) | ((~x) & 3)
+        x >>= 2
+    return out
 
-    def __init__(self, chroms, k=13, chromBits=None):
+
+class HostIndex:
+    """The arrays BBIndex reads: per-block CSR (starts, sites), COUNTS, the length histogram, the tunables.
+
+    backend="numpy" builds on the host; backend="torch" runs the same count -> scan -> scatter on the GPU
+    (every step is a bandwidth-bound pass over the genome or the key space) and copies the arrays back."""
+
+    def __init__(self, chroms, k=13, chromBits=None, backend="auto", device=0):
         self.k = k
         self.chroms = [np.ascontiguousarray(np.frombuffer(bytes(c), np.uint8)) if not isinstance(c, np.ndarray)
                        else np.ascontiguousarray(c, dtype=np.uint8) for c in chroms]
@@ -38,21 +51,44 @@ class HostIndex:
             chromBits = min(16, (32 - int(maxlen).bit_length()) - 1)
         self.chromBits = chromBits
         self.nchroms = n
+        self.nblocks = (n >> chromBits) + 1
+        if backend == "auto":
+            backend = "numpy"
+            if k >= 12:
+                try:
+                    import torch
+                    if torch.cuda.is_available():
+                        backend = "torch"
+                except Exception:
+                    pass
+        if backend == "torch":
+            self._build_torch(device)
+        else:
+            self._build_numpy()
+        self.length_histogram = self._length_histogram(self.counts)
+        self._set_params()
+
+    # -- shared pieces -----------------------------------------------------------------------------
+    def _block_chroms(self, b):
+        cpb = 1 << self.chromBits
+        return range(max(1, b * cpb), min(self.nchroms, b * cpb + cpb - 1) + 1)
+
+    def _build_numpy(self):
+        k, n, chromBits = self.k, self.nchroms, self.chromBits
         keyspace = 1 << (2 * k)
         cpb = 1 << chromBits
         shift = 31 - chromBits
-        self.nblocks = (n >> chromBits) + 1
         lut = np.full(256, -1, np.int64)
         for i, ch in enumerate(b"ACGT"):
             lut[ch] = i
         banmask = (1 << (2 * k - 4)) - 1
         self.starts, self.sites = [], []
-        counts = np.zeros(keyspace, np.int64)
-        clump_keys, clump_vals = [], []
+        counts = np.zeros(keyspace, np.int32)
+        clump_keys = []
         self.defined_bases = 0
         for b in range(self.nblocks):
             keys_all, sites_all = [], []
-            for chrom in range(max(1, b * cpb), min(n, b * cpb + cpb - 1) + 1):
+            for chrom in self._block_chroms(b):
                 arr = self.chroms[chrom - 1]
                 code = lut[arr]
                 self.defined_bases += int((code >= 0).sum())
@@ -71,45 +107,103 @@ class HostIndex:
                 pos = np.nonzero(valid)[0]
                 keys_all.append(key[pos])
                 sites_all.append((((chrom & (cpb - 1)) << shift) | pos).astype(np.int64))
-            if keys_all:
-                keys_cat = np.concatenate(keys_all)
-                sites_cat = np.concatenate(sites_all)
-            else:
-                keys_cat = np.zeros(0, np.int64)
-                sites_cat = np.zeros(0, np.int64)
+            keys_cat = np.concatenate(keys_all) if keys_all else np.zeros(0, np.int64)
+            sites_cat = np.concatenate(sites_all) if sites_all else np.zeros(0, np.int64)
             order = np.argsort(keys_cat, kind="stable")      # genome order inside each list, like the reference
             keys_sorted = keys_cat[order]
             sites = sites_cat[order].astype(np.int32)
-            cnt = np.bincount(keys_sorted, minlength=keyspace)
-            starts = np.zeros(keyspace + 1, np.int64)
-            np.cumsum(cnt, out=starts[1:])
-            counts += cnt
-            # clumpy keys: neighbours in a list at distance 1..5 (BBIndex.java:125-143)
-            if len(sites) > 1:
+            uniq, cnt = np.unique(keys_sorted, return_counts=True)
+            c32 = np.zeros(keyspace + 1, np.int32)
+            c32[uniq + 1] = cnt
+            counts[uniq] += cnt.astype(np.int32)
+            starts = np.cumsum(c32, dtype=np.int32)
+            if len(sites) > 1:                                 # clumpy keys (BBIndex.java:125-143)
                 dif = sites[1:].astype(np.int64) - sites[:-1].astype(np.int64)
-                same = keys_sorted[1:] == keys_sorted[:-1]
-                hit = same & (dif > 0) & (dif <= 5)
+                hit = (keys_sorted[1:] == keys_sorted[:-1]) & (dif > 0) & (dif <= 5)
                 if hit.any():
                     kk = keys_sorted[1:][hit]
                     clump_keys.append(np.minimum(kk, rc_keys(kk, k)))
-            self.starts.append(starts.astype(np.int32))
+            self.starts.append(starts)
             self.sites.append(np.ascontiguousarray(sites))
-        counts = np.minimum(counts, 2**31 - 1)
-        allk = np.arange(keyspace, dtype=np.int64)
-        rk = rc_keys(allk, k)
-        comb = np.where(allk != rk, np.minimum(counts + counts[rk], 2**31 - 1), counts)
-        counts = comb
+        # COUNTS[key] = len(key) + len(rc(key)) (BBIndex.java:147-153): only keys that occur need touching
+        nz = np.nonzero(counts)[0].astype(np.int64)
+        rk = rc_keys(nz, k)
+        own, other = counts[nz].astype(np.int64), counts[rk].astype(np.int64)
+        comb = np.where(nz != rk, np.minimum(own + other, 2**31 - 1), own).astype(np.int32)
+        counts[nz] = comb
+        counts[rk] = comb
         if clump_keys:
-            ck = np.concatenate(clump_keys)
-            clumps = np.bincount(ck, minlength=keyspace)
-            cand = np.nonzero(clumps)[0]
-            ln = counts[cand]
-            zero = cand[(ln > 2000) & (clumps[cand].astype(np.float32) > np.float32(0.75) * ln.astype(np.float32))]
+            ck, cc = np.unique(np.concatenate(clump_keys), return_counts=True)
+            ln = counts[ck].astype(np.int64)
+            zero = ck[(ln > 2000) & (cc.astype(np.float32) > np.float32(0.75) * ln.astype(np.float32))]
             counts[zero] = 0
-            counts[rk[zero]] = 0
-        self.counts = counts.astype(np.int32)
-        self.length_histogram = self._length_histogram(self.counts)
-        self._set_params()
+            counts[rc_keys(zero, k)] = 0
+        self.counts = counts
+
+    def _build_torch(self, device):
+        import torch
+        dev = torch.device("cuda", device)
+        k, chromBits = self.k, self.chromBits
+        keyspace = 1 << (2 * k)
+        cpb = 1 << chromBits
+        shift = 31 - chromBits
+        lut = torch.full((256,), -1, dtype=torch.int64, device=dev)
+        for i, ch in enumerate(b"ACGT"):
+            lut[ch] = i
+        banmask = (1 << (2 * k - 4)) - 1
+        self.starts, self.sites = [], []
+        counts = torch.zeros(keyspace, dtype=torch.int64, device=dev)
+        clump = torch.zeros(0, dtype=torch.int64, device=dev)
+        self.defined_bases = 0
+        for b in range(self.nblocks):
+            keys_all, sites_all = [], []
+            for chrom in self._block_chroms(b):
+                arr = torch.from_numpy(self.chroms[chrom - 1]).to(dev)
+                code = lut[arr.long()]
+                self.defined_bases += int((code >= 0).sum().item())
+                L = arr.numel()
+                npos = L - k
+                if npos <= 0:
+                    continue
+                csum = torch.cat((torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum((code < 0).long(), 0)))
+                valid = (csum[k:k + npos] - csum[:npos]) == 0
+                c2 = torch.where(code < 0, torch.zeros_like(code), code)
+                key = torch.zeros(npos, dtype=torch.int64, device=dev)
+                for j in range(k):
+                    key = (key << 2) | c2[j:j + npos]
+                valid &= (key >> 4) != (key & banmask)
+                pos = torch.nonzero(valid).flatten()
+                keys_all.append(key[pos])
+                sites_all.append(((chrom & (cpb - 1)) << shift) | pos)
+            keys_cat = torch.cat(keys_all) if keys_all else torch.zeros(0, dtype=torch.int64, device=dev)
+            sites_cat = torch.cat(sites_all) if sites_all else torch.zeros(0, dtype=torch.int64, device=dev)
+            keys_sorted, order = torch.sort(keys_cat, stable=True)
+            sites = sites_cat[order].to(torch.int32)
+            cnt = torch.bincount(keys_sorted, minlength=keyspace)
+            starts = torch.zeros(keyspace + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(cnt, 0, out=starts[1:])
+            counts += cnt
+            if sites.numel() > 1:
+                dif = sites[1:].long() - sites[:-1].long()
+                hit = (keys_sorted[1:] == keys_sorted[:-1]) & (dif > 0) & (dif <= 5)
+                kk = keys_sorted[1:][hit]
+                clump = torch.cat((clump, torch.minimum(kk, _rc_keys_torch(kk, k))))
+            self.starts.append(starts.to(torch.int32).cpu().numpy())
+            self.sites.append(np.ascontiguousarray(sites.cpu().numpy()))
+            del cnt, starts, keys_sorted, order
+        nz = torch.nonzero(counts).flatten()
+        rk = _rc_keys_torch(nz, k)
+        own, other = counts[nz], counts[rk]
+        comb = torch.where(nz != rk, torch.clamp(own + other, max=2**31 - 1), own)
+        counts[nz] = comb
+        counts[rk] = comb
+        if clump.numel():
+            ck, cc = torch.unique(clump, return_counts=True)
+            ln = counts[ck]
+            zero = ck[(ln > 2000) & (cc.float() > 0.75 * ln.float())]
+            counts[zero] = 0
+            counts[_rc_keys_torch(zero, k)] = 0
+        self.counts = counts.to(torch.int32).cpu().numpy()
 
     @staticmethod
     def _length_histogram(counts, buckets=1000):

@@ -99,3 +99,31 @@ def algorithmic_bytes(jobs):
     rows = jobs["read_len"].astype(np.int64)
     cols = (jobs["refEndLoc"].astype(np.int64) - jobs["refStartLoc"].astype(np.int64) + 1)
     return int((2 * (rows + cols) + 59).sum())
+
+
+def make_offsets(readlen, blocksize, density, min_keys=2):
+    """KeyRing.makeOffsets(readlen, blocksize, density, minKeysDesired) (current/align2/KeyRing.java:255-297,
+    makeOffsetsWithNumberOfKeys :186-229): evenly spaced key offsets.  Host-side input generation: in the
+    reference this (and the quality-driven makeOffsets3) runs in Java before findAdvanced is called."""
+    if readlen < blocksize:
+        return []
+    slots = readlen - blocksize + 1
+    desired = int(np.ceil(np.float64(np.float32(readlen) * np.float32(density) / np.float32(blocksize))))
+    desired = min(slots, max(min_keys, desired))
+    if slots == 1 or desired == 1:
+        return [slots // 2]
+    if slots == 2 or desired == 2:
+        return [0, slots - 1]
+    if slots == 3 or desired == 3:
+        return [0, slots // 2, slots - 1]
+    midslots = slots - 2
+    middles = min(min(desired, slots) - 2, midslots)
+    fsp = max(np.float32(1.0), np.float32(midslots) / np.float32(middles + 1.0))
+    offs = [0] * (middles + 2)
+    offs[-1] = slots - 1
+    for i in range(1, middles + 1):
+        offs[i] = int(np.floor(np.float32(fsp * np.float32(i)) + np.float32(0.5)))
+    if middles > 2:
+        offs[1] = int(fsp)
+        offs[middles] = int(np.ceil(np.float64(np.float32(fsp * np.float32(middles)))))
+    return offs

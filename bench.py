@@ -47,29 +47,103 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(jobs, reads, ref, max_rows, max_cols, target_seconds=15.0):
-    """Times the CPU oracle (a port of the reference's C + Java walkers) on a bounded sample."""
-    from oracle import oracle as orc
-    L = orc.lib()
-    L.orc_bench_align.restype = C.c_double
-    L.orc_bench_align.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                  C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-    cores = usable_cores()
-    jobs = np.ascontiguousarray(jobs)
-    cells, chk = C.c_int64(), C.c_int64()
+def _emulate_read(oi, om, refb, bp, bm, offsets, key_scores, max_sites, L):
+    """The reference's control flow for one read, from the oracle's pieces (probe -> scoreNoIndels -> scoreSlow)."""
+    from oracle.oracle import score_no_indels
+    maxSw = 70 + (L - 1) * 100
+    maxImp = maxSw - 495
+    minMsaLimit = -258 + int(np.float32(0.56) * np.float32(maxSw))
+    sites = oi.find(bp, bm, [0] * L, key_scores, offsets, cap=max_sites)
+    near, force, sws = 0, False, []
+    for e in sites:
+        if e["perfect"]:
+            sw = maxSw
+            near += 1
+        else:
+            sw = score_no_indels(bm if e["strand"] else bp, refb, e["start"])
+            if sw >= maxImp:
+                near += 1
+                e["stop"] = e["start"] + L - 1
+                e["gaps"] = []
+            elif e["score"] >= maxImp:
+                force = True
+        sws.append(sw)
+    dp = []
+    if (-near if force else near) < 1:
+        for s, e in enumerate(sites):
+            semip = e["semiperfect"] or sws[s] >= maxSw
+            if sws[s] < maxImp and not semip and not e["gaps"]:
+                bases = bm if e["strand"] else bp
+                ms = max(sws[s], minMsaLimit)
+                sv, mx = om.fillAndScoreLimited(bases, refb, e["start"] - 4, e["stop"] + 4, ms)
+                tb = None
+                if sv is not None:
+                    tb = om.traceback(bases, refb, max(0, e["start"] - 4), e["stop"] + 4, mx[0], mx[1], mx[2])
+                dp.append((s, sv, tb))
+    return sites, sws, dp
 
-    def run(n):
-        return L.orc_bench_align(jobs.ctypes.data, n, reads.ctypes.data, ref.ctypes.data, max_rows, max_cols,
-                                 cores, 1, C.byref(cells), C.byref(chk))
-    probe_n = min(len(jobs), 2000 * cores)
+
+def parity_sample(pipe, out, reads, ref, hi, offsets, key_scores, count, max_sites, max_cols):
+    """Checks the first `count` reads of the last step end to end against the oracle."""
+    from oracle.oracle import OracleIndex, OracleMSA
+    L = pipe.read_len
+    oi = OracleIndex([ref], k=hi.k, chromBits=hi.chromBits)
+    om = OracleMSA(160, max_cols)
+    refb = ref.tobytes()
+    comp = np.full(256, 255, np.uint8)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+    by_src = {int(s): i for i, s in enumerate(out["src"])}
+    bad = 0
+    for r in range(count):
+        bp_a = reads[r * L:(r + 1) * L]
+        bp, bm = bp_a.tobytes(), comp[bp_a[::-1]].tobytes()
+        sites, sws, dp = _emulate_read(oi, om, refb, bp, bm, offsets, key_scores, max_sites, L)
+        ok = int(out["nsites"][r]) == len(sites)
+        for s, e in enumerate(sites if ok else []):
+            g = out["sites"][r, s]
+            ok &= (int(g["chrom"]), int(g["strand"]), int(g["start"]), int(g["hits"])) == (e["chrom"], e["strand"], e["start"], e["hits"])
+            ok &= int(out["no_indel"][r, s]) == sws[s]
+        want = {s for s, _, _ in dp}
+        have = {src % max_sites for src in by_src if src // max_sites == r}
+        ok &= want == have
+        for s, sv, tb in (dp if ok else []):
+            i = by_src[r * max_sites + s]
+            res = out["results"][i]
+            gs = None if res["score_len"] == 0 else res["score"][: res["score_len"]].tolist()
+            ok &= gs == sv
+            if sv is not None:
+                ok &= out["match"][i, : res["match_len"]].tobytes() == tb
+        bad += (not ok)
+    return {"checked_reads": count, "mismatches": bad}
+
+
+def cpu_baseline(k, chrom_bits, reads, ref, L, offsets, key_scores, max_cols, target_seconds=15.0):
+    """The same per-read pipeline on the host cores, built from the CPU oracle (a port of the reference's logic):
+    probe + ungapped filter + DP + traceback (oracle/bench_oracle.c:orc_bench_map), one worker thread per usable
+    core sharing one read-only index, on a bounded sample of the same read batch."""
+    from oracle.oracle import OracleIndex
+    cores = usable_cores()
+    oi = OracleIndex([ref], k=k, chromBits=chrom_bits)
+    L_ = oi.L
+    L_.orc_bench_map.restype = C.c_double
+    L_.orc_bench_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    offs = np.asarray(offsets, np.int32)
+    ks = np.asarray(key_scores, np.int32)
+    nreads = len(reads) // L
+    mapped, jobs, cells = C.c_int64(), C.c_int64(), C.c_int64()
+
+    def run(count):
+        return L_.orc_bench_map(C.c_void_p(oi.h), reads.ctypes.data, count, L, offs.ctypes.data, ks.ctypes.data, len(offs),
+                                max_cols, cores, C.byref(mapped), C.byref(jobs), C.byref(cells))
+    probe_n = min(nreads, 2000 * cores)
     t = run(probe_n)
-    rate = probe_n / max(t, 1e-6)
-    n = int(min(len(jobs), max(probe_n, rate * target_seconds)))
-    t = run(n)
-    return {"value": n / t, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads of the same job list, fillAndScoreLimited+traceback, %d threads, %.1f s"
-                      % (n, cores, t),
-            "cells_per_s": cells.value / t}
+    count = int(min(nreads, max(probe_n, probe_n / max(t, 1e-6) * target_seconds)))
+    t = run(count)
+    return {"value": count / t, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads of the same batch through probe + ungapped filter + DP + traceback on the CPU oracle, "
+                      "%d threads, %.1f s; %d DP jobs, %d reads mapped" % (count, cores, t, jobs.value, mapped.value)}
 
 
 def main():
@@ -79,17 +153,35 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU per step")
     ap.add_argument("--ref-len", type=int, default=0, help="reference length (default: E. coli K-12)")
+    ap.add_argument("--k", type=int, default=13)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parity-sample", type=int, default=2000)
+    ap.add_argument("--parity-sample", type=int, default=300)
     args = ap.parse_args()
 
     import torch
     from bbmap_amd import msa as M
     from bbmap_amd import workload as W
+    from bbmap_amd.index import HostIndex
+    from bbmap_amd.pipeline import MapPipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    read_len, k = 150, args.k
+    ref_len = args.ref_len or W.ECOLI_K12_LEN
+    ref = W.make_reference(ref_len, seed=1)
+    # every rank draws its own shard of reads (same generator, different stream); the index is replicated per GPU
+    reads, _, truth = W.make_reads_and_jobs(ref, args.reads, read_len=read_len, seed=2 + 1000 * rank)
+    offsets = W.make_offsets(read_len, k, 1.9)
+    key_scores = [100 * k] * len(offsets)          # GENERATE_KEY_SCORES_FROM_QUALITY needs qualities; synthetic reads have none
+    max_sites, max_cols = 8, 256
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        # host-only work, done before this process touches the GPU
+        chrom_bits = min(16, (32 - int(len(ref)).bit_length()) - 1)
+        cpu = cpu_baseline(k, chrom_bits, reads, ref, read_len, offsets, key_scores, max_cols)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -98,111 +190,100 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    read_len = 150
-    ref_len = args.ref_len or W.ECOLI_K12_LEN
-    ref = W.make_reference(ref_len, seed=1)
-    # every rank draws its own shard of reads (same generator, different stream)
-    reads, jobs, truth = W.make_reads_and_jobs(ref, args.reads, read_len=read_len, seed=2 + 1000 * rank)
-    cols = (jobs["refEndLoc"] - jobs["refStartLoc"] + 1)
-    max_rows, max_cols = 160, 256
-    assert int(cols.max()) <= max_cols
-    match_stride = 352
-    n = len(jobs)
-
-    dev = torch.device("cuda", local_rank)
-    d_ref = torch.from_numpy(ref).to(dev)
-    d_reads = torch.from_numpy(reads).to(dev)
-    d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(dev)
-    d_res = torch.zeros(n * M.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    d_match = torch.zeros(n * match_stride, dtype=torch.uint8, device=dev)
-    ctx = M.MSAContext(maxRows=max_rows, maxColumns=max_cols, device=local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        ctx.align_batch_device(n, d_jobs.data_ptr(), d_reads.data_ptr(), d_ref.data_ptr(), d_res.data_ptr(),
-                               d_match.data_ptr(), match_stride, stream)
+    n = args.reads
+    t_ix = time.perf_counter()
+    hi = HostIndex([ref], k=k, backend="torch", device=local_rank)
+    t_ix = time.perf_counter() - t_ix
+    pipe = MapPipeline(hi, n, read_len, offsets, key_scores, device=local_rank, max_sites=max_sites, max_columns=max_cols)
+    pipe.load_reads(reads)
 
     for _ in range(args.warmup):
-        step()
+        pipe.step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms, slow_ms = [], []
+    dp_ms, probe_ms, njobs_hist, probe_stats = [], [], [], None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        a, b = ctx.last_kernel_ms()     # HIP events recorded on the launch stream around the kernels
-        kernel_ms.append(a)
-        slow_ms.append(b)
+        nj = pipe.step()
+        njobs_hist.append(nj)
+        st, pms = pipe.probe_stats()            # HIP events on the launch stream around the probe kernel
+        probe_ms.append(pms)
+        probe_stats = st
+        dp_ms.append(pipe.msa.last_kernel_ms()[0] if nj else 0.0)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=pipe.dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     # ---- outside the timed region: checks and bookkeeping
-    res = d_res.cpu().numpy().view(M.RESULT_DTYPE)
-    aligned = int((res["score_len"] > 0).sum())
-    cells = int(res["iterations"].sum())
+    njobs = njobs_hist[-1]
+    out = pipe.fetch(njobs)
+    cnt = pipe.last_counters
+    res = out["results"]
+    dp_ok = np.zeros(n, bool)
+    if njobs:
+        np.logical_or.at(dp_ok, out["src"] // max_sites, res["score_len"] > 0)
+    mapped = int(((out["nsites"] > 0) & ((out["no_indel"].max(axis=1) >= 70 + 149 * 100 - 495) | dp_ok)).sum())
+    cells = int(res["iterations"].sum()) if njobs else 0
     parity = None
     if rank == 0 and args.parity_sample > 0:
-        from oracle.oracle import OracleMSA
-        om = OracleMSA(max_rows, max_cols)
-        refb = ref.tobytes()
-        mt = d_match[: args.parity_sample * match_stride].cpu().numpy().reshape(-1, match_stride)
-        bad = 0
-        for k in range(min(n, args.parity_sample)):
-            j = jobs[k]
-            rd = reads[j["read_off"]: j["read_off"] + j["read_len"]].tobytes()
-            sv, mx = om.fillAndScoreLimited(rd, refb, int(j["refStartLoc"]), int(j["refEndLoc"]), int(j["minScore"]))
-            g = res[k]
-            gs = None if g["score_len"] == 0 else g["score"][: g["score_len"]].tolist()
-            ok = gs == sv
-            if ok and sv is not None:
-                tb = om.traceback(rd, refb, int(j["refStartLoc"]), int(j["refEndLoc"]), mx[0], mx[1], mx[2])
-                ok = mt[k, : g["match_len"]].tobytes() == tb
-            bad += (not ok)
-        parity = {"checked": min(n, args.parity_sample), "mismatches": bad}
-        if bad:
-            raise SystemExit("parity check failed: %d of %d sample alignments differ from the oracle" % (bad, parity["checked"]))
+        parity = parity_sample(pipe, out, reads, ref, hi, offsets, key_scores, min(n, args.parity_sample), max_sites, max_cols)
+        if parity["mismatches"]:
+            raise SystemExit("parity check failed: %s" % parity)
 
     if rank == 0:
         total_reads = n * world * args.steps
         value = total_reads / elapsed
-        k_ms = float(np.mean(kernel_ms))
-        alg_bytes = W.algorithmic_bytes(jobs)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        d_ms, p_ms = float(np.mean(dp_ms)), float(np.mean(probe_ms))
+        jobs = out["jobs"]
+        dp_bytes = W.algorithmic_bytes(jobs) if njobs else 0
+        nkeys = len(offsets)
+        # 2 strands x nkeys x (8 + 8) + 2 x 4 x (list entries streamed) + ref bytes compared + 64 x sites out
+        probe_bytes = n * 2 * nkeys * 16 + 4 * (probe_stats[0] + probe_stats[1]) + probe_stats[3] + 64 * probe_stats[4]
+        if d_ms >= p_ms:
+            dom, dom_ms, dom_bytes = "msa_fill_fast_kernel", d_ms, dp_bytes
+        else:
+            dom, dom_ms, dom_bytes = "probe_kernel", p_ms, probe_bytes
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("msa_fill_fast_kernel_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(dom + "_bytes_per_launch")
             except Exception:
                 traffic = None
-        out = {
+        out_json = {
             "metric": "aligned_reads_per_sec", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic E. coli K-12 sized reference (%d bp, seed 1), %d x %d-bp SE reads "
-                                   "per GPU (seed 2, mutated mix); slow-align DP stage only: one fillAndScoreLimited + "
-                                   "traceback per read at its candidate site (index probe not yet on the GPU)" % (ref_len, n, read_len),
-                       "reads_per_gpu_per_step": n, "read_len": read_len, "mean_columns": float(cols.mean()),
-                       "aligned_fraction": aligned / n, "dp_cells_per_step": cells,
-                       "gcups": cells / (k_ms * 1e-3) / 1e9, "parity": parity},
+            "config": {"workload": "configs[1]: synthetic E. coli K-12 sized reference (%d bp, seed 1), %d x %d-bp SE reads per GPU "
+                                   "(seed 2, mutated mix), k=%d index resident in HBM; per step: reverse complement -> index probe "
+                                   "(BBIndex.findAdvanced) -> ungapped site filter -> slow-align DP + traceback for the sites that "
+                                   "need it" % (ref_len, n, read_len, k),
+                       "reads_per_gpu_per_step": n, "read_len": read_len, "keys_per_read": nkeys,
+                       "dp_jobs_per_step": njobs, "reads_finished_without_dp": int(cnt[1]), "reads_without_site": int(cnt[3]),
+                       "mapped_fraction": mapped / n, "dp_cells_per_step": cells,
+                       "dp_gcups": (cells / (d_ms * 1e-3) / 1e9) if d_ms > 0 else 0.0,
+                       "probe_list_entries_per_step": int(probe_stats[0] + probe_stats[1]),
+                       "probe_extend_calls_per_step": int(probe_stats[2]),
+                       "index_build_s_gpu": t_ix, "parity": parity},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "msa_fill_fast_kernel", "kernel_ms": k_ms, "generic_kernel_ms": float(np.mean(slow_ms)),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": dom, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(dom_bytes),
+                         "kernels": {"probe_kernel": {"ms": p_ms, "algorithmic_bytes": int(probe_bytes)},
+                                     "msa_fill_fast_kernel": {"ms": d_ms, "algorithmic_bytes": int(dp_bytes)}}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(jobs, reads, ref, max_rows, max_cols)
-        print(json.dumps(out))
+        if cpu is not None:
+            out_json["cpu_baseline"] = cpu
+        print(json.dumps(out_json))
     if dist is not None:
         dist.destroy_process_group()
 
