@@ -173,7 +173,8 @@ def main():
     ref_len = args.ref_len or W.ECOLI_K12_LEN
     ref = W.make_reference(ref_len, seed=1)
     # every rank draws its own shard of reads (same generator, different stream); the index is replicated per GPU
-    reads, _, truth = W.make_reads_and_jobs(ref, args.reads, read_len=read_len, seed=2 + 1000 * rank)
+    from bbmap_amd import dist as D
+    reads, _, truth = W.make_reads_and_jobs(ref, args.reads, read_len=read_len, seed=D.shard_seed(2, rank))
     offsets = W.make_offsets(read_len, k, 1.9)
     key_scores = [100 * k] * len(offsets)          # GENERATE_KEY_SCORES_FROM_QUALITY needs qualities; synthetic reads have none
     max_sites, max_cols = 8, 256
@@ -218,9 +219,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=pipe.dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = D.max_over_ranks(elapsed, dist, pipe.dev)
 
     # ---- outside the timed region: checks and bookkeeping
     njobs = njobs_hist[-1]

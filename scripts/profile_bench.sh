@@ -1,5 +1,5 @@
 #!/bin/bash
-# Profiles bench.py's kernels on the GPU box: kernel trace/stats first, then PMC passes (separate runs).
+# Profiles bench.py (whole pipeline) on the GPU box: kernel trace/stats first, then PMC passes (separate runs).
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
