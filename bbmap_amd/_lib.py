@@ -15,7 +15,7 @@ EXPORTS = [
     "bbmsa_create", "bbmsa_destroy", "bbmsa_align_batch_device", "bbmsa_align_batch",
     "bbmsa_last_kernel_ms",
     "bbband_create", "bbband_destroy", "bbband_align_batch_device", "bbband_align_batch",
-    "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch", "bbidx_last_stats",
+    "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch", "bbidx_last_stats", "bbidx_set_kernel",
     "bbpipe_revcomp_device", "bbpipe_select_jobs_device",
 ]
 

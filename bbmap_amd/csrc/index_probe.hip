@@ -27,84 +27,17 @@
 #include <vector>
 
 #include "bbmap_amd.h"
+#include "index_common.h"
 
 void bbmap_set_error(const char *msg);   // msa_host.hip
 
 namespace bbidx {
-
-constexpr int KB = BBIDX_MAX_KEYS;
-constexpr int MAXLEN = BBIDX_MAX_READ_LEN;
-constexpr int BASE_HIT_SCORE = 100, Z_MULT = 20, Y_MULT = 10, SMALL_LIST = 20, MIN_LISTS_RETAIN = 6, MINGAP = 256;
-constexpr float HIT_FRACTION_TO_RETAIN = 0.85f, MIN_SCORE_MULT = 0.15f, MIN_QSCORE_MULT = 0.025f, MIN_QSCORE_MULT2 = 0.1f;
-constexpr float DYN_SCORE = 0.84f, DYN_QSCORE = 0.6f, DYN_QSCORE_PERFECT = 0.8f;
-#define PRESCAN_QSCORE_THRESH (DYN_QSCORE * .95f)
-
-struct DevIndex {
-    bbidx_params p;
-    int nblocks, nchroms;
-    const int *const *starts;
-    const int *const *sites;
-    const int *counts;
-    const int *lengthHistogram;
-    const uint8_t *const *chromArr;
-    const int *chromArrLen;
-    const int *chromLengths;
-};
-
-struct Params {
-    DevIndex ix;
-    const bbidx_read *reads;
-    const uint8_t *bases;
-    const int8_t *baseScores;
-    const int *keyinfo;
-    bbidx_site *sites;
-    int *nsites;
-    long long nreads;
-    int maxSites;
-    unsigned int *queue;
-    unsigned long long *stats;     // [4] totals of the Walker counters + [4] = site records written
-};
-
-__device__ inline int base_num(int b) {
-    switch (b) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2;
-                 case 'T': case 't': case 'U': case 'u': return 3; default: return -1; }
-}
-__device__ inline int rc_key(int kmer, int k) {
-    int out = 0;
-    for (int i = 0; i < k; i++) { out = (out << 2) | ((~kmer) & 3); kmer >>= 2; }
-    return out;
-}
-// dna/AminoAcid.java:633-645 (baseToComplementExtended); 0xFF where the reference holds -1
-__device__ inline int complement_extended(int b) {
-    switch (b) {
-        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
-        case 'M': return 'K'; case 'R': return 'Y'; case 'S': return 'W'; case 'V': return 'B';
-        case 'W': return 'S'; case 'Y': return 'R'; case 'H': return 'D'; case 'K': return 'M';
-        case 'D': return 'H'; case 'B': return 'V'; case 'N': return 'N'; case 'X': return 'X';
-        case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
-        case 'm': return 'k'; case 'r': return 'y'; case 's': return 'w'; case 'v': return 'b';
-        case 'w': return 's'; case 'y': return 'r'; case 'h': return 'd'; case 'k': return 'm';
-        case 'd': return 'h'; case 'b': return 'v'; case 'n': return 'n'; case 'x': return 'x';
-        case 'U': return 'A'; case 'u': return 'a';
-        case '?': return '?'; case ' ': return ' '; case '-': return '-'; case '*': return '*'; case '.': return '.';
-    }
-    return 0xFF;
-}
-__device__ inline int absdif(int a, int b) { return a > b ? a - b : b - a; }
 
 // the read as one strand sees it: plus = bytes as given; minus = reverse complement, base scores reversed
 struct Strand {
     const uint8_t *b; const int8_t *q; int len; bool minus;
     __device__ inline int base(int i) const { return minus ? complement_extended(b[len - 1 - i]) : b[i]; }
     __device__ inline int bscore(int i) const { return minus ? q[len - 1 - i] : q[i]; }
-};
-
-struct Codec {
-    int shift, siteMask, lowMask, highMask, cpb;
-    __device__ inline int toNumber(int site, int chrom) const { return ((chrom & lowMask) << shift) | site; }
-    __device__ inline int chromOf(int number, int baseChrom) const { return (int)((unsigned)number >> shift) + (baseChrom & highMask); }
-    __device__ inline int siteOf(int number) const { return number & siteMask; }
-    __device__ inline int baseChrom(int chrom) const { return max(0, chrom & highMask); }
 };
 
 struct Walker {
@@ -123,12 +56,6 @@ struct Lists {
     const int *sites;
 };
 
-__device__ int calcApproxHitsCutoff(const bbidx_params &p, int keys, int hits, int currentCutoff, bool perfect) {
-    const int reduction = min(max(hits / p.hitReductionDiv, p.maxHitsReduction2), max(p.maximumMaxHitsReduction, keys / 8));
-    int r = max(p.minApproxHitsToKeep, max(currentCutoff, hits - reduction));
-    if (perfect) r = max(r, keys);
-    return r;
-}
 __device__ int maxScoreZ(const Walker &w, const int *offsets, int n) {
     int score = 0, a0 = -1, b0 = -1;
     for (int i = 0; i < n; i++) { const int a = offsets[i]; if (b0 < a) { score += b0 - a0; a0 = a; } b0 = a + w.k; }
@@ -243,20 +170,6 @@ __device__ void findMaxQscore2(const Walker &w, Lists &L, int baseChrom, int pre
 }
 
 // MultiStateAligner11tsJNI.calcAffineScore(locArray, baseScores, bases[, minContig]) in plain points
-__device__ inline int calcDelScoreApprox(int len) {      // MultiStateAligner11tsJNI.java:1347-1376 with approximateGaps
-    if (len <= 0) return 0;
-    int score = -472;
-    if (len > MINGAP) { const int rem = len % 128, div = (len - 128) / 128; score += div * -2; len = rem + 128; }
-    if (len > 80) { score += ((len - 80 + 3) / 4) * -1; len = 80; }
-    if (len > 20) { score += (len - 20) * -1; len = 20; }
-    if (len > 5) { score += (len - 5) * -9; len = 5; }
-    if (len > 1) score += (len - 1) * -33;
-    return score;
-}
-__device__ inline int insCum(int n) {                    // POINTS_INS_ARRAY_C[n], n in 1..5
-    return -395 + (n > 1 ? (n - 1) * -39 : 0);
-}
-__device__ inline int subArr(int t) { return t > 5 ? -25 : (t > 1 ? -51 : -127); }   // POINTS_SUB_ARRAY[t]
 __device__ int calcAffineScore(const int *locArray, int n, const Strand &rd, int minContig) {
     int contig = 0, maxContig = 0, score = 0, lastLoc = -3, lastValue = -1, timeInMode = 0;
     for (int i = 0; i < n; i++) {
@@ -646,9 +559,12 @@ __global__ __launch_bounds__(64) void probe_kernel(const Params P) {
     int locArray[MAXLEN];
     Lists L;
 
+    // second pass behind the wave kernel: nothing to do unless it left reads pending
+    if (P.onlyPending && __hip_atomic_load(&P.queue[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     for (;;) {
         const long long r = (long long)atomicAdd(P.queue, 1u);
         if (r >= P.nreads) break;
+        if (P.onlyPending && P.nsites[r] != NSITES_PENDING) continue;
         const bbidx_read rr = P.reads[r];
         const int blen = rr.len;
         int n = rr.nkeys;
@@ -763,9 +679,10 @@ __global__ __launch_bounds__(64) void probe_kernel(const Params P) {
         cSites += (unsigned)ssl.n;
     }
     if (P.stats) {
-        atomicAdd(&P.stats[0], (unsigned long long)w.cPrescan); atomicAdd(&P.stats[1], (unsigned long long)w.cWalk);
-        atomicAdd(&P.stats[2], (unsigned long long)w.cExtend); atomicAdd(&P.stats[3], (unsigned long long)w.cRefBytes);
-        atomicAdd(&P.stats[4], (unsigned long long)cSites);
+        unsigned long long *st = P.stats + 8 * (blockIdx.x % STAT_SHARDS);
+        atomicAdd(&st[0], (unsigned long long)w.cPrescan); atomicAdd(&st[1], (unsigned long long)w.cWalk);
+        atomicAdd(&st[2], (unsigned long long)w.cExtend); atomicAdd(&st[3], (unsigned long long)w.cRefBytes);
+        atomicAdd(&st[4], (unsigned long long)cSites);
     }
 }
 
@@ -781,6 +698,7 @@ struct bbidx_ctx {
     int blocks;
     hipEvent_t ev[2];
     bool timed;
+    int kernelKind;       // BBIDX_KERNEL_*
 };
 
 static thread_local char g_ierr[256];
@@ -813,6 +731,7 @@ extern "C" int bbidx_create(int32_t device, const bbidx_index_desc *d, bbidx_ctx
     bbidx_ctx *c = new (std::nothrow) bbidx_ctx();
     if (!c) return ifail(BBMAP_E_NOMEM, "bbidx_create: out of memory");
     c->device = device;
+    c->kernelKind = BBIDX_KERNEL_AUTO;
     c->blocks = prop.multiProcessorCount * 8;
     const size_t keyspace = (size_t)1 << (2 * p.k);
     int rc = BBMAP_OK;
@@ -832,7 +751,7 @@ extern "C" int bbidx_create(int32_t device, const bbidx_index_desc *d, bbidx_ctx
     if (rc == BBMAP_OK) rc = upload(c, d->chromArrLen, (size_t)d->nchroms + 1, &c->dev.chromArrLen);
     if (rc == BBMAP_OK) rc = upload(c, d->chromLengths, (size_t)d->nchroms + 1, &c->dev.chromLengths);
     if (rc == BBMAP_OK && hipMalloc(&c->d_queue, 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
-    if (rc == BBMAP_OK && hipMalloc(&c->d_stats, 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
+    if (rc == BBMAP_OK && hipMalloc(&c->d_stats, bbidx::STAT_SHARDS * 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
     if (rc == BBMAP_OK && (hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess)) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipEventCreate failed");
     if (rc != BBMAP_OK) { bbidx_destroy(c); return rc; }
     *out = c;
@@ -859,14 +778,21 @@ extern "C" int bbidx_find_batch_device(bbidx_ctx *c, void *stream_, int64_t n, c
     hipStream_t stream = (hipStream_t)stream_;
     IHIP(hipSetDevice(c->device));
     IHIP(hipMemsetAsync(c->d_queue, 0, 64, stream));
-    IHIP(hipMemsetAsync(c->d_stats, 0, 64, stream));
+    IHIP(hipMemsetAsync(c->d_stats, 0, bbidx::STAT_SHARDS * 64, stream));
     bbidx::Params P;
     P.stats = c->d_stats;
     P.ix = c->dev; P.reads = reads; P.bases = bases; P.baseScores = baseScores; P.keyinfo = keyinfo;
     P.sites = sites; P.nsites = nsites; P.nreads = n; P.maxSites = max_sites; P.queue = c->d_queue;
+    P.onlyPending = 0;
     long long blocks = (n + 63) / 64;
     if (blocks > c->blocks) blocks = c->blocks;
     IHIP(hipEventRecord(c->ev[0], stream));
+    if (c->kernelKind == BBIDX_KERNEL_AUTO) {
+        // one read per wavefront; reads it cannot take (more than 64 keys) are marked and picked up by the per-lane kernel
+        const int rc = bbidx_launch_wave(P, stream);
+        if (rc != BBMAP_OK) return rc;
+        P.onlyPending = 1;
+    }
     hipLaunchKernelGGL(bbidx::probe_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, P);
     IHIP(hipGetLastError());
     IHIP(hipEventRecord(c->ev[1], stream));
@@ -929,6 +855,17 @@ extern "C" int bbidx_last_stats(bbidx_ctx *c, int64_t *stats5, float *kernel_ms)
     IHIP(hipSetDevice(c->device));
     IHIP(hipEventSynchronize(c->ev[1]));
     if (kernel_ms) IHIP(hipEventElapsedTime(kernel_ms, c->ev[0], c->ev[1]));
-    if (stats5) IHIP(hipMemcpy(stats5, c->d_stats, 5 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (stats5) {
+        std::vector<unsigned long long> h((size_t)bbidx::STAT_SHARDS * 8);
+        IHIP(hipMemcpy(h.data(), c->d_stats, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int j = 0; j < 5; j++) stats5[j] = 0;
+        for (int s = 0; s < bbidx::STAT_SHARDS; s++) for (int j = 0; j < 5; j++) stats5[j] += (int64_t)h[(size_t)s * 8 + j];
+    }
+    return BBMAP_OK;
+}
+
+extern "C" int bbidx_set_kernel(bbidx_ctx *c, int32_t kind) {
+    if (!c || (kind != BBIDX_KERNEL_AUTO && kind != BBIDX_KERNEL_LANE)) return ifail(BBMAP_E_ARG, "bbidx_set_kernel: bad argument");
+    c->kernelKind = kind;
     return BBMAP_OK;
 }

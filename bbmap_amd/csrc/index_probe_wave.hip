@@ -1,0 +1,877 @@
+// k-mer index probe (align2.BBIndex.findAdvanced) on gfx950 -- ONE READ PER WAVEFRONT.
+//
+// BBIndex.find is an order-dependent state machine per read, so a read cannot be split across workgroups; but every
+// step inside it is a small data-parallel operation over the read's K keys (K <= 64) or its L bases:
+//   * lane i owns key/list i: the list cursor, its current site, offset and key score live in that lane's registers;
+//   * the reference's binary heap (QuadHeap) only ever exposes its minimum under (site, column): a DPP min-reduction
+//     plus a ballot gives the same element; the "how many lists are near this site" scans are ballots + popcounts;
+//   * extendScore / setPerfect / calcAffineScore walk the read 64 bases per step against coalesced reference bytes,
+//     the per-base location array lives in LDS; sequential carry (first stop, streak lengths, last defined
+//     location) is recovered from ballot masks with count-leading/trailing-zero arithmetic;
+//   * control flow is wave-uniform by construction (every decision is taken on a ballot/readlane value), so EXEC
+//     stays full and the cross-lane operations are always legal.
+// Nothing per-read is kept in scratch memory: the per-lane kernel (index_probe.hip) spilled ~10 KB per read to HBM.
+// Reads with more than 64 keys are marked NSITES_PENDING and taken by the per-lane kernel afterwards.
+//
+// Functions follow current/align2/BBIndex.java exactly as index_probe.hip does (same citations); the two kernels and
+// the CPU oracle are compared SiteScore by SiteScore in tests/test_index_gpu.py.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdio>
+
+#include "bbmap_amd.h"
+#include "index_common.h"
+
+void bbmap_set_error(const char *msg);
+
+namespace bbidxw {
+using namespace bbidx;
+typedef unsigned long long u64;
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+struct WaveLds {
+    int loc[MAXLEN];              // the per-base location array of extendScore
+    int xch[5][64];               // lane <-> lane exchange (compaction), greedy-trim tables
+    int gaps[BBIDX_MAX_GAPS];
+    int ngaps;
+    uint8_t base[2][MAXLEN + 8];  // [0] the read as given, [1] its reverse complement
+    int8_t bsc[MAXLEN + 8];       // base scores of the plus strand
+};
+
+// LDS ordering inside one wave: DS operations execute in order, this only stops the compiler from moving or
+// caching LDS accesses across a phase boundary.
+__device__ inline void wsync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ inline int rl(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+__device__ inline u64 lt_mask(int lane) { return (1ull << lane) - 1ull; }
+__device__ inline u64 gt_mask(int lane) { return (~0ull << lane) << 1; }
+__device__ inline int hibit(u64 m) { return 63 - __builtin_clzll(m); }
+
+struct OpMin { __device__ inline int operator()(int a, int b) const { return min(a, b); } };
+struct OpMax { __device__ inline int operator()(int a, int b) const { return max(a, b); } };
+struct OpSum { __device__ inline int operator()(int a, int b) const { return a + b; } };
+// full-wave reduction to a uniform value: xor-1, xor-2 (quad_perm), row_half_mirror, row_mirror, then the four rows
+template <class Op> __device__ inline int wred(int v, Op op) {
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return op(op(a, b), op(c, d));
+}
+__device__ inline int wmin(int v) { return wred(v, OpMin()); }
+__device__ inline int wmax(int v) { return wred(v, OpMax()); }
+__device__ inline int wsum(int v) { return wred(v, OpSum()); }
+__device__ inline int popc(u64 m) { return __builtin_popcountll(m); }
+
+// wave-uniform state of one read
+struct U {
+    const DevIndex *ix;
+    Codec c;
+    int k, baseKeyHitScore, indelPenalty, indelPenaltyMult, maxPenalty, scoreZ1Key;
+    int lane, blen;
+    unsigned cPrescan, cWalk, cExtend, cRefBytes;
+};
+
+// one list per lane (the reference's Quad heap entries), compacted: lanes 0..n-1
+struct WL {
+    int row, stop, value, offs, ksc;
+    bool live;
+    int n, nlive;              // uniform
+    const int *sites;          // uniform
+};
+
+__device__ inline int adjustSite(const U &u, int a, int offset, int baseChrom) {
+    if ((a & u.c.siteMask) >= offset) return a - offset;
+    const int ch = u.c.chromOf(a, baseChrom), st = u.c.siteOf(a);
+    return u.c.toNumber(max(st - offset, 0), ch);
+}
+
+// BBIndex.maxQuickScore :2473-2487 over lanes 0..n-1 (offsets ascending: the coverage of maxScoreZ :2948-2964 is
+// sum(min(k, next - this)) + k)
+__device__ int maxQuickScoreW(const U &u, int off, int ksc, int n) {
+    const int nxt = __shfl_down(off, 1);
+    int contrib = 0;
+    if (u.lane < n) contrib = ksc + Z_MULT * ((u.lane < n - 1) ? min(u.k, nxt - off) : u.k);
+    return wsum(contrib) + Y_MULT * (rl(off, n - 1) - rl(off, 0));
+}
+
+// BBIndex.scoreZ2 :2882-2914
+__device__ int scoreZ2W(const U &u, int value, int offs, int centerVal, int numApproxHits, int numHits) {
+    if (numApproxHits == 1) return u.scoreZ1Key;
+    const int maxLoc = centerVal + u.ix->p.maxIndel2, minLoc = max(0, centerVal - u.ix->p.maxIndel);
+    const bool inr = u.lane < numHits && value >= minLoc && value <= maxLoc;
+    const u64 R = __ballot(inr);
+    const u64 above = R & gt_mask(u.lane);
+    const int j = above ? __builtin_ctzll(above) : u.lane;
+    const int offj = __shfl(offs, j);
+    const int contrib = inr ? (above ? min(u.k, offj - offs) : u.k) : 0;
+    return wsum(contrib) * Z_MULT;
+}
+
+// BBIndex.quickScore :2490-2511 with scoreLeft/scoreRight :2967-3035.  The chain "accept a key if it lies within
+// MAX_INDEL of the last accepted one" is sequential; when every key within MAX_INDEL of the centre sits exactly on the
+// centre (no indel between keys) the chain degenerates to a sum, otherwise it is walked with scalar readlanes.
+__device__ int quickScoreW(const U &u, int value, int ksc, int offs, int centerIndex, int centerVal, int numApproxHits, int numHits) {
+    const int ksC = rl(ksc, centerIndex);
+    if (numApproxHits == 1) return ksC;
+    const int maxIndel = u.ix->p.maxIndel;
+    const bool act = u.lane < numHits;
+    const u64 eqM = __ballot(act && value == centerVal);
+    const u64 inM = __ballot(act && absdif(value, centerVal) <= maxIndel);
+    int x;
+    if (eqM == inM) {
+        x = wsum((act && value == centerVal) ? ksc : 0);
+    } else {
+        x = ksC;
+        for (int dir = -1; dir <= 1; dir += 2) {
+            int loc = centerVal;
+            for (int i = centerIndex + dir; i >= 0 && i < numHits; i += dir) {
+                const int li = rl(value, i);
+                const int offset = absdif(li, loc);
+                if (offset <= maxIndel) {
+                    x += rl(ksc, i);
+                    if (offset != 0) x -= min(u.indelPenalty + u.indelPenaltyMult * offset, u.maxPenalty);
+                    loc = li;
+                }
+            }
+        }
+    }
+    x -= centerIndex;
+    const int rightIndex = hibit(eqM);
+    return x + Y_MULT * (rl(offs, rightIndex) - rl(offs, centerIndex));
+}
+
+// Pops every list whose head equals `site`, in (site, column) order (QuadHeap.poll/add of the reference's inner
+// loop, BBIndex.java:1637-1666 and :2420-2444).  Returns true when the caller's loop must end (a list ran out and
+// fewer than `cutoff` lists remain, or perfectOnly).
+__device__ bool popSite(const U &u, WL &L, int site, int cutoff, bool perfectOnly, int baseChrom, unsigned &counter) {
+    for (;;) {
+        const bool hit = L.live && L.value == site;
+        const u64 Pm = __ballot(hit);
+        if (!Pm) break;
+        const int row = L.row + 1;
+        const bool dies = hit && row >= L.stop;
+        const u64 D = __ballot(dies);
+        if (D) {
+            const int nd = popc(D);
+            const int jexit = perfectOnly ? 1 : max(1, L.nlive - cutoff + 1);
+            if (jexit <= nd) {
+                u64 m = D;
+                for (int j = 1; j < jexit; j++) m &= m - 1;
+                const int d = __builtin_ctzll(m);
+                counter += (unsigned)popc(Pm & (lt_mask(d) | (1ull << d)));
+                return true;
+            }
+            L.nlive -= nd;
+        }
+        counter += (unsigned)popc(Pm);
+        if (hit) {
+            if (dies) L.live = false;
+            else { L.row = row; L.value = adjustSite(u, L.sites[row], L.offs, baseChrom); }
+        }
+        if (L.nlive == 0) break;
+    }
+    return false;
+}
+
+// BBIndex.findMaxQscore2 :2294-2450
+__device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, bool perfectOnly, int &outQ, int &outHits) {
+    const bbidx_params &p = u.ix->p;
+    const int numHits = L.n;
+    const int mqs = maxQuickScoreW(u, L.offs, L.ksc, numHits);
+    int topQscore = -999999999, maxHits = 0, approxHitsCutoff, indelCutoff;
+    if (perfectOnly) { approxHitsCutoff = numHits; indelCutoff = 0; }
+    else { approxHitsCutoff = max(prevMaxHits, min(p.minApproxHitsToKeep, numHits - 1)); indelCutoff = p.maxIndel2; }
+    while (L.nlive > 0) {
+        const int site = wmin(L.live ? L.value : INT_MAX);
+        const int centerIndex = __builtin_ctzll(__ballot(L.live && L.value == site));
+        const int minsite = site - min(p.maxIndel, indelCutoff), maxsite = site + p.maxIndel2;
+        const int approxHits = popc(__ballot(u.lane < numHits && L.value >= minsite && L.value <= maxsite));
+        if (approxHits >= approxHitsCutoff) {
+            const int qscore = quickScoreW(u, L.value, L.ksc, L.offs, centerIndex, site, approxHits, numHits)
+                             + scoreZ2W(u, L.value, L.offs, site, approxHits, numHits);
+            if (qscore > topQscore) {
+                maxHits = max(approxHits, maxHits);
+                approxHitsCutoff = max(approxHitsCutoff, approxHits - 1);
+                topQscore = qscore;
+                if (qscore >= mqs) break;
+            }
+        }
+        if (popSite(u, L, site, approxHitsCutoff, perfectOnly, baseChrom, u.cPrescan)) break;
+    }
+    outQ = topQscore; outHits = maxHits;
+}
+
+// MultiStateAligner11tsJNI.calcAffineScore(locArray, baseScores, bases, minContig) :871-1027 over the LDS location
+// array, 64 bases per step.  Sequential state of the reference and how it is recovered:
+//   lastValue  = the previous element                       -> loc[p-1]
+//   lastLoc    = the last positive element before p         -> highest set bit of the "positive" ballot below p
+//   timeInMode = length of the run of -1 ending at p        -> distance to the highest "not -1" bit below p
+//   contig     = equal-to-previous streak                   -> popcount of "equal" events since the last reset event
+__device__ int calcAffineScoreW(const U &u, const WaveLds &S, int strand, int minContig) {
+    const int blen = u.blen, lane = u.lane;
+    int score = 0, carryLastLoc = -3, carryRun = 0, carryContig = 0, maxContig = 0;
+    for (int base = 0; base < blen; base += 64) {
+        const int p = base + lane;
+        const bool valid = p < blen;
+        const int loc = valid ? S.loc[p] : 0;
+        const int prev = (valid && p > 0) ? S.loc[p - 1] : -1;
+        const bool pos = valid && loc > 0, neg1 = valid && loc == -1;
+        const u64 posM = __ballot(pos), n1M = __ballot(neg1);
+        const u64 lt = lt_mask(lane);
+        const u64 mlo = posM & lt;
+        const int lastLoc = mlo ? S.loc[base + hibit(mlo)] : carryLastLoc;
+        int c = 0, ev = 0;                                   // ev: 1 equal, 2 restart, 3 indel
+        if (pos) {
+            const int bs = S.bsc[strand ? blen - 1 - p : p];
+            if (loc == prev) { c = 100 + bs; ev = 1; }
+            else if (loc == lastLoc || lastLoc < 0) { c = 70 + bs; ev = 2; }
+            else if (loc < lastLoc) { c = 70 + bs + calcDelScoreApprox(lastLoc - loc + 1); ev = 3; }
+            else { c = 70 + bs + insCum(min(loc - lastLoc, 5)); ev = 3; }
+        } else if (neg1) {
+            const u64 nb = ~n1M & lt;
+            const int t = nb ? lane - hibit(nb) : lane + 1 + carryRun;
+            c = subArr(t);
+        }
+        score += wsum(c);
+        if (minContig > 1) {
+            const u64 EM = __ballot(ev == 1), SM = __ballot(ev == 2), IM = __ballot(ev == 3), RM = SM | IM;
+            int cval = 0;
+            if (ev == 1) {
+                const u64 rlo = RM & lt;
+                if (rlo) { const int r = hibit(rlo); cval = popc(EM & lt & gt_mask(r)) + 1 + (int)((SM >> r) & 1); }
+                else cval = popc(EM & lt) + 1 + carryContig;
+            } else if (ev == 2) cval = 1;
+            maxContig = max(maxContig, wmax(cval));
+            const u64 all = EM | RM;
+            if (all) carryContig = rl(cval, hibit(all));
+        }
+        if (posM) carryLastLoc = rl(loc, hibit(posM));
+        const int last = min(63, blen - 1 - base);
+        if ((n1M >> last) & 1) {
+            const u64 nbAll = ~n1M & (lt_mask(last) | (1ull << last));
+            carryRun = nbAll ? last - hibit(nbAll) : last + 1 + carryRun;
+        } else carryRun = 0;
+    }
+    if (minContig > 1 && maxContig < minContig) score = min(score, -50 * blen);
+    return score;
+}
+
+// BBIndex.extendScore :2558-2833
+__device__ int extendScoreW(U &u, WaveLds &S, int strand, int value, int offs, int numHits, int chrom, int centerIndex) {
+    const bbidx_params &p = u.ix->p;
+    const int blen = u.blen, lane = u.lane, k = u.k;
+    const int centerVal = rl(value, centerIndex), centerLoc = u.c.siteOf(centerVal);
+    const int minVal = centerVal - p.maxIndel, maxVal = centerVal + p.maxIndel2;
+    const uint8_t *ref = u.ix->chromArr[chrom];
+    const int reflen = u.ix->chromArrLen[chrom];
+    const uint8_t *rb = S.base[strand];
+    u.cExtend++;
+    for (int i = lane; i < blen; i += 64) S.loc[i] = -1;
+    wsync();
+    const u64 R = __ballot(lane < numHits && value >= minVal && value <= maxVal);
+    // backward from each key's last base; the first key in range runs through mismatches, the others stop at the first
+    int keynum = 0;
+    for (u64 m = R; m; m &= m - 1) {
+        const int i = __builtin_ctzll(m);
+        const int refbase = u.c.siteOf(rl(value, i)), c0 = rl(offs, i) + k - 1;
+        keynum++;
+        if (c0 < 0 || refbase + c0 >= reflen) continue;
+        if (keynum == 1) {
+            for (int base = 0; base <= c0; base += 64) {
+                const int q = base + lane;
+                if (q <= c0 && rb[q] == ref[refbase + q]) S.loc[q] = refbase;
+            }
+            u.cRefBytes += (unsigned)(c0 + 1);
+        } else {
+            for (int top = c0; top >= 0; top -= 64) {
+                const int q = top - lane;
+                const bool valid = q >= 0;
+                const int old = valid ? S.loc[q] : 0;
+                const u64 Em = __ballot(valid && old == refbase);
+                if (Em & 1) break;                                              // already holds this site: nothing compared
+                const bool mm = valid && rb[q] != ref[refbase + q];
+                const u64 stopM = Em | __ballot(mm);
+                const int s = stopM ? __builtin_ctzll(stopM) : 64;
+                if (valid && lane < s && (old < 0 || refbase == centerLoc)) S.loc[q] = refbase;
+                u.cRefBytes += (unsigned)(min(s, min(64, top + 1)) + ((s < 64 && !((Em >> s) & 1)) ? 1 : 0));
+                if (s < 64) break;
+            }
+        }
+        wsync();
+    }
+    // forward from the base after each key: runs through mismatches over unassigned bases, stops on an assigned base
+    // once a mismatch has been seen
+    for (u64 m = R; m; m &= m - 1) {
+        const int i = __builtin_ctzll(m);
+        const int refbase = u.c.siteOf(rl(value, i));
+        bool mmprev = false;
+        for (int c = rl(offs, i) + k; c < blen; c += 64) {
+            const int q = c + lane;
+            const bool valid = q < blen && refbase + q < reflen;
+            const int old = valid ? S.loc[q] : -1;
+            const bool A = valid && old >= 0;
+            const u64 Em = __ballot(valid && old == refbase);
+            if (Em & 1) break;
+            const bool mm = valid && rb[q] != ref[refbase + q];
+            const u64 mmM = __ballot(mm), validM = __ballot(valid), Am = __ballot(A);
+            const bool mmBefore = mmprev || (mmM & lt_mask(lane)) != 0;
+            const bool stop = valid && (old == refbase || (A && (mmBefore || mm)));
+            const u64 stopM = __ballot(stop) | ~validM;
+            const int s = stopM ? __builtin_ctzll(stopM) : 64;
+            if (valid && lane < s && !mm && (old < 0 || refbase == centerLoc)) S.loc[q] = refbase;
+            unsigned cnt = (unsigned)s;
+            if (s < 64 && ((validM >> s) & 1)) {
+                const bool Es = (Em >> s) & 1, As = (Am >> s) & 1;
+                const bool mmBeforeS = mmprev || (mmM & lt_mask(s)) != 0;
+                if (!Es && !(mmBeforeS && As)) cnt++;
+            }
+            u.cRefBytes += cnt;
+            if (s < 64) break;
+            mmprev = mmprev || mmM != 0;
+        }
+        wsync();
+    }
+    for (int i = lane; i < blen; i += 64) if (rb[i] == 'N') S.loc[i] = -2;
+    wsync();
+    return calcAffineScoreW(u, S, strand, p.kfilter);
+}
+
+// BBIndex.makeGapArray :2837-2878 -- rare (a site spanning more than MINGAP + read length); one lane walks LDS
+__device__ int makeGapArrayW(const U &u, WaveLds &S, int minLoc, int minGap) {
+    if (u.lane == 0) {
+        int *locArray = S.loc;
+        const int n = u.blen;
+        int gaps = 0; bool doSort = false;
+        if (locArray[0] < 0) locArray[0] = minLoc;
+        for (int i = 1; i < n; i++) {
+            if (locArray[i] < 0) locArray[i] = locArray[i - 1] + 1; else locArray[i] += i;
+            if (locArray[i] < locArray[i - 1]) doSort = true;
+        }
+        if (doSort) {
+            for (int i = 1; i < n; i++) { const int v = locArray[i]; int j = i - 1; while (j >= 0 && locArray[j] > v) { locArray[j + 1] = locArray[j]; j--; } locArray[j + 1] = v; }
+        }
+        for (int i = 1; i < n; i++) if (locArray[i] - locArray[i - 1] > minGap) gaps++;
+        int len = 0;
+        if (gaps >= 1) {
+            len = 2 + gaps * 2;
+            if (len > BBIDX_MAX_GAPS) len = -1;
+            else {
+                S.gaps[0] = locArray[0]; S.gaps[len - 1] = locArray[n - 1];
+                for (int i = 1, j = 1; i < n; i++) if (locArray[i] - locArray[i - 1] > minGap) { S.gaps[j] = locArray[i - 1]; S.gaps[j + 1] = locArray[i]; j += 2; }
+            }
+        }
+        S.ngaps = len;
+    }
+    wsync();
+    return __builtin_amdgcn_readfirstlane(S.ngaps);
+}
+
+// SiteScore.setPerfect (current/stream/SiteScore.java:239-292): order-independent form
+__device__ void setPerfectW(const U &u, const WaveLds &S, int chrom, int strand, int start, int stop, int &perfectOut, int &semiOut) {
+    const int blen = u.blen;
+    perfectOut = 0; semiOut = 0;
+    if (blen != stop - start + 1) return;
+    const uint8_t *ref = u.ix->chromArr[chrom];
+    const int reflen = u.ix->chromArrLen[chrom];
+    const uint8_t *rb = S.base[strand];
+    bool perfect = true;
+    int refloc = start, readloc = 0, N = 0;
+    const int mx = min(stop, reflen - 1), nlimit = blen / 2;
+    if (start < 0) { N -= start; readloc -= start; refloc -= start; perfect = false; }
+    if (stop >= reflen) { N += (stop - reflen + 1); perfect = false; }
+    if (N > nlimit) return;
+    bool anyHard = false, anyCN = false, anyBad = false;
+    for (int j0 = 0; refloc + j0 <= mx; j0 += 64) {
+        const int j = j0 + u.lane;
+        bool bad = false, hard = false, cn = false;
+        if (refloc + j <= mx) {
+            const int c = rb[readloc + j], r = ref[refloc + j];
+            bad = (c != r || c == 'N'); hard = bad && r != 'N'; cn = bad && c == 'N';
+        }
+        const u64 badM = __ballot(bad);
+        if (badM) {
+            anyBad = true;
+            if (__ballot(hard)) { anyHard = true; break; }
+            if (__ballot(cn)) anyCN = true;
+            N += popc(badM);
+            if (N > nlimit) break;
+        }
+    }
+    if (anyHard || N > nlimit) return;
+    const bool semi = !anyCN;
+    semiOut = semi ? 1 : 0;
+    perfectOut = (perfect && !anyBad && semi && N == 0) ? 1 : 0;
+}
+__device__ inline bool overlap(int a1, int b1, int a2, int b2) { return a2 <= b1 && b2 >= a1; }
+
+struct SiteOut { bbidx_site *v; int n, cap; bool overflow; };
+struct PrevSite { int idx, chrom, strand, start, stop, score, perfect, semiperfect, ngaps; };
+
+// BBIndex.slowWalk3 :1219-1706
+__device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int offsK, int kscK, int baseChrom_,
+                           SiteOut &ssl, int *bestScores, bool allBasesCovered, int maxScore, bool fullyDefined) {
+    const bbidx_params &p = u.ix->p;
+    const int blen = u.blen, lane = u.lane;
+    const int mqs = maxQuickScoreW(u, offsK, kscK, numKeys);
+    const int baseChrom = u.c.baseChrom(baseChrom_);
+    const int numHits = L.n;
+    const bool filter_by_qscore = numKeys >= 5;
+    const int minScore = (int)(MIN_SCORE_MULT * maxScore);
+    const int minQuickScore = (int)(MIN_QSCORE_MULT * mqs);
+    int currentTopScore = bestScores[0];
+    int cutoff = max(minScore, (int)(currentTopScore * DYN_SCORE));
+    int qcutoff = max(bestScores[2], minQuickScore);
+    int bestqscore = bestScores[3], maxHits = bestScores[1], perfectsFound = bestScores[5];
+    int approxHitsCutoff = calcApproxHitsCutoff(p, numKeys, maxHits, p.minApproxHitsToKeep, currentTopScore >= maxScore);
+    if (approxHitsCutoff > numHits) return;
+    const bool shortCircuit = allBasesCovered && numKeys == numHits && filter_by_qscore;
+    if (currentTopScore >= maxScore) qcutoff = max(qcutoff, (int)(mqs * DYN_QSCORE_PERFECT));
+
+    PrevSite pv; pv.idx = -1; pv.chrom = pv.strand = pv.start = pv.stop = pv.score = pv.perfect = pv.semiperfect = pv.ngaps = 0;
+    bool finished = false;
+    while (L.nlive > 0 && !finished) {
+        const int site = wmin(L.live ? L.value : INT_MAX);
+        const int centerIndex = __builtin_ctzll(__ballot(L.live && L.value == site));
+        const int minsite = site - p.maxIndel, maxsite = site + p.maxIndel2;
+        const bool inr = lane < numHits && L.value >= minsite && L.value <= maxsite;
+        const int approxHits = popc(__ballot(inr));
+        if (approxHits >= approxHitsCutoff) {
+            const int maxNearbySite = wmax(inr ? L.value : site);
+            int score;
+            int qscore = filter_by_qscore ? quickScoreW(u, L.value, L.ksc, L.offs, centerIndex, site, approxHits, numHits) : qcutoff;
+            qscore += scoreZ2W(u, L.value, L.offs, site, approxHits, numHits);
+            int mapStart = site, mapStop = maxNearbySite;
+            bool locArrayValid = false;
+            if (qscore < qcutoff) score = -1;
+            else {
+                const int chrom = u.c.chromOf(site, baseChrom);
+                if (shortCircuit && qscore == mqs) score = maxScore;
+                else {
+                    score = extendScoreW(u, S, strand, L.value, L.offs, numHits, chrom, centerIndex);
+                    locArrayValid = true;
+                    int mn = INT_MAX, mx = INT_MIN;
+                    for (int i = lane; i < blen; i += 64) { const int x = S.loc[i]; if (x > -1) { mn = min(mn, x); mx = max(mx, x); } }
+                    mn = wmin(mn); mx = wmax(mx);
+                    if (mn < 0 || mx < 0) score = -99999;
+                    mapStart = u.c.toNumber(mn, chrom);
+                    mapStop = u.c.toNumber(mx, chrom);
+                }
+                if (score == maxScore) {
+                    qcutoff = max(qcutoff, (int)(mqs * DYN_QSCORE_PERFECT));
+                    approxHitsCutoff = calcApproxHitsCutoff(p, numKeys, maxHits, p.minApproxHitsToKeep, true);
+                }
+                if (score >= cutoff) { qcutoff = max(qcutoff, (int)(qscore * DYN_QSCORE)); bestqscore = max(qscore, bestqscore); }
+            }
+            if (score >= cutoff) {
+                if (score > currentTopScore) {
+                    maxHits = max(approxHits, maxHits);
+                    approxHitsCutoff = calcApproxHitsCutoff(p, numKeys, maxHits, approxHitsCutoff, currentTopScore >= maxScore);
+                    cutoff = max(cutoff, (int)(score * DYN_SCORE));
+                    if (score >= maxScore) cutoff = max(cutoff, (int)(score * 0.95f));
+                    currentTopScore = score;
+                }
+                const int chrom = u.c.chromOf(mapStart, baseChrom);
+                const int site2 = u.c.siteOf(mapStart);
+                const int site3 = u.c.siteOf(mapStop) + blen - 1;
+                int ngaps = 0;
+                if (site3 - site2 >= MINGAP + blen && locArrayValid) {
+                    ngaps = makeGapArrayW(u, S, site2, MINGAP);
+                    if (ngaps < 0) ngaps = 0;
+                    if (ngaps > 0) {
+                        if (lane == 0) { S.gaps[0] = min(S.gaps[0], site2); S.gaps[ngaps - 1] = max(S.gaps[ngaps - 1], site3); }
+                        wsync();
+                    }
+                }
+                const bool perfect1 = (score == maxScore && fullyDefined);
+                const bool inbounds = (site2 >= 0 && site3 < u.ix->chromLengths[chrom]);
+                const bool havePrev = pv.idx >= 0;
+                bool makeNew = false, withGaps = false;
+                if (inbounds && ngaps == 0 && havePrev && pv.chrom == chrom && pv.strand == strand && overlap(pv.start, pv.stop, site2, site3)) {
+                    const int betterScore = max(score, pv.score);
+                    const int minStart = min(pv.start, site2), maxStop = max(pv.stop, site3);
+                    const bool perfect2 = (pv.score == maxScore && fullyDefined);
+                    const bool shortEnough = (maxStop - minStart < 2 * blen);
+                    bbidx_site *pd = &ssl.v[pv.idx];
+                    if (pv.start == site2 && pv.stop == site3) {
+                        pv.score = betterScore;
+                        pv.perfect = (pv.perfect || perfect1 || perfect2) ? 1 : 0;
+                        if (pv.perfect) pv.semiperfect = 1;
+                        if (lane == 0) { pd->score = pv.score; pd->perfect = pv.perfect; pd->semiperfect = pv.semiperfect; }
+                    } else if (shortEnough && pv.start == site2 && !pv.semiperfect) {
+                        if (perfect2) { }
+                        else if (perfect1) {
+                            pv.stop = site3;
+                            if (!pv.perfect) perfectsFound++;
+                            pv.perfect = pv.semiperfect = 1;
+                        } else {
+                            pv.stop = maxStop;
+                            setPerfectW(u, S, pv.chrom, pv.strand, pv.start, pv.stop, pv.perfect, pv.semiperfect);
+                        }
+                        pv.score = betterScore;
+                        if (lane == 0) {
+                            pd->stop = pv.stop; if (pv.ngaps) pd->gaps[pv.ngaps - 1] = pv.stop;
+                            pd->perfect = pv.perfect; pd->semiperfect = pv.semiperfect; pd->score = pv.score;
+                        }
+                    } else if (shortEnough && pv.stop == site3 && !pv.semiperfect) {
+                        if (perfect2) { }
+                        else if (perfect1) {
+                            pv.start = site2;
+                            if (!pv.perfect) perfectsFound++;
+                            pv.perfect = pv.semiperfect = 1;
+                        } else {
+                            pv.start = minStart;
+                            setPerfectW(u, S, pv.chrom, pv.strand, pv.start, pv.stop, pv.perfect, pv.semiperfect);
+                        }
+                        pv.score = betterScore;
+                        if (lane == 0) {
+                            pd->start = pv.start; if (pv.ngaps) pd->gaps[0] = pv.start;
+                            pd->perfect = pv.perfect; pd->semiperfect = pv.semiperfect; pd->score = pv.score;
+                        }
+                    } else makeNew = true;
+                } else if (inbounds) { makeNew = true; withGaps = true; }
+                if (makeNew) {
+                    int sp = perfect1 ? 1 : 0, ssemi = sp;
+                    if (!perfect1) setPerfectW(u, S, chrom, strand, site2, site3, sp, ssemi);
+                    const int sg = withGaps ? ngaps : 0;
+                    if (ssl.n >= ssl.cap) { ssl.overflow = true; finished = true; }
+                    else {
+                        int wv = 0;
+                        switch (lane) {
+                            case 0: wv = chrom; break; case 1: wv = strand; break; case 2: wv = site2; break; case 3: wv = site3; break;
+                            case 4: wv = approxHits; break; case 5: wv = score; break; case 6: wv = sp; break; case 7: wv = ssemi; break;
+                            case 8: wv = sg; break;
+                            default: wv = (lane < 9 + sg) ? S.gaps[lane - 9] : 0; break;
+                        }
+                        if (lane < 25) ((int *)&ssl.v[ssl.n])[lane] = wv;
+                        const int idx = ssl.n++;
+                        bool stopNow = false;
+                        if (sp) {
+                            if (!havePrev || !pv.perfect || !(pv.chrom == chrom && pv.strand == strand && overlap(site2, site3, pv.start, pv.stop))) {
+                                perfectsFound++;
+                                if (p.quitAfterTwoPerfects && perfectsFound >= 2) stopNow = true;
+                            }
+                        }
+                        pv.idx = idx; pv.chrom = chrom; pv.strand = strand; pv.start = site2; pv.stop = site3; pv.score = score;
+                        pv.perfect = sp; pv.semiperfect = ssemi; pv.ngaps = sg;
+                        if (stopNow) break;
+                    }
+                }
+            }
+        }
+        if (finished) break;
+        if (popSite(u, L, site, approxHitsCutoff, false, baseChrom, u.cWalk)) break;
+    }
+    bestScores[0] = max(bestScores[0], currentTopScore);
+    bestScores[1] = max(bestScores[1], maxHits);
+    bestScores[2] = max(bestScores[2], qcutoff);
+    bestScores[3] = max(bestScores[3], bestqscore);
+    bestScores[4] = mqs;
+    bestScores[5] = perfectsFound;
+}
+
+// Solver.valueOfElement (current/align2/Solver.java:97-151)
+__device__ long long valueOfElement(const int *offsets, int noffsets, const int *lengths, float keyWeight, int chunk,
+                                    const int *lists, int numlists, int index, long long pointsPerSite) {
+    const long long PPL = 30000, PPB1 = 6000, BONUS_END = 40000, WIDTH = 5500, SPACING = -30;
+    if (numlists < 1) return 0;
+    const int prospect = lists[index];
+    if (lengths[prospect] == 0) return -999999;
+    long long valuep = PPL + (PPL * 2 / numlists) + ((PPL * 10) / lengths[prospect]);
+    const long long valuem = pointsPerSite * lengths[prospect];
+    if (prospect == 0 || prospect == noffsets - 1) valuep += BONUS_END;
+    if (numlists == 1) { valuep += (WIDTH + PPB1) * chunk; return ((long long)__fmul_rn((float)valuep, keyWeight)) + valuem; }
+    const int first = lists[0], last = lists[numlists - 1];
+    const int offL = (prospect == first ? -1 : offsets[lists[index - 1]]);
+    const int offP = offsets[prospect];
+    const int offR = (prospect == last ? offsets[noffsets - 1] + 1 : offsets[lists[index + 1]]);
+    const int oldL = offP - offL, oldR = offR - offP, newS = offR - offL;
+    valuep += (long long)((oldL * oldL + oldR * oldR) - (newS * newS)) * SPACING;
+    int uniquelyCovered;
+    if (prospect == first) uniquelyCovered = offR - offP;
+    else if (prospect == last) uniquelyCovered = offP - offL;
+    else { const int b = offR - (offL + chunk); uniquelyCovered = b > 0 ? b : 0; }
+    if (prospect == first || prospect == last) valuep += (PPB1 + WIDTH) * uniquelyCovered;
+    else valuep += PPB1 * uniquelyCovered;
+    return ((long long)__fmul_rn((float)valuep, keyWeight)) + valuem;
+}
+
+// BBIndex.trimExcessHitListsByGreedy :266-350 (+ Solver.findWorstGreedy :46-95): lane j evaluates list position j,
+// the "first strict prefix minimum below the early-termination score" rule comes from an exclusive prefix-min scan.
+// x = lengths[lane] (COUNTS of the lane's key), key = keys[lane]; both are updated in place.
+__device__ int trimByGreedyW(const U &u, WaveLds &S, int off, int ksc, int n, int maxHitLists, int &key, int &x) {
+    const DevIndex &ix = *u.ix;
+    const bbidx_params &p = ix.p;
+    const int lane = u.lane;
+    const float inv = __fdiv_rn(1.0f, (float)u.baseKeyHitScore);
+    const int limit = max(SMALL_LIST, ix.lengthHistogram[p.maxAverageListToSearch]) * n;
+    const int limit2 = max(SMALL_LIST, ix.lengthHistogram[p.maxAverageListToSearch2]);
+    const int limit3 = max(SMALL_LIST, ix.lengthHistogram[p.maxShortestListToSearch]);
+    const bool act = lane < n;
+    if (!act) x = 0;
+    int sum = wsum(x);
+    const int initialHitCount = popc(__ballot(act && x != 0));
+    const int shortest = wmin((act && x > 0) ? x : INT_MAX - 1);
+    if (initialHitCount < p.minApproxHitsToKeep) return initialHitCount;
+    if (shortest > limit3 && !p.slow) { key = -1; return 0; }
+    int *listsL = S.xch[0], *offL = S.xch[1], *lenL = S.xch[2];
+    if (act) offL[lane] = off;
+    int hitsCount = initialHitCount;
+    const long long EARLY = -50LL * 2000;
+    while (hitsCount >= p.minApproxHitsToKeep && (sum > limit || sum / initialHitCount > limit2 || hitsCount > maxHitLists)) {
+        const u64 M = __ballot(act && x > 0);
+        if (act) { lenL[lane] = x; if (x > 0) listsL[popc(M & lt_mask(lane))] = lane; }
+        wsync();
+        long long v = LLONG_MAX;
+        if (lane < hitsCount) v = valueOfElement(offL, n, lenL, __fmul_rn((float)ksc, inv), p.k, listsL, hitsCount, lane, p.pointsPerSite);
+        long long pm = v;                                   // inclusive prefix minimum
+        for (int d = 1; d < 64; d <<= 1) { const long long t = __shfl_up(pm, d); if (lane >= d) pm = min(pm, t); }
+        long long ex = __shfl_up(pm, 1);
+        if (lane == 0) ex = LLONG_MAX;
+        const bool upd = lane < hitsCount && v < ex;
+        const u64 earlyM = __ballot(upd && lane != 0 && ex < EARLY);
+        const int worstIndex = earlyM ? __builtin_ctzll(earlyM) : hibit(__ballot(upd));
+        const long long worstValue64 = __shfl(v, worstIndex);
+        const int worstValue = worstValue64 < INT_MIN ? INT_MIN : (worstValue64 > INT_MAX ? INT_MAX : (int)worstValue64);
+        const int worst = listsL[worstIndex];
+        const int lenWorst = rl(x, worst);
+        sum -= lenWorst;
+        wsync();
+        if (worstValue > 0 || lenWorst < SMALL_LIST) return hitsCount;
+        hitsCount--;
+        if (lane == worst) { x = 0; key = -1; }
+    }
+    return hitsCount;
+}
+
+// compaction of up to five per-lane values through LDS: lanes with keep==true move to lanes 0..count-1
+template <int NV> __device__ inline int compactW(WaveLds &S, int lane, bool keep, int (&v)[NV]) {
+    const u64 M = __ballot(keep);
+    const int pos = popc(M & lt_mask(lane));
+    wsync();
+    if (keep) for (int j = 0; j < NV; j++) S.xch[j][pos] = v[j];
+    wsync();
+    for (int j = 0; j < NV; j++) v[j] = S.xch[j][lane];
+    wsync();
+    return popc(M);
+}
+
+// BBIndex.getHits (:354-391) + the heap fill at the top of slowWalk3/findMaxQscore2: builds the compacted lists
+__device__ int makeListsW(const U &u, WaveLds &S, WL &L, int block, int baseChrom, int key, int off, int ksc, int n, int minHits) {
+    const DevIndex &ix = *u.ix;
+    const int *bs = ix.starts[block], *st = ix.sites[block];
+    int start = -1, stop = -1, first = 0;
+    if (u.lane < n && key >= 0 && ix.counts[key] > 0) {
+        const int s0 = bs[key], x = bs[key + 1] - s0;
+        if (x > 0) { first = st[s0]; if (first != -1) { start = s0; stop = s0 + x; } }
+    }
+    const int nh = popc(__ballot(start >= 0));
+    if (nh < minHits) return nh;
+    int v[5] = {start, stop, off, ksc, first};
+    compactW<5>(S, u.lane, start >= 0, v);
+    L.n = L.nlive = nh; L.sites = st;
+    L.live = u.lane < nh;
+    L.row = v[0]; L.stop = v[1]; L.offs = v[2]; L.ksc = v[3];
+    L.value = L.live ? adjustSite(u, v[4], v[2], baseChrom) : 0;
+    return nh;
+}
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void probe_wave_kernel(const Params P) {
+    __shared__ WaveLds lds[WAVES_PER_BLOCK];
+    __shared__ unsigned blockStats[5];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (threadIdx.x < 5) blockStats[threadIdx.x] = 0;
+    __syncthreads();
+    WaveLds &S = lds[wave];
+    const DevIndex &ix = P.ix;
+    const bbidx_params &p = ix.p;
+    const long long r = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
+    U u;
+    u.ix = &ix;
+    u.c.shift = 31 - p.chromBits; u.c.siteMask = (int)(0xFFFFFFFFu >> (p.chromBits + 1));
+    u.c.cpb = 1 << p.chromBits; u.c.lowMask = u.c.cpb - 1; u.c.highMask = ~u.c.lowMask;
+    u.k = p.k; u.baseKeyHitScore = BASE_HIT_SCORE * p.k;
+    u.indelPenalty = (u.baseKeyHitScore / 2) - 1; u.indelPenaltyMult = 20;
+    u.maxPenalty = u.baseKeyHitScore - (1 + u.baseKeyHitScore / 8);
+    u.scoreZ1Key = Z_MULT * p.k;
+    u.lane = lane; u.blen = 0;
+    u.cPrescan = u.cWalk = u.cExtend = u.cRefBytes = 0;
+    unsigned cSites = 0;
+
+    int result = 0;                      // what goes to nsites[r]
+    bool done = (r >= P.nreads);
+    bbidx_read rr; rr.len = 0; rr.nkeys = 0; rr.bases_off = 0; rr.keys_off = 0;
+    if (!done) rr = P.reads[r];
+    const int blen = rr.len;
+    int n = rr.nkeys;
+    u.blen = blen;
+    if (!done) {
+        if (n < 1 || blen < p.k) { result = 0; done = true; }
+        else if (n > KB || blen > MAXLEN) { result = -2; done = true; }
+        else if (n > 64) { result = NSITES_PENDING; done = true; }
+    }
+    // one uniform do { } while (0) body per read: `break` = finished with `result`
+    if (!done) do {
+        const uint8_t *bP = P.bases + rr.bases_off;
+        const int8_t *qP = P.baseScores + rr.bases_off;
+        const int *koff = P.keyinfo + rr.keys_off, *kscore = koff + n;
+        int sumBS = 0; bool undefinedBase = false;
+        for (int i = lane; i < blen; i += 64) {
+            const int b = bP[i], q = qP[i];
+            S.base[0][i] = (uint8_t)b; S.base[1][blen - 1 - i] = (uint8_t)complement_extended(b); S.bsc[i] = (int8_t)q;
+            sumBS += q;
+            if (b >= 128 || base_num(b) < 0) undefinedBase = true;
+        }
+        sumBS = wsum(sumBS);
+        const bool fullyDefined = __ballot(undefinedBase) == 0;
+        wsync();
+
+        // KeyRing.makeKeys; lane i owns key i
+        int off = 0, ksc = 0, keyOrig = -1;
+        if (lane < n) {
+            off = koff[lane]; ksc = kscore[lane];
+            int key = 0;
+            for (int q = off; q < off + p.k; q++) { const int x = base_num(S.base[0][q]); if (x < 0) { key = -1; break; } key = (key << 2) | x; }
+            keyOrig = key;
+        }
+        {   // the wave kernel's coverage arithmetic needs non-decreasing offsets (KeyRing.makeOffsets gives them)
+            const int prevOff = __shfl_up(off, 1);
+            if (__ballot(lane > 0 && lane < n && off < prevOff)) { result = NSITES_PENDING; break; }
+        }
+        const int cntOrig = keyOrig >= 0 ? ix.counts[keyOrig] : 0;
+        int key = keyOrig;
+        auto countHits = [&](int maxLen) -> int {
+            const bool v = key >= 0 && cntOrig > 0 && cntOrig < maxLen;
+            if (!v) key = -1;
+            return popc(__ballot(v));
+        };
+        const int maxLen = p.maxUsableLength;
+        int numHits = countHits(maxLen);
+        if (numHits > 0) {
+            const int trigger = (3 * n) / 4;
+            if (numHits < 4 && numHits < trigger) { key = keyOrig; numHits = countHits((maxLen * 3) / 2); }
+            if (numHits < 3 && numHits < trigger) { key = keyOrig; numHits = countHits(maxLen * 2); }
+            if (numHits < 3 && numHits < trigger) { key = keyOrig; numHits = countHits(maxLen * 3); }
+            if (numHits < 2 && numHits < trigger) { key = keyOrig; numHits = countHits(maxLen * 5); }
+        }
+        const int nOriginal = n;
+        int cnt = cntOrig;
+        if (numHits < n) { int v[4] = {off, key, ksc, cnt}; n = compactW<4>(S, lane, key >= 0, v); off = v[0]; key = v[1]; ksc = v[2]; cnt = v[3]; if (lane >= n) key = -1; }
+        if (p.trimByGreedy) {
+            const int maxLists = max((int)(HIT_FRACTION_TO_RETAIN * n), MIN_LISTS_RETAIN);
+            numHits = trimByGreedyW(u, S, off, ksc, n, maxLists, key, cnt);
+        }
+        if (numHits < p.minApproxHitsToKeep) { result = 0; break; }
+        if (numHits < n) { int v[3] = {off, key, ksc}; n = compactW<3>(S, lane, lane < n && key >= 0, v); off = v[0]; key = v[1]; ksc = v[2]; if (lane >= n) key = -1; }
+        // minus strand: KeyRing.reverseComplementKeys / reverseOffsets
+        int offM = 0, keyM = -1, kscM = 0;
+        {
+            const int src = (lane < n) ? n - 1 - lane : lane;
+            const int so = __shfl(off, src), sk = __shfl(key, src), ss = __shfl(ksc, src);
+            if (lane < n) { offM = blen - (so + p.k); keyM = rc_key(sk, p.k); kscM = ss; }
+        }
+        const int mqs = maxQuickScoreW(u, off, ksc, n);
+        int bestScores[6] = {0, 0, 0, 0, 0, 0};
+        const bool prescan = p.prescanQscore && numHits >= 5;
+        int hitsCutoff = 0, qscoreCutoff = (int)(MIN_QSCORE_MULT * mqs);
+        bool allBasesCovered = true, pretend;
+        {
+            const int off0 = rl(off, 0), offLast = rl(off, n - 1);
+            const int prevOff = __shfl_up(off, 1);
+            if (off0 != 0 || offLast != blen - p.k) allBasesCovered = false;
+            else if (__ballot(lane > 0 && lane < n && off > prevOff + p.k)) allBasesCovered = false;
+            pretend = allBasesCovered || n >= nOriginal - 4 || (n >= 9 && (offLast - off0 + p.k) > max(40, (int)(blen * .75f)));
+        }
+
+        const int cpb = u.c.cpb;
+        int ncycles = 0;
+        for (int chrom = p.minChrom; chrom <= p.maxChrom; chrom = ((chrom & u.c.highMask) + cpb)) ncycles += 2;
+        if (ncycles > 64) { result = -2; break; }
+        WL L;
+        L.row = L.stop = L.value = L.offs = L.ksc = 0; L.live = false; L.n = L.nlive = 0; L.sites = nullptr;
+        int precount = n, prescore = mqs;                 // lane c holds the prescan result of cycle c
+        bool dead = false;
+        if (prescan) {
+            int bestqscore = 0, maxHits = 0, minHitsToScore = p.minApproxHitsToKeep, cycle = 0; bool earlyOut = false;
+            for (int chrom = p.minChrom; chrom <= p.maxChrom && !earlyOut; chrom = ((chrom & u.c.highMask) + cpb)) {
+                const int baseChrom = u.c.baseChrom(chrom);
+                const int block = baseChrom >> p.chromBits;
+                for (int pmi = 0; pmi < 2 && !earlyOut; pmi++, cycle++) {
+                    const int nh = makeListsW(u, S, L, block, baseChrom, pmi ? keyM : key, pmi ? offM : off, pmi ? kscM : ksc, n, minHitsToScore);
+                    if (nh < minHitsToScore) { if (lane == cycle) { prescore = -9999; precount = 0; } }
+                    else {
+                        int tq, th;
+                        findMaxQscore2W(u, L, baseChrom, minHitsToScore, bestqscore >= mqs && pretend, tq, th);
+                        if (lane == cycle) { prescore = tq; precount = th; }
+                        bestqscore = max(tq, bestqscore); maxHits = max(maxHits, th);
+                        if (bestqscore >= mqs && pretend) { minHitsToScore = max(minHitsToScore, maxHits); earlyOut = true; }
+                    }
+                }
+            }
+            bestScores[1] = max(bestScores[1], maxHits);
+            bestScores[3] = max(bestScores[3], bestqscore);
+            if (bestScores[1] < p.minApproxHitsToKeep) dead = true;
+            else if ((float)bestScores[3] < __fmul_rn((float)mqs, MIN_QSCORE_MULT2)) dead = true;
+            else if (bestScores[3] >= mqs && pretend) {
+                hitsCutoff = calcApproxHitsCutoff(p, n, bestScores[1], p.minApproxHitsToKeep, true);
+                qscoreCutoff = max(qscoreCutoff, (int)(bestScores[3] * DYN_QSCORE_PERFECT));
+            } else {
+                hitsCutoff = calcApproxHitsCutoff(p, n, bestScores[1], p.minApproxHitsToKeep, false);
+                qscoreCutoff = max(qscoreCutoff, (int)(bestScores[3] * PRESCAN_QSCORE_THRESH));
+            }
+        }
+        if (dead) { result = 0; break; }
+
+        const int maxScore = 70 + (blen - 1) * 100 + sumBS;               // msa.maxQuality(baseScores)
+        SiteOut ssl; ssl.v = P.sites + r * (long long)P.maxSites; ssl.n = 0; ssl.cap = P.maxSites; ssl.overflow = false;
+        int cycle = 0; bool quit = false;
+        for (int chrom = p.minChrom; chrom <= p.maxChrom && !quit; chrom = ((chrom & u.c.highMask) + cpb)) {
+            const int baseChrom = u.c.baseChrom(chrom);
+            const int block = baseChrom >> p.chromBits;
+            for (int strand = 0; strand < 2 && !quit; strand++, cycle++) {
+                if (!prescan || rl(precount, cycle) >= hitsCutoff || rl(prescore, cycle) >= qscoreCutoff) {
+                    const int nh = makeListsW(u, S, L, block, baseChrom, strand ? keyM : key, strand ? offM : off, strand ? kscM : ksc, n, p.minApproxHitsToKeep);
+                    if (nh >= p.minApproxHitsToKeep)
+                        slowWalk3W(u, S, L, strand, n, strand ? offM : off, strand ? kscM : ksc, chrom, ssl, bestScores,
+                                   allBasesCovered, maxScore, fullyDefined);
+                }
+                if (p.quitAfterTwoPerfects && bestScores[5] >= 2) quit = true;
+            }
+        }
+        result = ssl.overflow ? -1 : ssl.n;
+        cSites = (unsigned)ssl.n;
+    } while (0);
+
+    if (r < P.nreads && lane == 0) {
+        P.nsites[r] = result;
+        if (result == NSITES_PENDING) atomicAdd(&P.queue[1], 1u);
+    }
+    if (P.stats) {
+        if (lane == 0) {
+            atomicAdd(&blockStats[0], u.cPrescan); atomicAdd(&blockStats[1], u.cWalk); atomicAdd(&blockStats[2], u.cExtend);
+            atomicAdd(&blockStats[3], u.cRefBytes); atomicAdd(&blockStats[4], cSites);
+        }
+        __syncthreads();
+        if (threadIdx.x < 5 && blockStats[threadIdx.x])
+            atomicAdd(&P.stats[8 * (blockIdx.x % STAT_SHARDS) + threadIdx.x], (unsigned long long)blockStats[threadIdx.x]);
+    }
+}
+
+}  // namespace bbidxw
+
+int bbidx_launch_wave(const bbidx::Params &P, hipStream_t stream) {
+    const long long blocks = (P.nreads + bbidxw::WAVES_PER_BLOCK - 1) / bbidxw::WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(bbidxw::probe_wave_kernel, dim3((unsigned)blocks), dim3(64 * bbidxw::WAVES_PER_BLOCK), 0, stream, P);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        static thread_local char msg[256];
+        snprintf(msg, sizeof msg, "probe_wave_kernel launch failed: %s", hipGetErrorString(e));
+        bbmap_set_error(msg);
+        return BBMAP_E_HIP;
+    }
+    return BBMAP_OK;
+}

@@ -313,6 +313,12 @@ class DeviceIndex:
         self.L.bbidx_find_batch_device.restype = C.c_int
         _lib.check(self.L.bbidx_create(device, C.byref(d), C.byref(h)), "bbidx_create")
         self.h = h
+        self.L.bbidx_set_kernel.argtypes = [C.c_void_p, C.c_int32]
+        self.L.bbidx_set_kernel.restype = C.c_int
+
+    def set_kernel(self, kind):
+        """kind: "auto" (one read per wavefront, per-lane kernel for the reads that do not fit) or "lane"."""
+        _lib.check(self.L.bbidx_set_kernel(self.h, {"auto": 0, "lane": 1}[kind]), "bbidx_set_kernel")
 
     def close(self):
         if getattr(self, "h", None):

@@ -239,6 +239,12 @@ int bbidx_find_batch(bbidx_ctx *ctx, int64_t n_reads, const bbidx_read *reads,
  * reference bytes compared, site records written}. */
 int bbidx_last_stats(bbidx_ctx *ctx, int64_t *stats5, float *kernel_ms);
 
+/* Which probe kernel a context launches.  AUTO (default): one read per wavefront (registers + LDS), with the
+ * one-read-per-lane kernel taking the reads that do not fit it (more than 64 keys).  LANE: the per-lane kernel
+ * for every read (any shape up to BBIDX_MAX_KEYS / BBIDX_MAX_READ_LEN; kept as the cross-check). */
+enum { BBIDX_KERNEL_AUTO = 0, BBIDX_KERNEL_LANE = 1 };
+int bbidx_set_kernel(bbidx_ctx *ctx, int32_t kind);
+
 /* =====================================================================================
  * Pipeline glue (device-resident): which probe sites need a slow alignment.
  *   Mirrors the host logic between the two hot kernels: AbstractMapThread.scoreNoIndels

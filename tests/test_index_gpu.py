@@ -8,7 +8,8 @@ from tests.index_problems import make_genome, make_reads
 pytestmark = pytest.mark.gpu
 
 
-def run_case(genomes, k, chromBits, reads, tweak=None):
+def run_case(genomes, k, chromBits, reads, tweak=None, cap=48):
+    """Both probe kernels (one read per wavefront; one read per lane) against the oracle, SiteScore by SiteScore."""
     hi = HostIndex(genomes, k=k, chromBits=chromBits)
     oi = OracleIndex(genomes, k=k, chromBits=chromBits)
     if tweak:
@@ -16,15 +17,19 @@ def run_case(genomes, k, chromBits, reads, tweak=None):
             hi.params[name] = val
             setattr(oi.s.p, name, val)
     di = DeviceIndex(hi)
-    got = di.find_batch([(bp, bs, ks, offs) for bp, bm, bs, ks, offs, t in reads], max_sites=48)
-    nonempty = 0
-    for i, (bp, bm, bs, ks, offs, truth) in enumerate(reads):
-        exp = oi.find(bp, bm, bs, ks, offs, cap=48)
-        assert got[i] is not None, "read %d: probe reported overflow/unsupported" % i
-        assert got[i] == exp, "read %d (truth %s): %s != %s" % (i, truth, got[i], exp)
-        nonempty += bool(exp)
+    exp = []
+    for bp, bm, bs, ks, offs, truth in reads:
+        try:
+            exp.append(oi.find(bp, bm, bs, ks, offs, cap=cap))
+        except RuntimeError:                       # more than `cap` sites: the kernels must report the overflow too
+            exp.append(None)
+    for kind in ("auto", "lane"):
+        di.set_kernel(kind)
+        got = di.find_batch([(bp, bs, ks, offs) for bp, bm, bs, ks, offs, t in reads], max_sites=cap)
+        for i, (bp, bm, bs, ks, offs, truth) in enumerate(reads):
+            assert got[i] == exp[i], "%s kernel, read %d (truth %s): %s != %s" % (kind, i, truth, got[i], exp[i])
     di.close()
-    return nonempty
+    return sum(bool(e) for e in exp)
 
 
 def test_single_chromosome_k13():
@@ -51,3 +56,31 @@ def test_long_reads():
     genomes = [make_genome(61, 200000)]
     reads = make_reads(10, genomes, 150, read_len=400, k=13)
     run_case(genomes, 13, None, reads)
+
+
+def test_kfilter_and_many_keys():
+    # kfilter > 1 exercises the contig bookkeeping of calcAffineScore; density 3 gives > 64 keys for 400-bp reads,
+    # which the wavefront kernel hands to the per-lane kernel
+    genomes = [make_genome(71, 150000)]
+    reads = make_reads(11, genomes, 300, k=12)
+    run_case(genomes, 12, None, reads, tweak={"kfilter": 20})
+    long_reads = make_reads(12, genomes, 60, read_len=400, k=13, density=3.0)
+    assert max(len(r[4]) for r in long_reads) > 64
+    run_case(genomes, 13, None, long_reads)
+
+
+def test_dense_repeats_long_lists():
+    # a genome made mostly of diverged repeat copies: long k-mer lists, many candidate sites per read, greedy trimming
+    import random
+    rng = random.Random(5)
+    fam = [bytes(rng.choice(b"ACGT") for _ in range(500)) for _ in range(4)]
+    body = bytearray()
+    while len(body) < 120000:
+        cp = bytearray(rng.choice(fam))
+        for _ in range(rng.randint(0, 25)):
+            cp[rng.randrange(len(cp))] = rng.choice(b"ACGT")
+        body += cp + bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 300)))
+    genomes = [b"N" * 400 + bytes(body) + b"N" * 400]
+    reads = make_reads(13, genomes, 400, k=11)
+    run_case(genomes, 11, None, reads, cap=160)
+    run_case(genomes, 11, None, reads[:200], tweak={"maxUsableLength": 4000, "maxUsableLength2": 8000}, cap=24)
