@@ -18,10 +18,12 @@
 #include <cstdio>
 
 #include "bbmap_amd.h"
+#include "wave_prims.h"
 
 void bbmap_set_error(const char *msg);
 
 namespace bbpipe {
+using namespace wavep;
 
 __device__ inline int complement_extended(int b) {
     switch (b) {
@@ -47,23 +49,44 @@ __global__ void revcomp_kernel(const bbidx_read *reads, long long n, const uint8
     for (int i = threadIdx.x & 63; i < rr.len; i += 64) out[rr.bases_off + i] = (uint8_t)complement_extended(in[rr.bases_off + rr.len - 1 - i]);
 }
 
-// MSA.scoreNoIndels(read, ref, refStart) without base scores, MultiStateAligner11tsJNI.java:1034-1089
-__device__ int score_no_indels(const uint8_t *read, int len, const uint8_t *ref, int reflen, int refStart) {
-    int score = 0, mode = -1, timeInMode = 0, readStart = 0, readStop = len;
+// MSA.scoreNoIndels(read, ref, refStart) without base scores, MultiStateAligner11tsJNI.java:1034-1089, by one
+// wavefront, 64 bases per step.  The reference's running state is (mode, timeInMode) where undefined bases ('N',
+// bytes >= 128) leave both untouched; in event terms:
+//   match: +100 if the previous event was a match, else +70
+//   substitution: POINTS_SUB_ARRAY[t], t = length of the run of substitution events ending here
+// Both come from the match / substitution ballots with bit arithmetic; the carry between steps is (last event was a
+// match, length of the trailing substitution run).
+__device__ int score_no_indels_wave(const uint8_t *read, int len, const uint8_t *ref, int reflen, int refStart, int lane) {
+    int readStart = 0, readStop = len;
     if (refStart < 0) readStart = -refStart;                  // POINTS_NOREF is 0
     if (refStart + len > reflen) readStop -= (refStart + len - reflen);
-    for (int i = readStart; i < readStop; i++) {
-        const int c = read[i], r = ref[refStart + i];
-        if (c == r && c != 'N') {
-            if (mode == 0) { timeInMode++; score += 100; } else { timeInMode = 0; score += 70; }
-            mode = 0;
-        } else if (c >= 128 || c == 'N') {
-        } else if (r >= 128 || r == 'N') {
-        } else {
-            if (mode == 3) timeInMode++; else timeInMode = 0;
-            const int t = timeInMode + 1;
-            score += t > 5 ? -25 : (t > 1 ? -51 : -127);          // POINTS_SUB_ARRAY[timeInMode+1]
-            mode = 3;
+    int score = 0, carrySub = 0;
+    bool carryMatch = false;
+    for (int base = readStart; base < readStop; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < readStop;
+        const int c = valid ? read[i] : 'N', r = valid ? ref[refStart + i] : 'N';
+        const bool m = valid && c == r && c != 'N';
+        const bool sub = valid && !m && !(c >= 128 || c == 'N') && !(r >= 128 || r == 'N');
+        const u64 Mm = __ballot(m), Sm = __ballot(sub), ev = Mm | Sm, lt = lt_mask(lane);
+        int contrib = 0;
+        if (m) {
+            const u64 pe = ev & lt;
+            contrib = (pe ? (bool)((Mm >> hibit(pe)) & 1) : carryMatch) ? 100 : 70;
+        } else if (sub) {
+            const u64 pm = Mm & lt;
+            const int t = pm ? popc(Sm & lt & gt_mask(hibit(pm))) + 1 : popc(Sm & lt) + 1 + carrySub;
+            contrib = t > 5 ? -25 : (t > 1 ? -51 : -127);      // POINTS_SUB_ARRAY[t]
+        }
+        score += wsum(contrib);
+        if (ev) {
+            const int le = hibit(ev);
+            if ((Mm >> le) & 1) { carryMatch = true; carrySub = 0; }
+            else {
+                const u64 upto = lt_mask(le) | (1ull << le), pm = Mm & upto;
+                carrySub = pm ? popc(Sm & upto & gt_mask(hibit(pm))) : popc(Sm & upto) + carrySub;
+                carryMatch = false;
+            }
         }
     }
     return score;
@@ -88,54 +111,102 @@ struct SelectParams {
     int *noIndelScore;             // optional: per (read, site) ungapped score
 };
 
-__global__ void select_jobs_kernel(const SelectParams P) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P.nreads) return;
-    const int ns = P.nsites[r];
-    if (ns <= 0) { if (ns == 0) atomicAdd(&P.counters[3], 1u); return; }
-    const bbidx_read rr = P.reads[r];
-    const int len = rr.len;
-    const int maxSw = 70 + (len - 1) * 100;                        // msa.maxQuality(len)
-    const int maxImperfect = maxSw + (-472 < -395 - 100 ? -472 : -395 - 100);   // msa.maxImperfectScore
-    bbidx_site *ss = P.sites + r * (long long)P.maxSites;
-    int near = 0; bool forceSlow = false;
-    for (int s = 0; s < ns; s++) {
-        const uint8_t *bases = P.bases + rr.bases_off + (ss[s].strand ? P.minus_delta : 0);
-        const int oldScore = ss[s].score;
-        int sw;
-        if (ss[s].perfect) { near++; sw = maxSw; ss[s].ngaps = 0; }
-        else {
-            const uint8_t *ref = P.refs + P.chromOff[ss[s].chrom];
-            sw = score_no_indels(bases, len, ref, P.chromLen[ss[s].chrom], ss[s].start);
-            if (sw >= maxImperfect) {
-                near++;
-                ss[s].stop = ss[s].start + len - 1; ss[s].ngaps = 0;
-                if (sw >= maxSw) ss[s].perfect = ss[s].semiperfect = 1;
-            } else if (oldScore >= maxImperfect) forceSlow = true;
+constexpr int SEL_WAVES = 4, SEL_READS_PER_WAVE = 8, SEL_CAP = 128;
+
+// One wavefront takes SEL_READS_PER_WAVE consecutive reads; the DP jobs it selects are parked in LDS as
+// (read * maxSites + site, minScore) and written out behind ONE reservation on the global job counter per flush.
+__global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const SelectParams P) {
+    __shared__ int pendSrc[SEL_WAVES][SEL_CAP], pendMin[SEL_WAVES][SEL_CAP];
+    __shared__ unsigned blockCnt[3];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (threadIdx.x < 3) blockCnt[threadIdx.x] = 0;
+    __syncthreads();
+    int npend = 0;
+    unsigned cDone = 0, cGap = 0, cNoSite = 0;
+    auto flush = [&]() {
+        if (npend == 0) return;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&P.counters[0], (unsigned)npend);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (int j = lane; j < npend; j += 64) {
+            const int src = pendSrc[wave][j];
+            const long long r = src / P.maxSites;
+            const bbidx_read rr = P.reads[r];
+            const bbidx_site ssj = P.sites[src];
+            int start = ssj.start, stop = ssj.stop;
+            if (stop - start + 1 + 2 * P.pad > P.maxColumns) stop = start + P.maxColumns - 2 * P.pad - 1;
+            bbmsa_job j_;
+            j_.read_off = rr.bases_off + (ssj.strand ? P.minus_delta : 0);
+            j_.ref_off = P.chromOff[ssj.chrom];
+            j_.read_len = rr.len; j_.ref_len = P.chromLen[ssj.chrom];
+            j_.refStartLoc = start - P.pad; j_.refEndLoc = stop + P.pad;
+            j_.minScore = pendMin[wave][j];
+            j_.flags = BBMSA_FILL_AND_SCORE_LIMITED | BBMSA_DO_TRACEBACK;
+            P.jobs[base + j] = j_;
+            P.jobSrc[base + j] = src;
         }
-        ss[s].score = sw;                                             // ss.setScore(slowScoreNoIndel)
-        if (P.noIndelScore) P.noIndelScore[r * (long long)P.maxSites + s] = sw;
+        wsync();
+        npend = 0;
+    };
+    const long long r0 = ((long long)blockIdx.x * SEL_WAVES + wave) * SEL_READS_PER_WAVE;
+    for (int q = 0; q < SEL_READS_PER_WAVE; q++) {
+        const long long r = r0 + q;
+        if (r >= P.nreads) break;
+        const int ns = P.nsites[r];
+        if (ns <= 0) { if (ns == 0) cNoSite++; continue; }
+        const bbidx_read rr = P.reads[r];
+        const int len = rr.len;
+        const int maxSw = 70 + (len - 1) * 100;                        // msa.maxQuality(len)
+        const int maxImperfect = maxSw + (-472 < -395 - 100 ? -472 : -395 - 100);   // msa.maxImperfectScore
+        bbidx_site *ss = P.sites + r * (long long)P.maxSites;
+        int near = 0; bool forceSlow = false;
+        // lane s keeps what the second pass needs of site s (s < 64; further sites are re-read)
+        int mySw = 0, mySemi = 0, myGaps = 0;
+        for (int s = 0; s < ns; s++) {
+            const int strand = ss[s].strand, chrom = ss[s].chrom, start = ss[s].start, oldScore = ss[s].score;
+            int perfect = ss[s].perfect, semi = ss[s].semiperfect, ngaps = ss[s].ngaps, stop = ss[s].stop;
+            int sw;
+            if (perfect) { near++; sw = maxSw; ngaps = 0; }
+            else {
+                const uint8_t *bases = P.bases + rr.bases_off + (strand ? P.minus_delta : 0);
+                sw = score_no_indels_wave(bases, len, P.refs + P.chromOff[chrom], P.chromLen[chrom], start, lane);
+                if (sw >= maxImperfect) {
+                    near++;
+                    stop = start + len - 1; ngaps = 0;
+                    if (sw >= maxSw) perfect = semi = 1;
+                } else if (oldScore >= maxImperfect) forceSlow = true;
+            }
+            if (lane == 0) {
+                ss[s].score = sw; ss[s].stop = stop; ss[s].ngaps = ngaps; ss[s].perfect = perfect; ss[s].semiperfect = semi;
+                if (P.noIndelScore) P.noIndelScore[r * (long long)P.maxSites + s] = sw;
+            }
+            if (lane == (s & 63)) { mySw = sw; mySemi = semi; myGaps = ngaps; }
+        }
+        __threadfence_block();                                        // lane 0's site updates before any lane re-reads them
+        const int numNear = forceSlow ? -near : near;
+        if (numNear >= 1) { cDone++; continue; }
+        const int minMsaLimit = -258 + (int)__fmul_rn(P.minRatio, (float)maxSw);     // -CLEARZONE1e + (int)(ratio*maxSwScore)
+        for (int s0 = 0; s0 < ns; s0 += 64) {
+            const int s = s0 + lane;
+            int sw = mySw, semi = mySemi, gaps = myGaps;
+            if (s0 > 0 && s < ns) { sw = ss[s].score; semi = ss[s].semiperfect; gaps = ss[s].ngaps; }   // written by lane 0 above
+            const bool cand = s < ns && sw < maxImperfect && !semi;
+            const bool want = cand && gaps == 0;
+            cGap += (unsigned)popc(__ballot(cand && gaps > 0));
+            const u64 W = __ballot(want);
+            const int nw = popc(W);
+            if (npend + nw > SEL_CAP) flush();
+            if (want) { const int slot = npend + popc(W & lt_mask(lane)); pendSrc[wave][slot] = (int)(r * (long long)P.maxSites + s); pendMin[wave][slot] = max(sw, minMsaLimit); }
+            npend += nw;
+            wsync();
+        }
     }
-    const int numNear = forceSlow ? -near : near;
-    if (numNear >= 1) { atomicAdd(&P.counters[1], 1u); return; }
-    const int minMsaLimit = -258 + (int)__fmul_rn(P.minRatio, (float)maxSw);     // -CLEARZONE1e + (int)(ratio*maxSwScore)
-    for (int s = 0; s < ns; s++) {
-        const int sw = ss[s].score;
-        if (!(sw < maxImperfect && !ss[s].semiperfect)) continue;
-        if (ss[s].ngaps > 0) { atomicAdd(&P.counters[2], 1u); continue; }
-        int start = ss[s].start, stop = ss[s].stop;
-        if (stop - start + 1 + 2 * P.pad > P.maxColumns) stop = start + P.maxColumns - 2 * P.pad - 1;
-        const unsigned k = atomicAdd(&P.counters[0], 1u);
-        bbmsa_job j;
-        j.read_off = rr.bases_off + (ss[s].strand ? P.minus_delta : 0);
-        j.ref_off = P.chromOff[ss[s].chrom];
-        j.read_len = len; j.ref_len = P.chromLen[ss[s].chrom];
-        j.refStartLoc = start - P.pad; j.refEndLoc = stop + P.pad;
-        j.minScore = max(sw, minMsaLimit);
-        j.flags = BBMSA_FILL_AND_SCORE_LIMITED | BBMSA_DO_TRACEBACK;
-        P.jobs[k] = j;
-        P.jobSrc[k] = (int)(r * (long long)P.maxSites + s);
-    }
+    // make this wave's site updates visible to its own flush (same wave, program order) and write the jobs out
+    __threadfence_block();
+    flush();
+    if (lane == 0) { atomicAdd(&blockCnt[0], cDone); atomicAdd(&blockCnt[1], cGap); atomicAdd(&blockCnt[2], cNoSite); }
+    __syncthreads();
+    if (threadIdx.x < 3 && blockCnt[threadIdx.x]) atomicAdd(&P.counters[1 + threadIdx.x], blockCnt[threadIdx.x]);
 }
 
 }  // namespace bbpipe
@@ -170,8 +241,9 @@ extern "C" int bbpipe_select_jobs_device(void *stream_, int64_t n_reads, const b
     P.chromOff = (const long long *)chrom_off; P.chromLen = chrom_len; P.refs = refs; P.nreads = n_reads;
     P.pad = pad; P.maxColumns = max_columns; P.minRatio = min_ratio; P.jobs = jobs; P.jobSrc = job_src; P.counters = counters;
     P.noIndelScore = no_indel_score;
-    const long long blocks = (n_reads + 255) / 256;
-    hipLaunchKernelGGL(bbpipe::select_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, P);
+    const long long per_block = bbpipe::SEL_WAVES * bbpipe::SEL_READS_PER_WAVE;
+    const long long blocks = (n_reads + per_block - 1) / per_block;
+    hipLaunchKernelGGL(bbpipe::select_jobs_kernel, dim3((unsigned)blocks), dim3(64 * bbpipe::SEL_WAVES), 0, stream, P);
     PHIP(hipGetLastError());
     return BBMAP_OK;
 }
