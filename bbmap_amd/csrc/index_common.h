@@ -20,6 +20,15 @@ constexpr float DYN_SCORE = 0.84f, DYN_QSCORE = 0.6f, DYN_QSCORE_PERFECT = 0.8f;
 constexpr int NSITES_PENDING = -3;   // written by the wave kernel for reads it leaves to the per-lane kernel
 constexpr int STAT_SHARDS = 256;     // work counters are sharded over this many 64-byte lines
 
+// One 32-byte record per key and block, built once by bbidx_create from the reference's arrays: everything
+// BBIndex.getHits needs for a key on BOTH strands (COUNTS, list start/length, first list entry) in one cache
+// line, instead of 3 dependent 4-byte gathers per strand from three 4^k-entry tables.
+struct __attribute__((aligned(32))) KeyEntry {
+    int cnt, cntRC;                // COUNTS[key], COUNTS[rc(key)]
+    int startF, lenF, firstF;      // this block's list of `key`: starts[key], its length, sites[starts[key]]
+    int startR, lenR, firstR;      // the same for rc(key)
+};
+
 struct DevIndex {
     bbidx_params p;
     int nblocks, nchroms;
@@ -30,6 +39,7 @@ struct DevIndex {
     const uint8_t *const *chromArr;
     const int *chromArrLen;
     const int *chromLengths;
+    const KeyEntry *const *fused;  // per block, 4^k records (null when the table could not be allocated)
 };
 
 struct Params {

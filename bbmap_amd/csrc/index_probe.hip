@@ -686,6 +686,17 @@ __global__ __launch_bounds__(64) void probe_kernel(const Params P) {
     }
 }
 
+__global__ void build_fused_kernel(KeyEntry *out, const int *starts, const int *sites, const int *counts, int k, long long nkeys) {
+    const long long key = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= nkeys) return;
+    const int rc = rc_key((int)key, k);
+    KeyEntry e;
+    e.cnt = counts[key]; e.cntRC = counts[rc];
+    e.startF = starts[key]; e.lenF = starts[key + 1] - e.startF; e.firstF = e.lenF > 0 ? sites[e.startF] : 0;
+    e.startR = starts[rc]; e.lenR = starts[rc + 1] - e.startR; e.firstR = e.lenR > 0 ? sites[e.startR] : 0;
+    out[key] = e;
+}
+
 }  // namespace bbidx
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -750,6 +761,24 @@ extern "C" int bbidx_create(int32_t device, const bbidx_index_desc *d, bbidx_ctx
     if (rc == BBMAP_OK) rc = upload(c, d->lengthHistogram, (size_t)1001, &c->dev.lengthHistogram);
     if (rc == BBMAP_OK) rc = upload(c, d->chromArrLen, (size_t)d->nchroms + 1, &c->dev.chromArrLen);
     if (rc == BBMAP_OK) rc = upload(c, d->chromLengths, (size_t)d->nchroms + 1, &c->dev.chromLengths);
+    if (rc == BBMAP_OK) {
+        // fused per-key records for the wave kernel; if HBM cannot hold them the context stays on the per-lane kernel
+        std::vector<const bbidx::KeyEntry *> hf((size_t)d->nblocks, nullptr);
+        bool ok = true;
+        for (int b = 0; b < d->nblocks && ok; b++) {
+            void *f = nullptr;
+            if (hipMalloc(&f, keyspace * sizeof(bbidx::KeyEntry)) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+            c->allocs.push_back(f);
+            hf[(size_t)b] = (const bbidx::KeyEntry *)f;
+            hipLaunchKernelGGL(bbidx::build_fused_kernel, dim3((unsigned)((keyspace + 255) / 256)), dim3(256), 0, nullptr,
+                               (bbidx::KeyEntry *)f, hs[(size_t)b], hsi[(size_t)b], c->dev.counts, p.k, (long long)keyspace);
+            if (hipGetLastError() != hipSuccess) ok = false;
+        }
+        if (ok && hipDeviceSynchronize() != hipSuccess) ok = false;
+        c->dev.fused = nullptr;
+        if (ok) rc = upload(c, hf.data(), hf.size(), (const bbidx::KeyEntry *const **)&c->dev.fused);
+        else c->kernelKind = BBIDX_KERNEL_LANE;
+    }
     if (rc == BBMAP_OK && hipMalloc(&c->d_queue, 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
     if (rc == BBMAP_OK && hipMalloc(&c->d_stats, bbidx::STAT_SHARDS * 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
     if (rc == BBMAP_OK && (hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess)) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipEventCreate failed");
@@ -866,6 +895,7 @@ extern "C" int bbidx_last_stats(bbidx_ctx *c, int64_t *stats5, float *kernel_ms)
 
 extern "C" int bbidx_set_kernel(bbidx_ctx *c, int32_t kind) {
     if (!c || (kind != BBIDX_KERNEL_AUTO && kind != BBIDX_KERNEL_LANE)) return ifail(BBMAP_E_ARG, "bbidx_set_kernel: bad argument");
+    if (kind == BBIDX_KERNEL_AUTO && !c->dev.fused) return ifail(BBMAP_E_NOMEM, "bbidx_set_kernel: the fused key table could not be allocated");
     c->kernelKind = kind;
     return BBMAP_OK;
 }

@@ -31,14 +31,17 @@ using namespace bbidx;
 using namespace wavep;
 
 constexpr int WAVES_PER_BLOCK = 4;
+constexpr int WMAXLEN = 400;      // longest read this kernel takes (longer ones go to the per-lane kernel): keeps a wave's
+                                  // LDS share under 160 KiB / 32 so that LDS never limits occupancy
 
 struct WaveLds {
-    int loc[MAXLEN];              // the per-base location array of extendScore
-    int xch[5][64];               // lane <-> lane exchange (compaction), greedy-trim tables
+    int loc[WMAXLEN];             // the per-base location array of extendScore
+    int xch[3][64];               // lane <-> lane exchange (compaction), greedy-trim tables
     int gaps[BBIDX_MAX_GAPS];
     int ngaps;
-    uint8_t base[2][MAXLEN + 8];  // [0] the read as given, [1] its reverse complement
-    int8_t bsc[MAXLEN + 8];       // base scores of the plus strand
+    uint8_t base[2][WMAXLEN + 8]; // [0] the read as given, [1] its reverse complement
+    int8_t bsc[WMAXLEN + 8];      // base scores of the plus strand
+    int8_t code[WMAXLEN + 8];     // AminoAcid.baseToNumber of the plus strand (-1 = undefined)
 };
 
 // wave-uniform state of one read
@@ -592,6 +595,9 @@ __device__ int trimByGreedyW(const U &u, WaveLds &S, int off, int ksc, int n, in
     const int shortest = wmin((act && x > 0) ? x : INT_MAX - 1);
     if (initialHitCount < p.minApproxHitsToKeep) return initialHitCount;
     if (shortest > limit3 && !p.slow) { key = -1; return 0; }
+    // every list shorter than SMALL_LIST: whichever list the first round picks as worst, the loop returns there
+    // (`lengths[worst] < SMALL_LIST`), so the values need not be computed
+    if (wmax(x) < SMALL_LIST) return initialHitCount;
     int *listsL = S.xch[0], *offL = S.xch[1], *lenL = S.xch[2];
     if (act) offL[lane] = off;
     int hitsCount = initialHitCount;
@@ -622,43 +628,59 @@ __device__ int trimByGreedyW(const U &u, WaveLds &S, int off, int ksc, int n, in
     return hitsCount;
 }
 
-// compaction of up to five per-lane values through LDS: lanes with keep==true move to lanes 0..count-1
-template <int NV> __device__ inline int compactW(WaveLds &S, int lane, bool keep, int (&v)[NV]) {
+// Compaction: lanes with keep==true move to lanes 0..count-1.  One LDS round trip publishes, for every destination
+// lane, the lane it takes its values from; the values themselves then move with ds_bpermute (no LDS storage).
+__device__ inline int compactSrc(WaveLds &S, int lane, bool keep, int &count) {
     const u64 M = __ballot(keep);
-    const int pos = popc(M & lt_mask(lane));
     wsync();
-    if (keep) for (int j = 0; j < NV; j++) S.xch[j][pos] = v[j];
+    if (keep) S.xch[0][popc(M & lt_mask(lane))] = lane;
     wsync();
-    for (int j = 0; j < NV; j++) v[j] = S.xch[j][lane];
+    const int src = S.xch[0][lane];
     wsync();
-    return popc(M);
+    count = popc(M);
+    return lane < count ? src : lane;
+}
+
+// what BBIndex.getHits needs for one key on one strand, taken from the fused KeyEntry of the key (plus strand) or of
+// the key it is the reverse complement of (minus strand)
+struct KeyHit { int cnt, start, len, first; };
+
+// the minus-strand view of lane i is the reverse-complement half of the record held by lane n-1-i
+__device__ inline KeyHit minusView(int lane, int n, int cntRC, int startR, int lenR, int firstR) {
+    const int src = (lane < n) ? n - 1 - lane : lane;
+    KeyHit h;
+    h.cnt = __shfl(cntRC, src); h.start = __shfl(startR, src); h.len = __shfl(lenR, src); h.first = __shfl(firstR, src);
+    return h;
 }
 
 // BBIndex.getHits (:354-391) + the heap fill at the top of slowWalk3/findMaxQscore2: builds the compacted lists
-__device__ int makeListsW(const U &u, WaveLds &S, WL &L, int block, int baseChrom, int key, int off, int ksc, int n, int minHits) {
-    const DevIndex &ix = *u.ix;
-    const int *bs = ix.starts[block], *st = ix.sites[block];
-    int start = -1, stop = -1, first = 0;
-    if (u.lane < n && key >= 0 && ix.counts[key] > 0) {
-        const int s0 = bs[key], x = bs[key + 1] - s0;
-        if (x > 0) { first = st[s0]; if (first != -1) { start = s0; stop = s0 + x; } }
-    }
-    const int nh = popc(__ballot(start >= 0));
+__device__ int makeListsW(const U &u, WaveLds &S, WL &L, int block, int baseChrom, const KeyHit &h, int off, int ksc, int n, int minHits) {
+    const bool hit = u.lane < n && h.cnt > 0 && h.len > 0 && h.first != -1;
+    const u64 M = __ballot(hit);
+    const int nh = popc(M);
     if (nh < minHits) return nh;
-    int v[5] = {start, stop, off, ksc, first};
-    compactW<5>(S, u.lane, start >= 0, v);
-    L.n = L.nlive = nh; L.sites = st;
+    int cnt;
+    const int src = compactSrc(S, u.lane, hit, cnt);
+    L.n = L.nlive = nh; L.sites = u.ix->sites[block];
     L.live = u.lane < nh;
-    L.row = v[0]; L.stop = v[1]; L.offs = v[2]; L.ksc = v[3];
-    L.value = L.live ? adjustSite(u, v[4], v[2], baseChrom) : 0;
+    L.row = __shfl(h.start, src); L.stop = L.row + __shfl(h.len, src); L.offs = __shfl(off, src); L.ksc = __shfl(ksc, src);
+    const int first = __shfl(h.first, src);
+    L.value = L.live ? adjustSite(u, first, L.offs, baseChrom) : 0;
     return nh;
 }
 
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void probe_wave_kernel(const Params P) {
+#ifndef BBIDX_WAVE_OCC
+#define BBIDX_WAVE_OCC 6
+#endif
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wave_kernel(const Params P) {
     __shared__ WaveLds lds[WAVES_PER_BLOCK];
     __shared__ unsigned blockStats[5];
+    __shared__ uint8_t compLut[256];      // AminoAcid.baseToComplementExtended
+    __shared__ int8_t numLut[256];        // AminoAcid.baseToNumber
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x < 5) blockStats[threadIdx.x] = 0;
+    compLut[threadIdx.x] = (uint8_t)complement_extended((int)threadIdx.x);
+    numLut[threadIdx.x] = (int8_t)(threadIdx.x < 128 ? base_num((int)threadIdx.x) : -1);
     __syncthreads();
     WaveLds &S = lds[wave];
     const DevIndex &ix = P.ix;
@@ -686,7 +708,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void probe_wave_kernel(const 
     if (!done) {
         if (n < 1 || blen < p.k) { result = 0; done = true; }
         else if (n > KB || blen > MAXLEN) { result = -2; done = true; }
-        else if (n > 64) { result = NSITES_PENDING; done = true; }
+        else if (n > 64 || blen > WMAXLEN) { result = NSITES_PENDING; done = true; }
     }
     // one uniform do { } while (0) body per read: `break` = finished with `result`
     if (!done) do {
@@ -696,9 +718,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void probe_wave_kernel(const 
         int sumBS = 0; bool undefinedBase = false;
         for (int i = lane; i < blen; i += 64) {
             const int b = bP[i], q = qP[i];
-            S.base[0][i] = (uint8_t)b; S.base[1][blen - 1 - i] = (uint8_t)complement_extended(b); S.bsc[i] = (int8_t)q;
+            S.base[0][i] = (uint8_t)b; S.base[1][blen - 1 - i] = compLut[b]; S.bsc[i] = (int8_t)q;
             sumBS += q;
-            if (b >= 128 || base_num(b) < 0) undefinedBase = true;
+            const int cd = numLut[b];
+            S.code[i] = (int8_t)cd;
+            if (cd < 0) undefinedBase = true;
         }
         sumBS = wsum(sumBS);
         const bool fullyDefined = __ballot(undefinedBase) == 0;
@@ -709,14 +733,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void probe_wave_kernel(const 
         if (lane < n) {
             off = koff[lane]; ksc = kscore[lane];
             int key = 0;
-            for (int q = off; q < off + p.k; q++) { const int x = base_num(S.base[0][q]); if (x < 0) { key = -1; break; } key = (key << 2) | x; }
+            for (int q = off; q < off + p.k; q++) { const int x = S.code[q]; if (x < 0) { key = -1; break; } key = (key << 2) | x; }
             keyOrig = key;
         }
         {   // the wave kernel's coverage arithmetic needs non-decreasing offsets (KeyRing.makeOffsets gives them)
             const int prevOff = __shfl_up(off, 1);
             if (__ballot(lane > 0 && lane < n && off < prevOff)) { result = NSITES_PENDING; break; }
         }
-        const int cntOrig = keyOrig >= 0 ? ix.counts[keyOrig] : 0;
+        // one 32-byte fused record per key: COUNTS and the list heads of the key and of its reverse complement
+        KeyEntry e; e.cnt = e.cntRC = e.startF = e.lenF = e.firstF = e.startR = e.lenR = e.firstR = 0;
+        if (keyOrig >= 0) e = ix.fused[0][keyOrig];
+        const int cntOrig = e.cnt;
         int key = keyOrig;
         auto countHits = [&](int maxLen) -> int {
             const bool v = key >= 0 && cntOrig > 0 && cntOrig < maxLen;
@@ -734,13 +761,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void probe_wave_kernel(const 
         }
         const int nOriginal = n;
         int cnt = cntOrig;
-        if (numHits < n) { int v[4] = {off, key, ksc, cnt}; n = compactW<4>(S, lane, key >= 0, v); off = v[0]; key = v[1]; ksc = v[2]; cnt = v[3]; if (lane >= n) key = -1; }
+        auto compactKeys = [&]() {
+            const int src = compactSrc(S, lane, lane < n && key >= 0, n);
+            off = __shfl(off, src); key = __shfl(key, src); ksc = __shfl(ksc, src); cnt = __shfl(cnt, src);
+            e.cntRC = __shfl(e.cntRC, src); e.startF = __shfl(e.startF, src); e.lenF = __shfl(e.lenF, src); e.firstF = __shfl(e.firstF, src);
+            e.startR = __shfl(e.startR, src); e.lenR = __shfl(e.lenR, src); e.firstR = __shfl(e.firstR, src);
+            if (lane >= n) key = -1;
+        };
+        if (numHits < n) compactKeys();
         if (p.trimByGreedy) {
             const int maxLists = max((int)(HIT_FRACTION_TO_RETAIN * n), MIN_LISTS_RETAIN);
             numHits = trimByGreedyW(u, S, off, ksc, n, maxLists, key, cnt);
         }
         if (numHits < p.minApproxHitsToKeep) { result = 0; break; }
-        if (numHits < n) { int v[3] = {off, key, ksc}; n = compactW<3>(S, lane, lane < n && key >= 0, v); off = v[0]; key = v[1]; ksc = v[2]; if (lane >= n) key = -1; }
+        if (numHits < n) compactKeys();
         // minus strand: KeyRing.reverseComplementKeys / reverseOffsets
         int offM = 0, keyM = -1, kscM = 0;
         {
@@ -748,6 +782,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void probe_wave_kernel(const 
             const int so = __shfl(off, src), sk = __shfl(key, src), ss = __shfl(ksc, src);
             if (lane < n) { offM = blen - (so + p.k); keyM = rc_key(sk, p.k); kscM = ss; }
         }
+        // block 0's list heads for both strands come from the records already in registers; further blocks reload
+        KeyHit hitP0, hitM0;
+        hitP0.cnt = cnt; hitP0.start = e.startF; hitP0.len = e.lenF; hitP0.first = e.firstF;
+        hitM0 = minusView(lane, n, e.cntRC, e.startR, e.lenR, e.firstR);
+        auto keyHits = [&](int block, int strand) -> KeyHit {
+            if (block == 0) return strand ? hitM0 : hitP0;
+            KeyEntry eb; eb.cnt = eb.cntRC = eb.startF = eb.lenF = eb.firstF = eb.startR = eb.lenR = eb.firstR = 0;
+            if (lane < n && key >= 0) eb = ix.fused[block][key];
+            if (strand) return minusView(lane, n, eb.cntRC, eb.startR, eb.lenR, eb.firstR);
+            KeyHit h; h.cnt = eb.cnt; h.start = eb.startF; h.len = eb.lenF; h.first = eb.firstF;
+            return h;
+        };
         const int mqs = maxQuickScoreW(u, off, ksc, n);
         int bestScores[6] = {0, 0, 0, 0, 0, 0};
         const bool prescan = p.prescanQscore && numHits >= 5;
@@ -775,7 +821,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void probe_wave_kernel(const 
                 const int baseChrom = u.c.baseChrom(chrom);
                 const int block = baseChrom >> p.chromBits;
                 for (int pmi = 0; pmi < 2 && !earlyOut; pmi++, cycle++) {
-                    const int nh = makeListsW(u, S, L, block, baseChrom, pmi ? keyM : key, pmi ? offM : off, pmi ? kscM : ksc, n, minHitsToScore);
+                    const int nh = makeListsW(u, S, L, block, baseChrom, keyHits(block, pmi), pmi ? offM : off, pmi ? kscM : ksc, n, minHitsToScore);
                     if (nh < minHitsToScore) { if (lane == cycle) { prescore = -9999; precount = 0; } }
                     else {
                         int tq, th;
@@ -808,7 +854,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void probe_wave_kernel(const 
             const int block = baseChrom >> p.chromBits;
             for (int strand = 0; strand < 2 && !quit; strand++, cycle++) {
                 if (!prescan || rl(precount, cycle) >= hitsCutoff || rl(prescore, cycle) >= qscoreCutoff) {
-                    const int nh = makeListsW(u, S, L, block, baseChrom, strand ? keyM : key, strand ? offM : off, strand ? kscM : ksc, n, p.minApproxHitsToKeep);
+                    const int nh = makeListsW(u, S, L, block, baseChrom, keyHits(block, strand), strand ? offM : off, strand ? kscM : ksc, n, p.minApproxHitsToKeep);
                     if (nh >= p.minApproxHitsToKeep)
                         slowWalk3W(u, S, L, strand, n, strand ? offM : off, strand ? kscM : ksc, chrom, ssl, bestScores,
                                    allBasesCovered, maxScore, fullyDefined);
