@@ -1,0 +1,31 @@
+// Host-side context of the MultiStateAligner11ts entry points (msa_host.hip, msa_gapped.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bbmap_amd.h"
+
+struct bbmsa_ctx {
+    bbmsa_config cfg;
+    int device;
+    int numCUs;
+    // fast kernel geometry
+    int G, R, fastCols, tmpBytes, blocks, ldsBytes;
+    long long dirSlotDwords;
+    unsigned int *d_dir;
+    unsigned int *d_counters;   // [0]=fast queue, [1]=slow count, [2]=generic queue
+    int *d_slowList;
+    long long slowCap;
+    // generic kernel
+    int genThreads;
+    int *d_matrix;
+    int *d_limits;
+    // gapped-reference scratch (msa_gapped.hip), grown on demand
+    uint8_t *d_gref;
+    int *d_gaux;
+    bbmsa_job *d_gjobs;
+    long long gappedCap;
+    hipEvent_t ev[3];
+    bool timed;
+    bool banded;
+};
+

@@ -571,8 +571,11 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 int padLeft = 0, padRight = 0;
                 if (bestRefStart < a) padLeft = max(0, a - bestRefStart);
                 else if (bestRefStart == a && state == 2) padLeft = stateTime;
-                if (bestRefStop > b) padRight = max(0, bestRefStop - b);
-                else if (bestRefStop == b && res2 == 2) padRight = bPacked & kTimeMask;
+                // score(..., gapped=true) walks with refEndLoc = translateToGappedCoordinate(b), which the library
+                // parked in ref_len (MultiStateAligner11tsJNI.java:507-516)
+                const int bW = (jb.flags & BBMSA_INTERNAL_GAPPED) ? jb.ref_len : b;
+                if (bestRefStop > bW) padRight = max(0, bestRefStop - bW);
+                else if (bestRefStop == bW && res2 == 2) padRight = bPacked & kTimeMask;
                 if (wantScore) {
                     sc[0] = bScore >> kScoreOffset; sc[1] = bestRefStart; sc[2] = bestRefStop;
                     sc[3] = rows; sc[4] = res1; sc[5] = res2; sc[6] = padLeft; sc[7] = padRight;

@@ -320,8 +320,9 @@ __global__ __launch_bounds__(64) void msa_fill_generic_kernel(const GenericParam
                 int padLeft = 0, padRight = 0;
                 if (bestRefStart < a) padLeft = max(0, a - bestRefStart);
                 else if (bestRefStart == a && state == 2) padLeft = stateTime;
-                if (bestRefStop > b) padRight = max(0, bestRefStop - b);
-                else if (bestRefStop == b && bestState == 2) padRight = plane_at(pl, bestState, rows, bestCol) & kTimeMask;
+                const int bW = (jb.flags & BBMSA_INTERNAL_GAPPED) ? jb.ref_len : b;      // see msa_fill_fast.hip
+                if (bestRefStop > bW) padRight = max(0, bestRefStop - bW);
+                else if (bestRefStop == bW && bestState == 2) padRight = plane_at(pl, bestState, rows, bestCol) & kTimeMask;
                 r.score[0] = bestScore >> kScoreOffset; r.score[1] = bestRefStart; r.score[2] = bestRefStop;
                 r.score[3] = rows; r.score[4] = bestCol; r.score[5] = bestState;
                 if (padLeft > 0 || padRight > 0) { r.score[6] = padLeft; r.score[7] = padRight; r.score_len = 8; }

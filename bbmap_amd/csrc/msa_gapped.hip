@@ -1,0 +1,210 @@
+// Gapped reference windows for the MultiStateAligner11ts entry points.
+//
+// A SiteScore whose index hit spans a long deletion carries a gap array {start, stop, start, stop, ...}; the
+// reference then aligns against a "gapped reference" in which every long gap is shortened to
+// GAPBUFFER + (gap % GAPLEN) bases, (gap - GAPBUFFER2) / GAPLEN gap symbols '-' (each standing for GAPLEN = 128
+// bases) and GAPBUFFER more bases (MultiStateAligner11tsJNI.makeGref, current/align2/MultiStateAligner11tsJNI.java:
+// 668-757), fills that buffer from column 0 to greflimit (fillLimited(..., gaps) :116-128), and translates the
+// resulting coordinates back (:759-801).  Here: one small kernel builds the gapped references of a batch into a
+// scratch buffer in HBM and derives ordinary jobs that point at them (a job's ref_off is relative to `refs`, so it
+// can address the scratch buffer), the normal fill kernels run, and a second small kernel translates score[1..2].
+// Gapped sites are rare (a few per thousand reads), so neither helper kernel is tuned.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdio>
+#include <cstring>
+
+#include "msa_common.h"
+#include "msa_ctx.h"
+
+void bbmap_set_error(const char *msg);
+
+namespace bbmsa {
+
+constexpr int K_GAPBUFFER = 64, K_GAPBUFFER2 = 128, K_GREF_CUSHION = 128;
+constexpr uint8_t K_GAPC = '-';
+
+struct GappedParams {
+    const bbmsa_job *jobs;
+    const bbmsa_gaps *gaps;
+    const uint8_t *refs;
+    bbmsa_job *out_jobs;
+    uint8_t *gref;            // n x glen bytes
+    int *aux;                 // n x 4: {origin, greflimit2, status (0 ok, 2 bad shape), ngaps}
+    long long njobs;
+    int glen;                 // maxColumns + 2 (the reference's grefbuffer length, MSA.java:77)
+    int maxColumns;
+};
+
+// MSA.fillAndScoreLimited's gapped branch (:104-105,:125-131) + makeGref (:668-757) for one job per thread
+__global__ void make_gref_kernel(const GappedParams P) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.njobs) return;
+    bbmsa_job jb = P.jobs[j];
+    int *aux = P.aux + 4 * j;
+    const int ngaps = P.gaps[j].ngaps;
+    aux[3] = ngaps;
+    if (ngaps <= 0) { aux[0] = 0; aux[1] = 0; aux[2] = 0; P.out_jobs[j] = jb; return; }
+    const uint8_t *ref = P.refs + jb.ref_off;
+    const int a = max(0, jb.refStartLoc), b = min(jb.ref_len - 1, jb.refEndLoc);
+    int g[BBMSA_MAX_GAPS];
+    for (int i = 0; i < BBMSA_MAX_GAPS; i++) g[i] = P.gaps[j].gaps[i];
+    bool bad = ngaps < 2 || ngaps > BBMSA_MAX_GAPS || (ngaps & 1) || b < a;
+    int gpos = 0, origin = 0, greflimit2 = -1;
+    uint8_t *gref = P.gref + j * (long long)P.glen;
+    if (!bad) {
+        g[0] = min(g[0], a);
+        g[ngaps - 1] = max(g[ngaps - 1], b);
+        origin = g[0];
+        // every byte the reference would read must exist (Java would throw on a negative or too large index)
+        for (int i = 0; i < ngaps && !bad; i++) if (g[i] < 0 || g[i] >= jb.ref_len) bad = true;
+        for (int i = 0; i + 1 < ngaps && !bad; i++) if (g[i + 1] < g[i]) bad = true;
+    }
+    for (int i = 0; i < ngaps && !bad; i += 2) {
+        const int x = g[i], y = g[i + 1];
+        for (int r = x; r <= y && !bad; r++, gpos++) { if (gpos >= P.glen) bad = true; else gref[gpos] = ref[r]; }
+        if (i + 2 < ngaps && !bad) {
+            const int z = g[i + 2];
+            const int gap = z - y - 1;
+            if (gap < K_GAPBUFFER2) { bad = true; break; }                        // the reference asserts gap >= MINGAP
+            const int rem = gap % kGapLen;
+            const int lim = y + K_GAPBUFFER + rem;
+            const int div = (gap - K_GAPBUFFER2) / kGapLen;
+            for (int r = y + 1; r <= lim && !bad; r++, gpos++) { if (gpos >= P.glen) bad = true; else gref[gpos] = ref[r]; }
+            for (int q = 0; q < div && !bad; q++, gpos++) { if (gpos >= P.glen) bad = true; else gref[gpos] = K_GAPC; }
+            for (int r = z - K_GAPBUFFER; r < z && !bad; r++, gpos++) { if (gpos >= P.glen) bad = true; else gref[gpos] = ref[r]; }
+        }
+    }
+    const int greflimit = gpos;
+    if (!bad) {
+        const int lim = min(P.glen, greflimit + K_GREF_CUSHION);
+        for (int i = greflimit, r = b + 1; i < lim; i++, r++) { gref[i] = (r < jb.ref_len) ? ref[r] : (uint8_t)'N'; greflimit2 = i; }
+        // translateToGappedCoordinate(a) must be 0 (asserted by the reference, :514): a <= origin always holds here
+        // because origin = min(gaps[0], a); the fill covers columns 0..greflimit, which needs that byte to exist
+        if (greflimit >= P.glen || greflimit + 1 > P.maxColumns) bad = true;
+    }
+    aux[0] = origin; aux[1] = greflimit2; aux[2] = bad ? 2 : 0;
+    bbmsa_job o = jb;
+    if (bad) {
+        // an impossible shape: the fill kernels answer BBMSA_ST_BAD_SHAPE for it
+        o.read_len = 0; o.refStartLoc = 0; o.refEndLoc = -1; o.flags = BBMSA_FILL_LIMITED_RAW;
+    } else {
+        // translateToGappedCoordinate(b): walk the gapped reference until the original coordinate is b (:781-801)
+        int gstop = INT_MIN;
+        if (b <= origin) gstop = b - origin;
+        else for (int i = 0, q = origin; i < greflimit2; i++) { if (q == b) { gstop = i; break; } q += (gref[i] == K_GAPC) ? kGapLen : 1; }
+        o.ref_off = (int64_t)(gref - P.refs);
+        o.ref_len = gstop;                                   // parked for the score2 tail (BBMSA_INTERNAL_GAPPED)
+        o.refStartLoc = 0; o.refEndLoc = greflimit;
+        o.flags = BBMSA_FILL_LIMITED | BBMSA_DO_SCORE | (jb.flags & BBMSA_DO_TRACEBACK) | BBMSA_INTERNAL_GAPPED;
+    }
+    P.out_jobs[j] = o;
+}
+
+// translateFromGappedCoordinate (:759-779) on score[1], score[2]
+__global__ void gref_post_kernel(const GappedParams P, bbmsa_result *results) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.njobs) return;
+    const int *aux = P.aux + 4 * j;
+    if (aux[3] <= 0 || aux[2] != 0) return;
+    bbmsa_result &r = results[j];
+    if (r.score_len <= 0) return;
+    const uint8_t *gref = P.gref + j * (long long)P.glen;
+    const int origin = aux[0], greflimit2 = aux[1];
+    for (int w = 1; w <= 2; w++) {
+        const int point = r.score[w];
+        int out = INT_MIN;
+        if (point <= 0) out = origin + point;
+        else for (int i = 0, q = origin; i < greflimit2; i++) { if (i == point) { out = q; break; } q += (gref[i] == K_GAPC) ? kGapLen : 1; }
+        r.score[w] = out;
+    }
+}
+
+}  // namespace bbmsa
+
+static thread_local char g_gerr[256];
+#define GHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(g_gerr, sizeof g_gerr, "%s failed: %s", #expr, hipGetErrorString(e_)); bbmap_set_error(g_gerr); return BBMAP_E_HIP; } } while (0)
+
+extern "C" int bbmsa_align_gapped_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const bbmsa_job *jobs,
+                                               const bbmsa_gaps *gaps, const uint8_t *reads, const uint8_t *refs,
+                                               bbmsa_result *results, uint8_t *match, int32_t match_stride) {
+    if (!c) { bbmap_set_error("bbmsa_align_gapped_batch_device: null context"); return BBMAP_E_ARG; }
+    if (n_jobs < 0 || n_jobs > 0x7fffffffLL) { bbmap_set_error("bbmsa_align_gapped_batch_device: n_jobs out of range"); return BBMAP_E_ARG; }
+    if (n_jobs == 0) return BBMAP_OK;
+    if (!jobs || !gaps || !reads || !refs || !results) { bbmap_set_error("bbmsa_align_gapped_batch_device: null buffer"); return BBMAP_E_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    GHIP(hipSetDevice(c->device));
+    const int glen = c->cfg.maxColumns + 2;
+    if (n_jobs > c->gappedCap) {
+        GHIP(hipStreamSynchronize(stream));
+        if (c->d_gref) { (void)hipFree(c->d_gref); c->d_gref = nullptr; }
+        if (c->d_gaux) { (void)hipFree(c->d_gaux); c->d_gaux = nullptr; }
+        if (c->d_gjobs) { (void)hipFree(c->d_gjobs); c->d_gjobs = nullptr; }
+        c->gappedCap = 0;
+        GHIP(hipMalloc(&c->d_gref, (size_t)n_jobs * (size_t)glen));
+        GHIP(hipMalloc(&c->d_gaux, (size_t)n_jobs * 16));
+        GHIP(hipMalloc(&c->d_gjobs, (size_t)n_jobs * sizeof(bbmsa_job)));
+        c->gappedCap = n_jobs;
+    }
+    bbmsa::GappedParams P;
+    P.jobs = jobs; P.gaps = gaps; P.refs = refs; P.out_jobs = c->d_gjobs; P.gref = c->d_gref; P.aux = c->d_gaux;
+    P.njobs = n_jobs; P.glen = glen; P.maxColumns = c->cfg.maxColumns;
+    const unsigned blocks = (unsigned)((n_jobs + 63) / 64);
+    hipLaunchKernelGGL(bbmsa::make_gref_kernel, dim3(blocks), dim3(64), 0, stream, P);
+    GHIP(hipGetLastError());
+    const int rc = bbmsa_align_batch_device(c, stream_, n_jobs, c->d_gjobs, reads, refs, results, match, match_stride);
+    if (rc != BBMAP_OK) return rc;
+    hipLaunchKernelGGL(bbmsa::gref_post_kernel, dim3(blocks), dim3(64), 0, stream, P, results);
+    GHIP(hipGetLastError());
+    return BBMAP_OK;
+}
+
+extern "C" int bbmsa_align_gapped_batch(bbmsa_ctx *c, int64_t n_jobs, const bbmsa_job *jobs, const bbmsa_gaps *gaps,
+                                        const uint8_t *reads, int64_t reads_bytes, const uint8_t *refs, int64_t refs_bytes,
+                                        bbmsa_result *results, uint8_t *match, int32_t match_stride) {
+    if (!c) { bbmap_set_error("bbmsa_align_gapped_batch: null context"); return BBMAP_E_ARG; }
+    if (n_jobs == 0) return BBMAP_OK;
+    if (n_jobs < 0 || !jobs || !gaps || !reads || !refs || !results || reads_bytes < 0 || refs_bytes < 0) {
+        bbmap_set_error("bbmsa_align_gapped_batch: bad argument"); return BBMAP_E_ARG;
+    }
+    for (int64_t i = 0; i < n_jobs; i++) {
+        const bbmsa_job &j = jobs[i];
+        if (j.read_len < 0 || j.read_off < 0 || j.read_off + j.read_len > reads_bytes ||
+            j.ref_len < 0 || j.ref_off < 0 || j.ref_off + j.ref_len > refs_bytes) {
+            bbmap_set_error("bbmsa_align_gapped_batch: a job lies outside its buffers"); return BBMAP_E_ARG;
+        }
+        if (gaps[i].ngaps <= 0 && !(j.flags & BBMSA_CLAMP_WINDOW) && (j.refStartLoc < 0 || j.refEndLoc >= j.ref_len)) {
+            bbmap_set_error("bbmsa_align_gapped_batch: window outside its reference array"); return BBMAP_E_ARG;
+        }
+    }
+    GHIP(hipSetDevice(c->device));
+    bbmsa_job *d_jobs = nullptr; bbmsa_gaps *d_gaps = nullptr; uint8_t *d_reads = nullptr, *d_refs = nullptr, *d_match = nullptr; bbmsa_result *d_res = nullptr;
+    int rc = BBMAP_OK;
+#define GGO(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(g_gerr, sizeof g_gerr, "%s failed: %s", #expr, hipGetErrorString(e_)); bbmap_set_error(g_gerr); rc = BBMAP_E_HIP; goto done; } } while (0)
+    GGO(hipMalloc(&d_jobs, (size_t)n_jobs * sizeof(bbmsa_job)));
+    GGO(hipMalloc(&d_gaps, (size_t)n_jobs * sizeof(bbmsa_gaps)));
+    GGO(hipMalloc(&d_reads, (size_t)(reads_bytes > 0 ? reads_bytes : 1)));
+    GGO(hipMalloc(&d_refs, (size_t)(refs_bytes > 0 ? refs_bytes : 1)));
+    GGO(hipMalloc(&d_res, (size_t)n_jobs * sizeof(bbmsa_result)));
+    if (match) GGO(hipMalloc(&d_match, (size_t)n_jobs * (size_t)match_stride));
+    GGO(hipMemcpy(d_jobs, jobs, (size_t)n_jobs * sizeof(bbmsa_job), hipMemcpyHostToDevice));
+    GGO(hipMemcpy(d_gaps, gaps, (size_t)n_jobs * sizeof(bbmsa_gaps), hipMemcpyHostToDevice));
+    GGO(hipMemcpy(d_reads, reads, (size_t)reads_bytes, hipMemcpyHostToDevice));
+    GGO(hipMemcpy(d_refs, refs, (size_t)refs_bytes, hipMemcpyHostToDevice));
+    GGO(hipMemset(d_res, 0xff, (size_t)n_jobs * sizeof(bbmsa_result)));
+    rc = bbmsa_align_gapped_batch_device(c, nullptr, n_jobs, d_jobs, d_gaps, d_reads, d_refs, d_res, d_match, match_stride);
+    if (rc != BBMAP_OK) goto done;
+    GGO(hipStreamSynchronize(nullptr));
+    GGO(hipMemcpy(results, d_res, (size_t)n_jobs * sizeof(bbmsa_result), hipMemcpyDeviceToHost));
+    if (match) GGO(hipMemcpy(match, d_match, (size_t)n_jobs * (size_t)match_stride, hipMemcpyDeviceToHost));
+done:
+    if (d_jobs) (void)hipFree(d_jobs);
+    if (d_gaps) (void)hipFree(d_gaps);
+    if (d_reads) (void)hipFree(d_reads);
+    if (d_refs) (void)hipFree(d_refs);
+    if (d_res) (void)hipFree(d_res);
+    if (d_match) (void)hipFree(d_match);
+    return rc;
+#undef GGO
+}

@@ -30,25 +30,7 @@ static int fail(int code, const char *fmt, const char *detail = "") {
         }                                                                                  \
     } while (0)
 
-struct bbmsa_ctx {
-    bbmsa_config cfg;
-    int device;
-    int numCUs;
-    // fast kernel geometry
-    int G, R, fastCols, tmpBytes, blocks, ldsBytes;
-    long long dirSlotDwords;
-    unsigned int *d_dir;
-    unsigned int *d_counters;   // [0]=fast queue, [1]=slow count, [2]=generic queue
-    int *d_slowList;
-    long long slowCap;
-    // generic kernel
-    int genThreads;
-    int *d_matrix;
-    int *d_limits;
-    hipEvent_t ev[3];
-    bool timed;
-    bool banded;
-};
+#include "msa_ctx.h"
 
 extern "C" const char *bbmap_last_error(void) { return g_err; }
 void bbmap_set_error(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
@@ -143,6 +125,9 @@ extern "C" void bbmsa_destroy(bbmsa_ctx *c) {
     if (c->d_slowList) (void)hipFree(c->d_slowList);
     if (c->d_matrix) (void)hipFree(c->d_matrix);
     if (c->d_limits) (void)hipFree(c->d_limits);
+    if (c->d_gref) (void)hipFree(c->d_gref);
+    if (c->d_gaux) (void)hipFree(c->d_gaux);
+    if (c->d_gjobs) (void)hipFree(c->d_gjobs);
     for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }

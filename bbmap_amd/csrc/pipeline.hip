@@ -11,8 +11,8 @@
 //   3. otherwise every site with ungapped score < maxImperfectScore and not semiperfect becomes one DP job:
 //      window = site +- SLOW_ALIGN_PADDING, minScore = max(ungapped score, minMsaLimit) (BBMapThread.java:289-309).
 // Not carried over (host-side policies of the mapper, out of scope here): trimList, findTipDeletions, the
-// stop-anchored retry of scoreNoIndels (:808-815), the second wider fill after pad hints (scoreSlow :312-335) and
-// sites that carry a gap array (they need makeGref; such sites are counted and skipped).
+// stop-anchored retry of scoreNoIndels (:808-815), the second wider fill after pad hints (scoreSlow :312-335).
+// Sites that carry a gap array go to a second job list (bbmsa_align_gapped_batch_device builds their gapped reference).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -107,8 +107,11 @@ struct SelectParams {
     float minRatio;
     bbmsa_job *jobs;
     int *jobSrc;                   // read * maxSites + site for each job
-    unsigned int *counters;        // [0] jobs, [1] reads finished without DP, [2] sites skipped (gap arrays), [3] reads with no site
+    unsigned int *counters;        // [0] jobs, [1] reads finished without DP, [2] gapped jobs (sites with gap arrays), [3] reads with no site
     int *noIndelScore;             // optional: per (read, site) ungapped score
+    bbmsa_job *gjobs;              // optional second list: jobs for sites that carry a gap array (need makeGref)
+    bbmsa_gaps *ggaps;
+    int *gjobSrc;
 };
 
 constexpr int SEL_WAVES = 4, SEL_READS_PER_WAVE = 8, SEL_CAP = 128;
@@ -117,12 +120,12 @@ constexpr int SEL_WAVES = 4, SEL_READS_PER_WAVE = 8, SEL_CAP = 128;
 // (read * maxSites + site, minScore) and written out behind ONE reservation on the global job counter per flush.
 __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const SelectParams P) {
     __shared__ int pendSrc[SEL_WAVES][SEL_CAP], pendMin[SEL_WAVES][SEL_CAP];
-    __shared__ unsigned blockCnt[3];
+    __shared__ unsigned blockCnt[2];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (threadIdx.x < 3) blockCnt[threadIdx.x] = 0;
+    if (threadIdx.x < 2) blockCnt[threadIdx.x] = 0;
     __syncthreads();
     int npend = 0;
-    unsigned cDone = 0, cGap = 0, cNoSite = 0;
+    unsigned cDone = 0, cNoSite = 0;
     auto flush = [&]() {
         if (npend == 0) return;
         unsigned base = 0;
@@ -192,7 +195,25 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
             if (s0 > 0 && s < ns) { sw = ss[s].score; semi = ss[s].semiperfect; gaps = ss[s].ngaps; }   // written by lane 0 above
             const bool cand = s < ns && sw < maxImperfect && !semi;
             const bool want = cand && gaps == 0;
-            cGap += (unsigned)popc(__ballot(cand && gaps > 0));
+            if (cand && gaps > 0) {                                   // rare: straight to the gapped list
+                const unsigned k = atomicAdd(&P.counters[2], 1u);
+                if (P.gjobs) {
+                    const bbidx_site sg = ss[s];
+                    bbmsa_job j_;
+                    j_.read_off = rr.bases_off + (sg.strand ? P.minus_delta : 0);
+                    j_.ref_off = P.chromOff[sg.chrom];
+                    j_.read_len = len; j_.ref_len = P.chromLen[sg.chrom];
+                    j_.refStartLoc = sg.start - P.pad; j_.refEndLoc = sg.stop + P.pad;
+                    j_.minScore = max(sw, minMsaLimit);
+                    j_.flags = BBMSA_FILL_AND_SCORE_LIMITED | BBMSA_DO_TRACEBACK;
+                    P.gjobs[k] = j_;
+                    bbmsa_gaps gg;
+                    gg.ngaps = sg.ngaps;
+                    for (int q = 0; q < BBMSA_MAX_GAPS; q++) gg.gaps[q] = q < sg.ngaps ? sg.gaps[q] : 0;
+                    P.ggaps[k] = gg;
+                    P.gjobSrc[k] = (int)(r * (long long)P.maxSites + s);
+                }
+            }
             const u64 W = __ballot(want);
             const int nw = popc(W);
             if (npend + nw > SEL_CAP) flush();
@@ -204,9 +225,9 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
     // make this wave's site updates visible to its own flush (same wave, program order) and write the jobs out
     __threadfence_block();
     flush();
-    if (lane == 0) { atomicAdd(&blockCnt[0], cDone); atomicAdd(&blockCnt[1], cGap); atomicAdd(&blockCnt[2], cNoSite); }
+    if (lane == 0) { atomicAdd(&blockCnt[0], cDone); atomicAdd(&blockCnt[1], cNoSite); }
     __syncthreads();
-    if (threadIdx.x < 3 && blockCnt[threadIdx.x]) atomicAdd(&P.counters[1 + threadIdx.x], blockCnt[threadIdx.x]);
+    if (threadIdx.x < 2 && blockCnt[threadIdx.x]) atomicAdd(&P.counters[threadIdx.x == 0 ? 1 : 3], blockCnt[threadIdx.x]);
 }
 
 }  // namespace bbpipe
@@ -228,7 +249,8 @@ extern "C" int bbpipe_select_jobs_device(void *stream_, int64_t n_reads, const b
                                          int64_t minus_delta, const int32_t *nsites, bbidx_site *sites, int32_t max_sites,
                                          const int64_t *chrom_off, const int32_t *chrom_len, const uint8_t *refs,
                                          int32_t pad, int32_t max_columns, float min_ratio,
-                                         bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score) {
+                                         bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score,
+                                         bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src) {
     if (n_reads < 0 || max_sites < 1 || pad < 0 || max_columns < 1) { bbmap_set_error("bbpipe_select_jobs_device: bad size"); return BBMAP_E_ARG; }
     if (n_reads == 0) return BBMAP_OK;
     if (!reads || !bases || !nsites || !sites || !chrom_off || !chrom_len || !refs || !jobs || !job_src || !counters) {
@@ -241,6 +263,10 @@ extern "C" int bbpipe_select_jobs_device(void *stream_, int64_t n_reads, const b
     P.chromOff = (const long long *)chrom_off; P.chromLen = chrom_len; P.refs = refs; P.nreads = n_reads;
     P.pad = pad; P.maxColumns = max_columns; P.minRatio = min_ratio; P.jobs = jobs; P.jobSrc = job_src; P.counters = counters;
     P.noIndelScore = no_indel_score;
+    if ((gapped_jobs != nullptr) != (gapped_gaps != nullptr) || (gapped_jobs != nullptr) != (gapped_src != nullptr)) {
+        bbmap_set_error("bbpipe_select_jobs_device: the three gapped-list buffers go together"); return BBMAP_E_ARG;
+    }
+    P.gjobs = gapped_jobs; P.ggaps = gapped_gaps; P.gjobSrc = gapped_src;
     const long long per_block = bbpipe::SEL_WAVES * bbpipe::SEL_READS_PER_WAVE;
     const long long blocks = (n_reads + per_block - 1) / per_block;
     hipLaunchKernelGGL(bbpipe::select_jobs_kernel, dim3((unsigned)blocks), dim3(64 * bbpipe::SEL_WAVES), 0, stream, P);

@@ -26,7 +26,9 @@ JOB_DTYPE = np.dtype([("read_off", "<i8"), ("ref_off", "<i8"), ("read_len", "<i4
 RESULT_DTYPE = np.dtype([("result", "<i4", (5,)), ("status", "<i4"), ("iterations", "<i8"),
                          ("score", "<i4", (8,)), ("score_len", "<i4"), ("match_len", "<i4"),
                          ("fill_kind", "<i4"), ("columns", "<i4")])
+GAPS_DTYPE = np.dtype([("ngaps", "<i4"), ("gaps", "<i4", (16,))])
 assert JOB_DTYPE.itemsize == C.sizeof(bbmsa_job) and RESULT_DTYPE.itemsize == C.sizeof(bbmsa_result)
+assert GAPS_DTYPE.itemsize == 68
 
 
 class MSAContext:
@@ -68,6 +70,21 @@ class MSAContext:
                                       refs.ctypes.data, refs.size, res.ctypes.data,
                                       match.ctypes.data if match is not None else None, match_stride)
         _lib.check(rc, "bbmsa_align_batch")
+        return res, match
+
+    def align_gapped_batch(self, jobs, gaps, reads, refs, match_stride=0):
+        """Like align_batch, with one GAPS_DTYPE record per job (ngaps == 0: an ordinary job)."""
+        jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+        gaps = np.ascontiguousarray(gaps, dtype=GAPS_DTYPE)
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        refs = np.ascontiguousarray(refs, dtype=np.uint8)
+        n = len(jobs)
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        match = np.zeros((n, match_stride), np.uint8) if match_stride > 0 else None
+        rc = self.L.bbmsa_align_gapped_batch(self.h, n, jobs.ctypes.data, gaps.ctypes.data, reads.ctypes.data, reads.size,
+                                             refs.ctypes.data, refs.size, res.ctypes.data,
+                                             match.ctypes.data if match is not None else None, match_stride)
+        _lib.check(rc, "bbmsa_align_gapped_batch")
         return res, match
 
     # -- device buffers (torch tensors or raw pointers) --------------------------------------
@@ -159,4 +176,24 @@ class MultiStateAligner11ts:
                         "iterations": int(r["iterations"]),
                         "score": None if r["score_len"] == 0 else r["score"][:r["score_len"]].tolist(),
                         "match": ms, "fill_kind": int(r["fill_kind"]), "columns": int(r["columns"])})
+        return out
+
+    # MSA.fillAndScoreLimited(read, ref, start, stop, minScore, gaps) + traceback(..., gapped) in one launch;
+    # problems: (read, ref, refStartLoc, refEndLoc, minScore, gaps or None)
+    def alignGapped(self, problems, traceback=True):
+        problems = list(problems)
+        flags = FILL_AND_SCORE_LIMITED | (DO_TRACEBACK if traceback else 0)
+        jobs, reads, refs = pack_problems([p[:5] for p in problems], flags)
+        gaps = np.zeros(len(problems), GAPS_DTYPE)
+        for k, p in enumerate(problems):
+            if p[5] is not None:
+                gaps[k]["ngaps"] = len(p[5])
+                gaps[k]["gaps"][:len(p[5])] = p[5]
+        stride = ((self.maxRows + self.maxColumns + 2 + 128 * 24 + 15) // 16) * 16
+        res, match = self.ctx.align_gapped_batch(jobs, gaps, reads, refs, stride)
+        out = []
+        for k, r in enumerate(res):
+            out.append({"status": int(r["status"]), "result": r["result"].tolist(),
+                        "score": None if r["score_len"] == 0 else r["score"][:r["score_len"]].tolist(),
+                        "match": match[k, :r["match_len"]].tobytes() if r["match_len"] > 0 else None})
         return out

@@ -54,6 +54,18 @@ class MapPipeline:
         self.match_stride = ((max_rows + max_columns + 15) // 16) * 16
         self.results = torch.zeros(cap * M.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
         self.match = torch.zeros(cap * self.match_stride, dtype=torch.uint8, device=self.dev)
+        # second job list: sites whose index hit spans a long deletion (gap arrays) align against a gapped reference
+        # (makeGref) that can be much wider than an ordinary window, so they get their own, wider MSA context
+        self.gap_cap = max(1024, n_reads // 16)
+        self.gap_columns = max(1024, max_columns)
+        self.msa_gapped = None
+        self.gjobs = torch.zeros(self.gap_cap * M.JOB_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
+        self.ggaps = torch.zeros(self.gap_cap * M.GAPS_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
+        self.gjob_src = torch.zeros(self.gap_cap, dtype=torch.int32, device=self.dev)
+        self.gmatch_stride = ((max_rows + self.gap_columns + 2 + 128 * 8 + 15) // 16) * 16
+        self.gresults = torch.zeros(self.gap_cap * M.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
+        self.gmatch = torch.zeros(self.gap_cap * self.gmatch_stride, dtype=torch.uint8, device=self.dev)
+        self.max_rows = max_rows
         self.last_counters = None
         self.last_ms = {}
 
@@ -75,13 +87,24 @@ class MapPipeline:
                                                self.nsites.data_ptr(), self.sites.data_ptr(), self.max_sites,
                                                self.chrom_off.data_ptr(), self.chrom_len.data_ptr(), self.refs.data_ptr(),
                                                self.pad, self.max_columns, self.min_ratio, self.jobs.data_ptr(),
-                                               self.job_src.data_ptr(), self.counters.data_ptr(), self.no_indel.data_ptr()),
+                                               self.job_src.data_ptr(), self.counters.data_ptr(), self.no_indel.data_ptr(),
+                                               self.gjobs.data_ptr(), self.ggaps.data_ptr(), self.gjob_src.data_ptr()),
                    "bbpipe_select_jobs_device")
         cnt = self.counters.cpu().numpy()                     # the one host round trip: how many DP jobs
         njobs = int(cnt[0])
         if njobs:
             self.msa.align_batch_device(njobs, self.jobs.data_ptr(), plus, self.refs.data_ptr(), self.results.data_ptr(),
                                         self.match.data_ptr(), self.match_stride, stream)
+        ngap = int(cnt[2])
+        if ngap > self.gap_cap:
+            raise RuntimeError("more gapped sites (%d) than the pipeline's gapped-job capacity (%d)" % (ngap, self.gap_cap))
+        if ngap:
+            if self.msa_gapped is None:
+                self.msa_gapped = M.MSAContext(maxRows=self.max_rows, maxColumns=self.gap_columns, device=self.dev.index or 0)
+            rc = L.bbmsa_align_gapped_batch_device(self.msa_gapped.h, C.c_void_p(stream), ngap, self.gjobs.data_ptr(),
+                                                   self.ggaps.data_ptr(), plus, self.refs.data_ptr(), self.gresults.data_ptr(),
+                                                   self.gmatch.data_ptr(), self.gmatch_stride)
+            _lib.check(rc, "bbmsa_align_gapped_batch_device")
         self.last_counters = cnt
         return njobs
 
@@ -101,4 +124,11 @@ class MapPipeline:
         res = self.results[: njobs * M.RESULT_DTYPE.itemsize].cpu().numpy().view(M.RESULT_DTYPE)
         match = self.match[: njobs * self.match_stride].cpu().numpy().reshape(njobs, self.match_stride)
         no_indel = self.no_indel.cpu().numpy().reshape(self.n, self.max_sites)
-        return dict(sites=sites, nsites=nsites, jobs=jobs, src=src, results=res, match=match, no_indel=no_indel)
+        ngap = int(self.last_counters[2])
+        gjobs = self.gjobs[: ngap * M.JOB_DTYPE.itemsize].cpu().numpy().view(M.JOB_DTYPE)
+        ggaps = self.ggaps[: ngap * M.GAPS_DTYPE.itemsize].cpu().numpy().view(M.GAPS_DTYPE)
+        gsrc = self.gjob_src[:ngap].cpu().numpy()
+        gres = self.gresults[: ngap * M.RESULT_DTYPE.itemsize].cpu().numpy().view(M.RESULT_DTYPE)
+        gmatch = self.gmatch[: ngap * self.gmatch_stride].cpu().numpy().reshape(ngap, self.gmatch_stride)
+        return dict(sites=sites, nsites=nsites, jobs=jobs, src=src, results=res, match=match, no_indel=no_indel,
+                    gjobs=gjobs, ggaps=ggaps, gsrc=gsrc, gresults=gres, gmatch=gmatch)

@@ -29,12 +29,13 @@ def make_reference(length, seed, pad=START_PAD):
 
 def make_reads_and_jobs(ref, n_reads, read_len=150, seed=2, pad=START_PAD, align_pad=4,
                         min_ratio=0.56, perfect_frac=0.5, flags=FILL_AND_SCORE_LIMITED | DO_TRACEBACK,
-                        chunk=131072, max_del=40, max_ins=12):
+                        chunk=131072, max_del=40, max_ins=12, long_del_frac=0.0, long_del=(300, 800)):
     """Returns (reads_blob uint8[n*read_len... variable], jobs structured array, truth dict)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     n = n_reads
     body = len(ref) - 2 * pad
-    start = rng.integers(pad, pad + body - read_len - max_del - 8, size=n, dtype=np.int64)
+    reach = max(max_del, long_del[1] if long_del_frac > 0 else 0)
+    start = rng.integers(pad, pad + body - read_len - reach - 8, size=n, dtype=np.int64)
     imperfect = rng.random(n) >= perfect_frac
     # event draws (only applied to imperfect reads)
     n_snp = np.where(imperfect & (rng.random(n) < 0.4), rng.integers(1, 4, size=n), 0)
@@ -43,6 +44,9 @@ def make_reads_and_jobs(ref, n_reads, read_len=150, seed=2, pad=START_PAD, align
     has_n = imperfect & (rng.random(n) < 0.2)
     # geometric-ish indel lengths, short ones most common
     del_len = np.where(has_del, np.minimum(max_del, rng.geometric(0.25, size=n)), 0).astype(np.int64)
+    if long_del_frac > 0:                        # long deletions (sh/randomreads.sh maxdellen): the probe reports gap arrays
+        is_long = has_del & (rng.random(n) < long_del_frac)
+        del_len = np.where(is_long, rng.integers(long_del[0], long_del[1] + 1, size=n), del_len).astype(np.int64)
     ins_len = np.where(has_ins, np.minimum(max_ins, rng.geometric(0.4, size=n)), 0).astype(np.int64)
     ev_pos = rng.integers(10, read_len - 10 - max_ins, size=n, dtype=np.int64)
 

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define BBMAP_AMD_ABI_VERSION 1
+#define BBMAP_AMD_ABI_VERSION 2
 
 enum {
     BBMAP_OK = 0,
@@ -51,7 +51,8 @@ enum {
     BBMSA_MODE_MASK          = 7,
     BBMSA_CLAMP_WINDOW = 1 << 3,  /* a=max(0,start), b=min(ref_len-1,end), MSA.java:104-105,118-121 */
     BBMSA_DO_SCORE     = 1 << 4,  /* run score2 on a non-null fill                                  */
-    BBMSA_DO_TRACEBACK = 1 << 5   /* run traceback2 on a non-null fill, write the match string      */
+    BBMSA_DO_TRACEBACK = 1 << 5,  /* run traceback2 on a non-null fill, write the match string      */
+    BBMSA_INTERNAL_GAPPED = 1 << 8 /* set by the library on the jobs it derives for gapped references; never by callers */
 };
 /* the composite the mapper calls most: MSA.fillAndScoreLimited(read, ref, start, stop, minScore, null) */
 #define BBMSA_FILL_AND_SCORE_LIMITED (BBMSA_FILL_LIMITED | BBMSA_CLAMP_WINDOW | BBMSA_DO_SCORE)
@@ -112,6 +113,24 @@ int bbmsa_align_batch(bbmsa_ctx *ctx, int64_t n_jobs, const bbmsa_job *jobs,
                       const uint8_t *reads, int64_t reads_bytes,
                       const uint8_t *refs, int64_t refs_bytes,
                       bbmsa_result *results, uint8_t *match, int32_t match_stride);
+
+/* Gapped reference windows: job i is MSA.fillAndScoreLimited(read, ref, refStartLoc, refEndLoc, minScore, gaps)
+ * (current/align2/MSA.java:103-134) for a SiteScore that carries a gap array.  When gaps[i].ngaps > 0 the library
+ * builds the gapped reference (MultiStateAligner11tsJNI.makeGref, current/align2/MultiStateAligner11tsJNI.java:
+ * 668-757: long gaps shrink to 64+rem bases, GAPC symbols, 64 bases), fills it as fillLimited(..., gaps) does
+ * (:116-128), runs score(..., gapped=true) / traceback(..., gapped=true) (:362-372, :499-531) and translates
+ * score[1], score[2] back to reference coordinates (:759-779).  Jobs with ngaps == 0 behave exactly as in
+ * bbmsa_align_batch_device.  For gapped jobs the mode bits of job.flags are ignored (always the Java fillLimited
+ * + window clamp + score); BBMSA_DO_TRACEBACK is honoured.  The reference asserts gstart == 0 (:514); a job that
+ * would break that, or whose gapped reference exceeds maxColumns + 2 bytes, gets BBMSA_ST_BAD_SHAPE. */
+#define BBMSA_MAX_GAPS 16
+typedef struct bbmsa_gaps { int32_t ngaps; int32_t gaps[BBMSA_MAX_GAPS]; } bbmsa_gaps;   /* 68 bytes */
+int bbmsa_align_gapped_batch_device(bbmsa_ctx *ctx, void *stream, int64_t n_jobs, const bbmsa_job *jobs,
+                                    const bbmsa_gaps *gaps, const uint8_t *reads, const uint8_t *refs,
+                                    bbmsa_result *results, uint8_t *match, int32_t match_stride);
+int bbmsa_align_gapped_batch(bbmsa_ctx *ctx, int64_t n_jobs, const bbmsa_job *jobs, const bbmsa_gaps *gaps,
+                             const uint8_t *reads, int64_t reads_bytes, const uint8_t *refs, int64_t refs_bytes,
+                             bbmsa_result *results, uint8_t *match, int32_t match_stride);
 
 /* Timing of the last bbmsa_align_batch_device launch sequence on this context, measured with
  * HIP events on the launch stream.  Valid after the stream has been synchronised. */
@@ -257,14 +276,17 @@ int bbpipe_revcomp_device(void *stream, int64_t n_reads, const bbidx_read *reads
                           const uint8_t *bases_in, uint8_t *bases_out);
 /* Scores every probe site without indels (MSA.scoreNoIndels), updates the site records in place, and appends one
  * bbmsa_job per site that still needs DP.  counters[4] (zeroed by the call): jobs written, reads finished without
- * DP, sites skipped because they carry a gap array, reads with no site.  `bases + minus_delta` must hold the
+ * DP, sites that carry a gap array, reads with no site.  `bases + minus_delta` must hold the
  * reverse-complemented reads at the same offsets.  no_indel_score (optional) receives the ungapped score of every
- * (read, site). */
+ * (read, site).  Sites with a gap array need a gapped reference: they are written to the second list
+ * (gapped_jobs / gapped_gaps / gapped_src, for bbmsa_align_gapped_batch_device) when it is given, and only counted
+ * when it is NULL. */
 int bbpipe_select_jobs_device(void *stream, int64_t n_reads, const bbidx_read *reads, const uint8_t *bases,
                               int64_t minus_delta, const int32_t *nsites, bbidx_site *sites, int32_t max_sites,
                               const int64_t *chrom_off, const int32_t *chrom_len, const uint8_t *refs,
                               int32_t pad, int32_t max_columns, float min_ratio,
-                              bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score);
+                              bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score,
+                              bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src);
 
 #ifdef __cplusplus
 }

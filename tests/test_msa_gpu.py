@@ -171,3 +171,49 @@ def test_full_size_batch_properties():
     # idempotence: a second pass gives identical records
     got2 = al.align(probs, ALL)
     assert got == got2
+
+
+def test_gapped_reference_jobs():
+    """fillAndScoreLimited(..., gaps) + traceback(gapped=True): makeGref on the device, fill on the gapped reference,
+    coordinates translated back (MultiStateAligner11tsJNI.java:116-128, :362-372, :499-531, :668-801)."""
+    import random
+    from oracle.oracle import OracleMSA
+    rng = random.Random(77)
+    ref = bytes(rng.choice(b"ACGT") for _ in range(6000))
+    probs = []
+    for i in range(60):
+        L = rng.choice([100, 150, 150, 200])
+        st = rng.randrange(200, 2000)
+        cut = rng.randrange(30, L - 30)
+        dl = rng.choice([300, 400, 700, 1500, 2600])          # long deletion: the read skips `dl` reference bases
+        rd = bytearray(ref[st:st + cut] + ref[st + cut + dl: st + dl + L])
+        for _ in range(rng.randint(0, 3)):
+            rd[rng.randrange(L)] = rng.choice(b"ACGT")
+        if i % 7 == 3:
+            del rd[10:12]                                      # plus a short deletion near the start
+        stop = st + dl + L - 1
+        # gap array as BBIndex.makeGapArray produces it: {start, end of first block, start of second block, stop}
+        gaps = [st, st + cut - 1 + rng.randint(0, 3), st + cut + dl - rng.randint(0, 3), stop]
+        if i % 5 == 4:                                         # three blocks
+            mid = st + cut + dl + 20
+            if stop - mid > 400:
+                gaps = gaps[:3] + [mid, stop - 20, stop]
+                gaps[4] = max(gaps[4], gaps[3] + 300)
+                if gaps[4] >= stop:
+                    gaps = gaps[:3] + [stop]
+        ms = int(rng.choice([0.3, 0.5, 0.56]) * (70 + 100 * (len(rd) - 1)))
+        probs.append((bytes(rd), ref, st - 4, stop + 4, ms, gaps))
+    probs.append((probs[0][0], ref, probs[0][2], probs[0][3], probs[0][4], None))     # an ungapped job in the same batch
+    al = M.MultiStateAligner11ts(maxRows=224, maxColumns=1600)
+    got = al.alignGapped(probs)
+    om = OracleMSA(224, 1600)
+    nonnull = 0
+    for p, g in zip(probs, got):
+        sv, mx = om.fillAndScoreLimited(p[0], p[1], p[2], p[3], p[4], p[5])
+        assert g["status"] != M.ST_BAD_SHAPE
+        assert g["score"] == sv, (p[2:], g, sv)
+        if sv is not None:
+            nonnull += 1
+            tb = om.traceback(p[0], p[1], max(0, p[2]), min(len(p[1]) - 1, p[3]), mx[0], mx[1], mx[2], gapped=p[5] is not None)
+            assert g["match"] == tb
+    assert nonnull > 30

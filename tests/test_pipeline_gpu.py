@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def test_pipeline_matches_emulation():
     k, L, n = 12, 150, 3000
     ref = W.make_reference(300000, seed=5, pad=2000)
-    reads, _, truth = W.make_reads_and_jobs(ref, n, read_len=L, seed=9, pad=2000)
+    reads, _, truth = W.make_reads_and_jobs(ref, n, read_len=L, seed=9, pad=2000, long_del_frac=0.4)
     hi = HostIndex([ref], k=k)
     offs = make_offsets(L, k, 1.9)
     ks = [100 * k] * len(offs)
@@ -36,7 +36,10 @@ def test_pipeline_matches_emulation():
     minMsaLimit = -258 + int(np.float32(0.56) * np.float32(maxSw))
     by_src = {int(s): i for i, s in enumerate(out["src"])}
     assert len(by_src) == njobs
-    checked_jobs = 0
+    by_gsrc = {int(s): i for i, s in enumerate(out["gsrc"])}
+    assert len(by_gsrc) == cnt[2]
+    omg = OracleMSA(160, 1024)
+    checked_jobs = checked_gapped = 0
     for r in range(600):
         bp = reads[r * L:(r + 1) * L].tobytes()
         bm = revcomp(bp)
@@ -63,8 +66,28 @@ def test_pipeline_matches_emulation():
         for s, e in enumerate(exp_sites):
             src = r * 8 + s
             semip = bool(out["sites"][r, s]["semiperfect"])
-            needs = num_near < 1 and sws[s] < maxImp and not semip and not e["gaps"]
+            gapped_now = bool(e["gaps"]) and sws[s] < maxImp        # a near-perfect ungapped score drops the gap array
+            needs_any = num_near < 1 and sws[s] < maxImp and not semip
+            needs = needs_any and not gapped_now
             assert (src in by_src) == needs, (r, s, e, sws[s], num_near)
+            assert (src in by_gsrc) == (needs_any and gapped_now), (r, s, e, sws[s], num_near)
+            if needs_any and gapped_now:
+                i = by_gsrc[src]
+                j = out["gjobs"][i]
+                gg = out["ggaps"][i]
+                assert gg["gaps"][: gg["ngaps"]].tolist() == e["gaps"]
+                assert (int(j["refStartLoc"]), int(j["refEndLoc"])) == (e["start"] - 4, e["stop"] + 4)
+                bases = bm if e["strand"] else bp
+                sv, mx = omg.fillAndScoreLimited(bases, refb, int(j["refStartLoc"]), int(j["refEndLoc"]), int(j["minScore"]), e["gaps"])
+                res = out["gresults"][i]
+                assert int(res["status"]) != 2
+                gs = None if res["score_len"] == 0 else res["score"][: res["score_len"]].tolist()
+                assert gs == sv
+                if sv is not None:
+                    tb = omg.traceback(bases, refb, max(0, int(j["refStartLoc"])), min(len(refb) - 1, int(j["refEndLoc"])),
+                                       mx[0], mx[1], mx[2], gapped=True)
+                    assert out["gmatch"][i, : res["match_len"]].tobytes() == tb
+                checked_gapped += 1
             if needs:
                 i = by_src[src]
                 j = out["jobs"][i]
@@ -81,3 +104,4 @@ def test_pipeline_matches_emulation():
                     assert out["match"][i, : res["match_len"]].tobytes() == tb
                 checked_jobs += 1
     assert checked_jobs > 20
+    assert cnt[2] > 0 and checked_gapped > 0
