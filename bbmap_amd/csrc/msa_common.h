@@ -64,6 +64,8 @@ struct FillParams {
     unsigned int *queue;          // work-queue head (zeroed before launch)
     unsigned int *dirbuf;         // traceback direction nibbles, one slot per resident job
     long long dir_slot_dwords;
+    const int *list;              // job indices to process (NULL = all njobs), filled by the narrow kernel
+    const unsigned int *list_count;
     int *slow_list;               // jobs the fast kernel hands to the generic kernel
     unsigned int *slow_count;
     int match_stride;
@@ -73,6 +75,26 @@ struct FillParams {
     int maxRows, maxColumns;      // context limits (MSA(maxRows_, maxColumns_))
     int bandwidth;
     float bandwidthRatio;
+};
+
+// one job per lane, a band of diagonals in registers (msa_fill_narrow.hip)
+struct NarrowParams {
+    const bbmsa_job *jobs;
+    const uint8_t *reads;
+    const uint8_t *refs;
+    bbmsa_result *results;
+    uint8_t *match;
+    long long njobs;
+    unsigned int *queue;          // work-queue head (zeroed before launch)
+    int *fast_list;               // jobs left to the wavefront kernel
+    unsigned int *fast_count;
+    unsigned long long *dirbuf;   // per resident wave: (maxRows + 1) x 64 lanes x 8 bytes of direction nibbles
+    unsigned int *stats;          // [0] jobs finished here, [1] candidates that left the band (handed on)
+    int match_stride;
+    int maxRows, maxColumns;
+    int bandwidth;
+    float bandwidthRatio;
+    int maxSlack;                 // candidate filter: maxQuality(rows) - minScore (points) at most this
 };
 
 struct GenericParams {

@@ -19,6 +19,11 @@ struct bbmsa_ctx {
     int genThreads;
     int *d_matrix;
     int *d_limits;
+    // narrow-window kernel (msa_fill_narrow.hip): one job per lane
+    int narrowBlocks, narrowSlack;     // 0 blocks = disabled
+    unsigned long long *d_narrowDir;
+    int *d_fastList;
+    long long fastCap;
     // gapped-reference scratch (msa_gapped.hip), grown on demand
     uint8_t *d_gref;
     int *d_gaux;

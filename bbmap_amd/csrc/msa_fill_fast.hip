@@ -97,13 +97,15 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
     const long long slot = ((long long)blockIdx.x * (blockDim.x >> 6) + wave) * jobsPerWave + sub;
     unsigned *dir = p.dirbuf + slot * p.dir_slot_dwords;
 
+    const long long total = p.list ? (long long)load_coherent(p.list_count) : p.njobs;
     for (;;) {
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(p.queue, (unsigned)jobsPerWave);
         base = __builtin_amdgcn_readfirstlane(base);
-        if ((long long)base >= p.njobs) break;
-        const long long j = (long long)base + sub;
-        const bool valid = j < p.njobs;
+        if ((long long)base >= total) break;
+        const long long q = (long long)base + sub;
+        const bool valid = q < total;
+        const long long j = (p.list && valid) ? (long long)p.list[q] : q;
 
         // ------------------------------------------------------------------ job setup
         bbmsa_job jb;

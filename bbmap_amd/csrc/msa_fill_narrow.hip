@@ -1,0 +1,410 @@
+// Narrow-window path of the MultiStateAligner11ts DP for gfx950: ONE JOB PER LANE, a band of B diagonals in registers.
+//
+// Why: fillLimitedX (jni/MultiStateAligner11tsJNI.c:361-704) only visits the columns of a row between the first
+// "good" column of the row above and one past the last good one.  When minScore is close to the best possible score
+// (a read with a few substitutions: the slow-align gate passes max(ungapped score, minMsaLimit) as minScore,
+// current/align2/BBMapThread.java:289-309) that window is 3-8 columns wide and follows the main diagonal; a third of
+// the jobs of the bench workload visit < 5 % of their rows x columns rectangle.  The wavefront kernel
+// (msa_fill_fast.hip) sweeps the whole rectangle in lock step whatever the window is; this kernel only walks a band
+// of B = 16 diagonals around the window:
+//   * position i of the band at row r is column r + D0 + i; the three planes of the band live in 3 x B registers,
+//     updated in place left to right (cell i needs old[i] = diagonal, old[i+1] = up, new[i-1] = left);
+//   * all 64 lanes (64 different jobs) run the same fully unrolled row step, so there is no divergence and no LDS;
+//   * a position outside the row's real window is "unvisited" and reads as subfloor, exactly what the reference's
+//     sentinels make it (consequence 1);
+//   * row 1 visits every column (its window is [1, columns], :441-449): the columns outside the band are evaluated
+//     too; row 1 has no left dependency (deletions are barred in rows < 3);
+//   * the moment a job's window touches the edge of the band (or the job has an undefined reference base, which
+//     the closed-form horizLimit below does not cover) the job is handed to the wavefront kernel through
+//     `fast_list`; nothing approximate is ever returned;
+//   * per cell the same 4-bit traceback record as the wavefront kernel, 64 bits per row, stored coalesced
+//     (row-major, lane-minor); traceback2 / score2 then run per lane on the records.
+// vertLimit is carried incrementally (suffix sums shrink by one base cost per row), horizLimit has the closed form
+// minScore - (MATCH + (columns-1-col) * MATCH2) when every reference base of the window is defined (:413-438).
+#include "msa_common.h"
+
+namespace bbmsa {
+
+namespace {
+
+constexpr int NB = 16;      // band width in diagonals
+
+__device__ inline int ctime_n(int t) { return t > kMaxTime ? kMaxTime - 3 : t; }
+__device__ inline int del_step_n(int streak) {
+    if (streak == 0) return P_DEL;
+    if (streak < 5) return P_DEL2;
+    if (streak < 20) return P_DEL3;
+    if (streak < 80) return P_DEL4;
+    return (streak & 3) == 0 ? P_DEL5 : 0;
+}
+__device__ inline int ins_step_n(int streak) {
+    if (streak == 0) return P_INS;
+    if (streak < 5) return P_INS2;
+    if (streak < 20) return P_INS3;
+    return P_INS4;
+}
+__device__ inline int sub_step_n(int streak) {
+    if (streak == 0) return P_SUB;
+    if (streak < 5) return P_SUB2;
+    return P_SUB3;
+}
+
+struct CellOut { int M, D, I; bool good; unsigned nib; };
+
+// One limited-fill cell, jni/MultiStateAligner11tsJNI.c:458-658, on packed predecessor values.
+// dM,dD,dI = (row-1,col-1); lM,lD = (row,col-1); uM,uI = (row-1,col).
+__device__ inline CellOut cell_eval(int row, int col, int rows, int columns, int call0, int call1, int ref0, int ref1,
+                                    int vlimit, int hlimit, int floorv, int subfloor,
+                                    int dM, int dD, int dI, int lM, int lD, int uM, int uI) {
+    CellOut o;
+    const bool gap = ref1 == '-';
+    const bool match = (call1 == ref1) && ref1 != 'N';
+    const bool prevMatch = (call0 == ref0) && ref0 != 'N';
+    const int limit = max(vlimit, hlimit);
+    const int limit3 = max(floorv, match ? limit - P_MATCH2 : limit - P_SUB3);
+    const int delNeeded = max(0, row - col - 1);
+    const int insNeeded = max(0, (rows - row) - (columns - col) - 1);
+    const int delPen = calc_del_off(delNeeded);
+    const int insPen = calc_ins_cum_off(insNeeded);
+    bool anyGood = false;
+    const int dm = dM & kScoreMask, dd = dD & kScoreMask, di = dI & kScoreMask;
+    const int lm = lM & kScoreMask, ld = lD & kScoreMask;
+    const int um = uM & kScoreMask, ui = uI & kScoreMask;
+
+    int timeM = 0;
+    if (gap || (dm <= limit3 && dd <= limit3 && di <= limit3)) {
+        o.M = subfloor;
+    } else {
+        const int streak = dM & kTimeMask;
+        int a, bonus, tA;
+        if (match) { a = dm + (prevMatch ? P_MATCH2 : P_MATCH); bonus = P_MATCH; tA = prevMatch ? streak + 1 : 1; }
+        else {
+            if (ref1 != 'N' && call1 != 'N') a = dm + (prevMatch ? (streak <= 1 ? P_SUBR : P_SUB) : sub_step_n(streak));
+            else a = dm;
+            bonus = P_SUB; tA = prevMatch ? 1 : streak + 1;
+        }
+        const int bb = dd + bonus, cc = di + bonus;
+        int score, time;
+        if (a >= bb && a >= cc) { score = a; time = tA; }
+        else if (bb >= cc) { score = bb; time = 1; }
+        else { score = cc; time = 1; }
+        const int limit2 = delNeeded > 0 ? limit - delPen : (insNeeded > 0 ? limit - insPen : limit);
+        if (score >= limit2) anyGood = true; else score = subfloor;
+        timeM = time;
+        o.M = score | ctime_n(time);
+    }
+    bool aWinsD = true;
+    if ((lm <= limit && ld <= limit) || row < 3 || row > rows - 3) {
+        o.D = subfloor;
+    } else {
+        const int streak = lD & kTimeMask;
+        int a = lm + P_DEL, bsc = ld + del_step_n(streak);
+        if (ref1 == 'N') { a += P_DEL_REF_N; bsc += P_DEL_REF_N; }
+        else if (gap) { a += P_GAP; bsc += P_GAP; }
+        int score, time;
+        if (a >= bsc) { score = a; time = 1; } else { score = bsc; time = streak + 1; aWinsD = false; }
+        int limit2 = limit;
+        if (insNeeded > 0) limit2 = limit - insPen;
+        else if (delNeeded > 0) limit2 = limit - calc_del_off(time + delNeeded) + calc_del_off(time);
+        if (score >= limit2) anyGood = true; else score = subfloor;
+        o.D = score | ctime_n(time);
+    }
+    bool aWinsI = true;
+    if (gap || (um <= limit && ui <= limit) || (row < 2 && col > 1) || (row > rows - 2 && col < columns - 1)) {
+        o.I = subfloor;
+    } else {
+        const int streak = uI & kTimeMask;
+        const int a = um + P_INS, bsc = ui + ins_step_n(streak);
+        int score, time;
+        if (a >= bsc) { score = a; time = 1; } else { score = bsc; time = streak + 1; aWinsI = false; }
+        int limit2 = limit;
+        if (delNeeded > 0) limit2 = limit - delPen;
+        else if (insNeeded > 0) limit2 = limit - calc_ins_cum_off(time + insNeeded) + calc_ins_cum_off(time);
+        if (score >= limit2) anyGood = true; else score = subfloor;
+        o.I = score | ctime_n(time);
+    }
+    // what traceback2 would decide at this cell (MultiStateAligner11tsJNI.java:389-443); see msa_fill_fast.hip
+    const bool msStay = (timeM > 1) || (dm >= max(dd, di));
+    const unsigned nibM = msStay ? 0u : ((dd >= di) ? 1u : 2u);
+    o.nib = nibM | (aWinsD ? 0u : 4u) | (aWinsI ? 0u : 8u);
+    o.good = anyGood;
+    return o;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void msa_fill_narrow_kernel(const NarrowParams p) {
+    const int lane = threadIdx.x;
+    unsigned long long *dirw = p.dirbuf + (long long)blockIdx.x * (long long)(p.maxRows + 1) * 64;
+    const bool ctxBanded = !(p.bandwidth < 1 && p.bandwidthRatio <= 0.0f);
+    unsigned nDone = 0, nLeft = 0;
+
+    for (;;) {
+        // ------------------------------------------------------------------ one candidate job per lane
+        long long j = -1;
+        bbmsa_job jb;
+        jb.read_off = 0; jb.ref_off = 0; jb.read_len = 0; jb.ref_len = 0; jb.refStartLoc = 0; jb.refEndLoc = -1; jb.minScore = 0; jb.flags = 0;
+        int rows = 0, a = 0, b = -1, columns = 0, minScore = 0, mode = 0;
+        for (;;) {
+            const long long q = (long long)atomicAdd(p.queue, 1u);
+            if (q >= p.njobs) break;
+            const bbmsa_job t = p.jobs[q];
+            int ta = t.refStartLoc, tb = t.refEndLoc;
+            const int tmode = t.flags & BBMSA_MODE_MASK;
+            if (t.flags & BBMSA_CLAMP_WINDOW) {
+                ta = max(0, ta); tb = min(t.ref_len - 1, tb);
+                if (tb - ta >= p.maxColumns) tb = min(t.ref_len - 1, ta + p.maxColumns - 1);
+            }
+            const int trows = t.read_len, tcols = tb - ta + 1;
+            bool cand = !ctxBanded && trows >= NB && tcols >= trows && trows <= p.maxRows && tcols <= p.maxColumns &&
+                        tmode != BBMSA_FILL_UNLIMITED_RAW;
+            int tmin = t.minScore;
+            if (cand && tmode == BBMSA_FILL_LIMITED) {            // the Java gate, MultiStateAligner11tsJNI.java:137-144 (halfband == 0)
+                if (tmin < 1 || (tcols + trows < 90) || (tcols > trows + min(170, trows + 20))) cand = false;
+                else tmin -= 120;
+            }
+            if (cand) cand = (70 + 100 * (trows - 1)) - tmin <= p.maxSlack;
+            if (cand) { j = q; jb = t; rows = trows; a = ta; b = tb; columns = tcols; minScore = tmin; mode = tmode; break; }
+            const unsigned k = atomicAdd(p.fast_count, 1u);
+            p.fast_list[k] = (int)q;
+        }
+        if (!__any(j >= 0)) break;
+        bool active = j >= 0;
+        const uint8_t *rd = p.reads + jb.read_off;
+        const uint8_t *rf = p.refs + jb.ref_off + a;                  // rf[c-1] = reference byte of column c
+        const int D0 = (columns - rows) / 2 - NB / 2;                 // column of band position i at row r: r + D0 + i
+
+        const int maxGain = (rows - 1) * P_MATCH2 + P_MATCH;
+        const int minScoreOff = minScore * 2048;
+        const int floorv = minScoreOff - maxGain;
+        const int subfloor = floorv - 5 * P_MATCH2;
+
+        // pre-scan: every reference base of the window defined (closed-form horizLimit); read's total base cost
+        int vs = 0;                                                   // sum of cost_v(i) for i >= current row
+        if (active) {
+            bool allDef = true;
+            for (int c = 0; c < columns; c++) allDef = allDef && fully_defined(rf[c]);
+            bool nextDef = false;
+            for (int i = rows - 1; i >= 0; i--) {
+                const bool def = fully_defined(rd[i]);
+                vs += def ? (nextDef ? P_MATCH2 : P_MATCH) : 0;
+                nextDef = def;
+            }
+            if (!allDef) { active = false; const unsigned k = atomicAdd(p.fast_count, 1u); p.fast_list[k] = (int)j; nLeft++; }
+        }
+        auto hlimit_at = [&](int col) -> int {
+            const int hs = col <= columns - 1 ? P_MATCH + (columns - 1 - col) * P_MATCH2 : 0;
+            return max(minScoreOff - hs, floorv);
+        };
+
+        int aM[NB + 1], aD[NB + 1], aI[NB + 1];                       // band of row r-1, then of row r (in place)
+#pragma unroll
+        for (int i = 0; i <= NB; i++) { aM[i] = 0; aD[i] = 0; aI[i] = 0; }   // row 0 is all zero
+        long long iters = 0;
+        int prevMin = 1, prevMax = columns;                           // minGoodCol / maxGoodCol of the row above
+        int stoppedRow = INT_MAX;                                     // first row the fill does not enter
+        int lastColStart = 1, lastHasGood = 0;
+        int bestM = 0, bestD = 0, bestI = 0, bestMc = -1, bestDc = -1, bestIc = -1;
+        // sliding window of reference bytes: byte k = column (row + D0 - 1 + k), k = 0..NB+1
+        unsigned long long w0 = 0, w1 = 0, w2 = 0;
+        auto ref_col = [&](int c) -> unsigned { return (active && c >= 1 && c <= columns) ? (unsigned)rf[c - 1] : 0u; };
+        if (active) {
+            for (int k = 0; k < 8; k++) w0 |= (unsigned long long)ref_col(1 + D0 - 1 + k) << (8 * k);
+            for (int k = 0; k < 8; k++) w1 |= (unsigned long long)ref_col(1 + D0 - 1 + 8 + k) << (8 * k);
+            for (int k = 0; k < 2; k++) w2 |= (unsigned long long)ref_col(1 + D0 - 1 + 16 + k) << (8 * k);
+        }
+        int call0 = '?';
+        int maxRowsBatch = active ? rows : 0;
+        for (int d = 32; d >= 1; d >>= 1) maxRowsBatch = max(maxRowsBatch, __shfl_xor(maxRowsBatch, d, 64));
+
+        // ------------------------------------------------------------------ fill, all lanes row by row
+        for (int row = 1; row <= maxRowsBatch; row++) {
+            const bool rowAct = active && row <= rows && stoppedRow == INT_MAX;
+            if (!__any(rowAct)) break;
+            int call1 = 0;
+            bool enter = false;
+            int colStart = 0, colStop = 0, vlimit = 0;
+            if (rowAct) {
+                call1 = rd[row - 1];
+                colStart = prevMin; colStop = prevMax;
+                enter = !(colStart < 0 || colStop < colStart);
+                if (!enter) stoppedRow = row;
+                // vertLimit[row]: suffix cost of the bases from index `row` on
+                const bool def = fully_defined(call1);
+                const bool nextDef = row < rows ? fully_defined(rd[row]) : false;
+                vs -= def ? (nextDef ? P_MATCH2 : P_MATCH) : 0;
+                vlimit = max(minScoreOff - vs, floorv);
+            }
+            const int c0 = row + D0;                                   // column of band position 0
+            bool go = rowAct && enter;
+            if (go && row == 1) {
+                // row 1 visits every column; the ones outside the band must hold no good cell
+                bool outGood = false;
+                for (int c = 1; c <= columns; c++) {
+                    if (c >= c0 && c < c0 + NB) continue;
+                    const int ref1 = rf[c - 1], ref0 = c < 2 ? '!' : rf[c - 2];
+                    const CellOut o = cell_eval(1, c, rows, columns, call0, call1, ref0, ref1, vlimit, hlimit_at(c), floorv, subfloor,
+                                                0, 0, 0, c == 1 ? calc_ins_cum_off(1) : subfloor, c == 1 ? calc_ins_cum_off(1) : subfloor, 0, 0);
+                    outGood = outGood || o.good;
+                }
+                iters += (long long)(columns - max(0, min(columns, c0 + NB - 1) - max(1, c0) + 1));
+                if (outGood) go = false;
+            }
+            if (go && row > 1 && (colStart < c0 || colStart > c0 + NB - 1)) go = false;      // window starts outside the band
+            const bool bailEarly = rowAct && enter && !go;
+            int minGood = -1, maxGood = -2;
+            bool rowDone = false;
+            int leftM = subfloor, leftD = subfloor;
+            if (go && colStart == 1) { leftM = calc_ins_cum_off(row); leftD = leftM; }
+            unsigned long long word = 0;
+            const int insPrev = calc_ins_cum_off(row - 1);
+            const bool lastRow = row == rows;
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                const int c = c0 + i;
+                const bool inRow = go && c >= colStart && c >= 1 && c <= columns && !rowDone;
+                int nM = subfloor, nD = subfloor, nI = subfloor;
+                if (inRow) {
+                    const unsigned rb0 = (unsigned)((i < 8 ? (w0 >> (8 * (i & 7))) : (w1 >> (8 * (i & 7)))) & 255u);
+                    const int k1 = i + 1;
+                    const unsigned rb1 = (unsigned)((k1 < 8 ? (w0 >> (8 * (k1 & 7))) : (k1 < 16 ? (w1 >> (8 * (k1 & 7))) : (w2 >> (8 * (k1 & 7))))) & 255u);
+                    const int ref0 = c < 2 ? '!' : (int)rb0, ref1 = (int)rb1;
+                    // (row-1, c-1): column 0 holds the cumulative insertion cost; (row-1, c): the next band position
+                    const int dM = (c == 1) ? insPrev : aM[i], dD = (c == 1) ? insPrev : aD[i], dI = (c == 1) ? insPrev : aI[i];
+                    const int uM = (i + 1 < NB) ? aM[i + 1] : (row == 1 ? 0 : subfloor);
+                    const int uI = (i + 1 < NB) ? aI[i + 1] : (row == 1 ? 0 : subfloor);
+                    const CellOut o = cell_eval(row, c, rows, columns, call0, call1, ref0, ref1, vlimit, hlimit_at(c), floorv, subfloor,
+                                                dM, dD, dI, leftM, leftD, uM, uI);
+                    nM = o.M; nD = o.D; nI = o.I;
+                    iters++;
+                    if (o.good) { maxGood = c; if (minGood < 0) minGood = c; }
+                    if (c > colStop && maxGood < c) rowDone = true;
+                    word |= (unsigned long long)o.nib << (4 * i);
+                    if (lastRow) {
+                        if (bestMc < 0 || (nM & kScoreMask) > (bestM & kScoreMask)) { bestM = nM; bestMc = c; }
+                        if (bestDc < 0 || (nD & kScoreMask) > (bestD & kScoreMask)) { bestD = nD; bestDc = c; }
+                        if (bestIc < 0 || (nI & kScoreMask) > (bestI & kScoreMask)) { bestI = nI; bestIc = c; }
+                    }
+                    leftM = nM; leftD = nD;
+                }
+                if (rowAct) { aM[i] = nM; aD[i] = nD; aI[i] = nI; }
+            }
+            // the row must have ended inside the band (or at the last column)
+            const bool unfinished = go && row > 1 && !rowDone && (c0 + NB - 1 < columns);
+            if (bailEarly || unfinished) {
+                active = false;
+                const unsigned k = atomicAdd(p.fast_count, 1u);
+                p.fast_list[k] = (int)j;
+                nLeft++;
+            } else if (go) {
+                prevMin = minGood; prevMax = maxGood;
+                dirw[(long long)row * 64 + lane] = word;
+                if (lastRow) { lastColStart = colStart; lastHasGood = minGood >= 0; }
+            }
+            // slide the reference-byte window by one column
+            {
+                const unsigned nb = ref_col(row + 1 + D0 - 1 + NB + 1);
+                w0 = (w0 >> 8) | (w1 << 56);
+                w1 = (w1 >> 8) | (w2 << 56);
+                w2 = (w2 >> 8) | ((unsigned long long)nb << 8);
+            }
+            call0 = call1;
+        }
+
+        // ------------------------------------------------------------------ result[] (jni/...c:672-703)
+        int bScore = INT_MIN, bCol = -1, bState = 0, bPacked = 0;
+        if (bestMc >= 0) { bScore = bestM & kScoreMask; bCol = bestMc; bState = 0; bPacked = bestM; }
+        if (bestDc >= 0 && (bestD & kScoreMask) > bScore) { bScore = bestD & kScoreMask; bCol = bestDc; bState = 1; bPacked = bestD; }
+        if (bestIc >= 0 && (bestI & kScoreMask) > bScore) { bScore = bestI & kScoreMask; bCol = bestIc; bState = 2; bPacked = bestI; }
+        int res1, res2, res3, res4 = 0;
+        bool fillNull = false;
+        if (stoppedRow <= rows) { res1 = 1; res2 = 0; res3 = kBadOff; res4 = 1; fillNull = true; }
+        else if (!lastHasGood) { res1 = max(1, lastColStart - 1); res2 = 0; res3 = subfloor; res4 = 1; fillNull = true; }
+        else if (bScore < minScoreOff) { res1 = bCol; res2 = bState; res3 = bScore; res4 = 1; fillNull = true; }
+        else { res1 = bCol; res2 = bState; res3 = bScore >> kScoreOffset; }
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // direction words are written before the walk reads them
+
+        // ------------------------------------------------------------------ score2 + traceback2 on the records, per lane
+        if (active) {
+            bbmsa_result r;
+            r.result[0] = rows; r.result[1] = res1; r.result[2] = res2; r.result[3] = res3; r.result[4] = res4;
+            r.status = (fillNull && mode == BBMSA_FILL_LIMITED) ? BBMSA_ST_NULL : BBMSA_ST_OK;
+            r.iterations = iters;
+            for (int i = 0; i < 8; i++) r.score[i] = 0;
+            r.score_len = 0; r.match_len = 0; r.fill_kind = 0; r.columns = columns;
+            if (!fillNull && (jb.flags & (BBMSA_DO_SCORE | BBMSA_DO_TRACEBACK))) {
+                const bool wantTrace = (jb.flags & BBMSA_DO_TRACEBACK) && p.match != nullptr;
+                uint8_t *out = wantTrace ? p.match + j * (long long)p.match_stride : nullptr;
+                int row = rows, col = res1, state = res2, n = 0, gaps = 0, stateTime = 0;
+                bool overflow = false;
+                while (row > 0 && col > 0) {
+                    const int i = col - row - D0;
+                    unsigned nib = 0;
+                    if (i >= 0 && i < NB) nib = (unsigned)(__hip_atomic_load(&dirw[(long long)row * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (4 * i)) & 15u;
+                    int prev;
+                    uint8_t sym;
+                    if (state == 0) {
+                        prev = (int)(nib & 3u);
+                        const int cb = rd[row - 1], rb = rf[col - 1];
+                        sym = (cb == rb) ? 'm' : ((!fully_defined(cb) || !fully_defined(rb)) ? 'N' : 'S');
+                        row--; col--;
+                    } else if (state == 1) {
+                        prev = (nib & 4u) ? 1 : 0;
+                        const int rb = rf[col - 1];
+                        if (rb == '-') { sym = '-'; gaps++; } else sym = 'D';
+                        col--;
+                    } else {
+                        prev = (nib & 8u) ? 2 : 0;
+                        sym = (col >= columns) ? 'Y' : 'I';
+                        row--;
+                    }
+                    if (wantTrace) { if (n < p.match_stride) out[n] = sym; else overflow = true; }
+                    n++;
+                    if (state == prev) stateTime++; else stateTime = 0;
+                    state = prev;
+                }
+                if (jb.flags & BBMSA_DO_SCORE) {
+                    int colS = col;
+                    if (row > colS) colS -= row;
+                    const int bestRefStart = a + colS, bestRefStop = a + res1 - 1;
+                    int padLeft = 0, padRight = 0;
+                    if (bestRefStart < a) padLeft = max(0, a - bestRefStart);
+                    else if (bestRefStart == a && state == 2) padLeft = stateTime;
+                    const int bW = (jb.flags & BBMSA_INTERNAL_GAPPED) ? jb.ref_len : b;      // see msa_fill_fast.hip
+                    if (bestRefStop > bW) padRight = max(0, bestRefStop - bW);
+                    else if (bestRefStop == bW && res2 == 2) padRight = bPacked & kTimeMask;
+                    r.score[0] = bScore >> kScoreOffset; r.score[1] = bestRefStart; r.score[2] = bestRefStop;
+                    r.score[3] = rows; r.score[4] = res1; r.score[5] = res2;
+                    if (padLeft > 0 || padRight > 0) { r.score[6] = padLeft; r.score[7] = padRight; r.score_len = 8; }
+                    else r.score_len = 6;
+                }
+                if (wantTrace) {
+                    if (col != row) { while (row > 0) { if (n < p.match_stride) out[n] = 'X'; else overflow = true; n++; row--; col--; } }
+                    const int totalLen = n + gaps * (kGapLen - 1);
+                    if (overflow || totalLen > p.match_stride) r.match_len = -1;
+                    else {
+                        for (int x = 0, y = n - 1; x < y; x++, y--) { const uint8_t t0 = out[x]; out[x] = out[y]; out[y] = t0; }
+                        if (gaps > 0) {
+                            int w = totalLen - 1;
+                            for (int x = n - 1; x >= 0; x--) {
+                                const uint8_t ch = out[x];
+                                if (ch != '-') out[w--] = ch;
+                                else for (int g = 0; g < kGapLen; g++) out[w--] = 'D';
+                            }
+                        }
+                        r.match_len = totalLen;
+                    }
+                }
+            }
+            p.results[j] = r;
+            nDone++;
+        }
+    }
+    if (p.stats) {
+        for (int d = 32; d >= 1; d >>= 1) { nDone += __shfl_xor(nDone, d, 64); nLeft += __shfl_xor(nLeft, d, 64); }
+        if (lane == 0) { if (nDone) atomicAdd(&p.stats[0], nDone); if (nLeft) atomicAdd(&p.stats[1], nLeft); }
+    }
+}
+
+}  // namespace bbmsa

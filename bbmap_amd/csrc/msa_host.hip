@@ -13,6 +13,7 @@
 namespace bbmsa {
 const void *fast_kernel_for(int R, bool banded);
 __global__ void msa_fill_generic_kernel(const GenericParams p);
+__global__ void msa_fill_narrow_kernel(const NarrowParams p);
 }  // namespace bbmsa
 
 static thread_local char g_err[512] = "";
@@ -112,6 +113,17 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     c->genThreads = (int)threads;
     HIP_TRY(hipMalloc(&c->d_matrix, (size_t)(threads * perThread)));
     HIP_TRY(hipMalloc(&c->d_limits, (size_t)(threads * (cfg->maxRows + cfg->maxColumns + 4) * 4)));
+    // narrow-window kernel: only without a band (a band changes the window rule); BBMSA_NARROW=0 disables it
+    c->narrowBlocks = 0;
+    c->narrowSlack = env_int("BBMSA_NARROW_SLACK", 2000);
+    if (!c->banded && env_int("BBMSA_NARROW", 1) != 0) {
+        int perCU = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)bbmsa::msa_fill_narrow_kernel, 64, 0));
+        if (perCU < 1) perCU = 1;
+        if (perCU > 16) perCU = 16;
+        c->narrowBlocks = c->numCUs * perCU;
+        HIP_TRY(hipMalloc(&c->d_narrowDir, (size_t)c->narrowBlocks * (size_t)(cfg->maxRows + 1) * 64 * 8));
+    }
     for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
     *out = c;
     return BBMAP_OK;
@@ -125,6 +137,8 @@ extern "C" void bbmsa_destroy(bbmsa_ctx *c) {
     if (c->d_slowList) (void)hipFree(c->d_slowList);
     if (c->d_matrix) (void)hipFree(c->d_matrix);
     if (c->d_limits) (void)hipFree(c->d_limits);
+    if (c->d_narrowDir) (void)hipFree(c->d_narrowDir);
+    if (c->d_fastList) (void)hipFree(c->d_fastList);
     if (c->d_gref) (void)hipFree(c->d_gref);
     if (c->d_gaux) (void)hipFree(c->d_gaux);
     if (c->d_gjobs) (void)hipFree(c->d_gjobs);
@@ -147,12 +161,33 @@ extern "C" int bbmsa_align_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_j
         HIP_TRY(hipMalloc(&c->d_slowList, (size_t)n_jobs * 4));
         c->slowCap = n_jobs;
     }
+    if (c->narrowBlocks > 0 && n_jobs > c->fastCap) {
+        if (c->d_fastList) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_fastList)); c->d_fastList = nullptr; }
+        HIP_TRY(hipMalloc(&c->d_fastList, (size_t)n_jobs * 4));
+        c->fastCap = n_jobs;
+    }
+    // counters: [0] fast queue, [1] slow count, [2] generic queue, [3] narrow queue, [4] fast-list count,
+    //           [5] jobs finished by the narrow kernel, [6] candidates it handed on
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 64, stream));
+    HIP_TRY(hipEventRecord(c->ev[0], stream));
+    if (c->narrowBlocks > 0) {
+        bbmsa::NarrowParams np;
+        np.jobs = jobs; np.reads = reads; np.refs = refs; np.results = results; np.match = match; np.njobs = n_jobs;
+        np.queue = c->d_counters + 3; np.fast_list = c->d_fastList; np.fast_count = c->d_counters + 4;
+        np.dirbuf = c->d_narrowDir; np.stats = c->d_counters + 5;
+        np.match_stride = match_stride; np.maxRows = c->cfg.maxRows; np.maxColumns = c->cfg.maxColumns;
+        np.bandwidth = c->cfg.bandwidth; np.bandwidthRatio = c->cfg.bandwidthRatio; np.maxSlack = c->narrowSlack;
+        long long nb = (n_jobs + 63) / 64;
+        if (nb > c->narrowBlocks) nb = c->narrowBlocks;
+        hipLaunchKernelGGL(bbmsa::msa_fill_narrow_kernel, dim3((unsigned)nb), dim3(64), 0, stream, np);
+        HIP_TRY(hipGetLastError());
+    }
 
     bbmsa::FillParams fp;
     fp.jobs = jobs; fp.reads = reads; fp.refs = refs; fp.results = results; fp.match = match;
     fp.njobs = n_jobs;
     fp.queue = c->d_counters; fp.dirbuf = c->d_dir; fp.dir_slot_dwords = c->dirSlotDwords;
+    fp.list = c->narrowBlocks > 0 ? c->d_fastList : nullptr; fp.list_count = c->d_counters + 4;
     fp.slow_list = c->d_slowList; fp.slow_count = c->d_counters + 1;
     fp.match_stride = match_stride; fp.lanesPerJob = c->G; fp.fastCols = c->fastCols; fp.tmpBytes = c->tmpBytes;
     fp.maxRows = c->cfg.maxRows; fp.maxColumns = c->cfg.maxColumns;
@@ -162,7 +197,6 @@ extern "C" int bbmsa_align_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_j
     long long blocks = (n_jobs + jobsPerBlock - 1) / jobsPerBlock;
     if (blocks > c->blocks) blocks = c->blocks;
     void *args[] = {&fp};
-    HIP_TRY(hipEventRecord(c->ev[0], stream));
     HIP_TRY(hipLaunchKernel(bbmsa::fast_kernel_for(c->R, c->banded), dim3((unsigned)blocks), dim3(256), args, (size_t)c->ldsBytes, stream));
     HIP_TRY(hipEventRecord(c->ev[1], stream));
 
@@ -188,6 +222,16 @@ extern "C" int bbmsa_last_kernel_ms(bbmsa_ctx *c, float *ms_fast, float *ms_slow
     HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
     if (ms_fast) *ms_fast = a;
     if (ms_slow) *ms_slow = b;
+    return BBMAP_OK;
+}
+
+extern "C" int bbmsa_last_counts(bbmsa_ctx *c, int64_t *counts4) {
+    if (!c || !c->timed || !counts4) return fail(BBMAP_E_ARG, "bbmsa_last_counts: nothing launched yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[2]));
+    unsigned h[16];
+    HIP_TRY(hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    counts4[0] = h[5]; counts4[1] = h[6]; counts4[2] = c->narrowBlocks > 0 ? h[4] : 0; counts4[3] = h[1];
     return BBMAP_OK;
 }
 

@@ -96,6 +96,13 @@ class MSAContext:
                                              C.c_void_p(match_ptr) if match_ptr else None, match_stride)
         _lib.check(rc, "bbmsa_align_batch_device")
 
+    def last_counts(self):
+        """{narrow: finished by the one-job-per-lane kernel, narrow_left: its candidates handed on, wave: jobs of the
+        wavefront kernel, generic: jobs of the generic kernel} for the last launch sequence."""
+        c = (C.c_int64 * 4)()
+        _lib.check(self.L.bbmsa_last_counts(self.h, c), "bbmsa_last_counts")
+        return {"narrow": c[0], "narrow_left": c[1], "wave": c[2], "generic": c[3]}
+
     def last_kernel_ms(self):
         a, b = C.c_float(), C.c_float()
         _lib.check(self.L.bbmsa_last_kernel_ms(self.h, C.byref(a), C.byref(b)), "bbmsa_last_kernel_ms")

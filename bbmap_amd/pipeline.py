@@ -100,7 +100,9 @@ class MapPipeline:
             raise RuntimeError("more gapped sites (%d) than the pipeline's gapped-job capacity (%d)" % (ngap, self.gap_cap))
         if ngap:
             if self.msa_gapped is None:
-                self.msa_gapped = M.MSAContext(maxRows=self.max_rows, maxColumns=self.gap_columns, device=self.dev.index or 0)
+                # fast_cols = the whole width: a gapped window that falls to the one-thread-per-job generic kernel costs ~1 ms
+                self.msa_gapped = M.MSAContext(maxRows=self.max_rows, maxColumns=self.gap_columns, device=self.dev.index or 0,
+                                               fast_cols=self.gap_columns)
             rc = L.bbmsa_align_gapped_batch_device(self.msa_gapped.h, C.c_void_p(stream), ngap, self.gjobs.data_ptr(),
                                                    self.ggaps.data_ptr(), plus, self.refs.data_ptr(), self.gresults.data_ptr(),
                                                    self.gmatch.data_ptr(), self.gmatch_stride)

@@ -28,3 +28,12 @@ for st in (0, 1):
 # jobs per read histogram
 src = out["src"] // 8
 print("jobs per read with jobs", np.bincount(np.bincount(src)[np.bincount(src) > 0]))
+print("kernel split", pipe.msa.last_counts(), "ms", pipe.msa.last_kernel_ms())
+cnt = pipe.last_counters
+print("counters", cnt)
+if cnt[2]:
+    g = out["gresults"]
+    print("gapped: status", np.bincount(g["status"]), "fill_kind", np.bincount(g["fill_kind"]), "columns pct", np.percentile(g["columns"], [0, 50, 90, 99, 100]))
+    print("gapped kernel split", pipe.msa_gapped.last_counts(), pipe.msa_gapped.last_kernel_ms())
+    gg = out["ggaps"]
+    print("ngaps", np.bincount(gg["ngaps"]))
