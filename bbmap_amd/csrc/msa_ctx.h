@@ -29,7 +29,7 @@ struct bbmsa_ctx {
     int *d_gaux;
     bbmsa_job *d_gjobs;
     long long gappedCap;
-    hipEvent_t ev[3];
+    hipEvent_t ev[4];      // start, after wavefront kernel, after generic kernel, after narrow kernel
     bool timed;
     bool banded;
 };

@@ -124,7 +124,7 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
         c->narrowBlocks = c->numCUs * perCU;
         HIP_TRY(hipMalloc(&c->d_narrowDir, (size_t)c->narrowBlocks * (size_t)(cfg->maxRows + 1) * 64 * 8));
     }
-    for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+    for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
     *out = c;
     return BBMAP_OK;
 }
@@ -142,7 +142,7 @@ extern "C" void bbmsa_destroy(bbmsa_ctx *c) {
     if (c->d_gref) (void)hipFree(c->d_gref);
     if (c->d_gaux) (void)hipFree(c->d_gaux);
     if (c->d_gjobs) (void)hipFree(c->d_gjobs);
-    for (int i = 0; i < 3; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
 
@@ -182,6 +182,7 @@ extern "C" int bbmsa_align_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_j
         hipLaunchKernelGGL(bbmsa::msa_fill_narrow_kernel, dim3((unsigned)nb), dim3(64), 0, stream, np);
         HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipEventRecord(c->ev[3], stream));
 
     bbmsa::FillParams fp;
     fp.jobs = jobs; fp.reads = reads; fp.refs = refs; fp.results = results; fp.match = match;
@@ -222,6 +223,16 @@ extern "C" int bbmsa_last_kernel_ms(bbmsa_ctx *c, float *ms_fast, float *ms_slow
     HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
     if (ms_fast) *ms_fast = a;
     if (ms_slow) *ms_slow = b;
+    return BBMAP_OK;
+}
+
+extern "C" int bbmsa_last_kernel_ms3(bbmsa_ctx *c, float *ms3) {
+    if (!c || !c->timed || !ms3) return fail(BBMAP_E_ARG, "bbmsa_last_kernel_ms3: nothing launched yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&ms3[0], c->ev[0], c->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&ms3[1], c->ev[3], c->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms3[2], c->ev[1], c->ev[2]));
     return BBMAP_OK;
 }
 

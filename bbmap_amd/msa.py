@@ -103,6 +103,12 @@ class MSAContext:
         _lib.check(self.L.bbmsa_last_counts(self.h, c), "bbmsa_last_counts")
         return {"narrow": c[0], "narrow_left": c[1], "wave": c[2], "generic": c[3]}
 
+    def last_kernel_ms3(self):
+        """(narrow-window kernel, wavefront kernel, generic kernel) milliseconds of the last launch sequence."""
+        m = (C.c_float * 3)()
+        _lib.check(self.L.bbmsa_last_kernel_ms3(self.h, m), "bbmsa_last_kernel_ms3")
+        return m[0], m[1], m[2]
+
     def last_kernel_ms(self):
         a, b = C.c_float(), C.c_float()
         _lib.check(self.L.bbmsa_last_kernel_ms(self.h, C.byref(a), C.byref(b)), "bbmsa_last_kernel_ms")

@@ -205,6 +205,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dp_ms, probe_ms, njobs_hist, probe_stats = [], [], [], None
+    narrow_ms, wave_ms, gapped_ms = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nj = pipe.step()
@@ -212,7 +213,10 @@ def main():
         st, pms = pipe.probe_stats()            # HIP events on the launch stream around the probe kernel
         probe_ms.append(pms)
         probe_stats = st
-        dp_ms.append(pipe.msa.last_kernel_ms()[0] if nj else 0.0)
+        k3 = pipe.msa.last_kernel_ms3() if nj else (0.0, 0.0, 0.0)
+        narrow_ms.append(k3[0]); wave_ms.append(k3[1])
+        dp_ms.append(k3[0] + k3[1] + k3[2])
+        gapped_ms.append(sum(pipe.msa_gapped.last_kernel_ms3()) if (pipe.msa_gapped is not None and pipe.last_counters[2]) else 0.0)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -231,6 +235,9 @@ def main():
         np.logical_or.at(dp_ok, out["src"] // max_sites, res["score_len"] > 0)
     mapped = int(((out["nsites"] > 0) & ((out["no_indel"].max(axis=1) >= 70 + 149 * 100 - 495) | dp_ok)).sum())
     cells = int(res["iterations"].sum()) if njobs else 0
+    ngapped = int(cnt[2])
+    gcells = int(out["gresults"]["iterations"].sum()) if ngapped else 0
+    split = pipe.msa.last_counts() if njobs else {"narrow": 0, "narrow_left": 0, "wave": 0, "generic": 0}
     parity = None
     if rank == 0 and args.parity_sample > 0:
         parity = parity_sample(pipe, out, reads, ref, hi, offsets, key_scores, min(n, args.parity_sample), max_sites, max_cols)
@@ -241,15 +248,18 @@ def main():
         total_reads = n * world * args.steps
         value = total_reads / elapsed
         d_ms, p_ms = float(np.mean(dp_ms)), float(np.mean(probe_ms))
+        n_ms, w_ms, g_ms = float(np.mean(narrow_ms)), float(np.mean(wave_ms)), float(np.mean(gapped_ms))
         jobs = out["jobs"]
         dp_bytes = W.algorithmic_bytes(jobs) if njobs else 0
+        # the wavefront kernel's own share of those bytes: the jobs the narrow-window kernel did not finish
+        wave_bytes = int(dp_bytes * (split["wave"] / max(1, njobs)))
         nkeys = len(offsets)
         # 2 strands x nkeys x (8 + 8) + 2 x 4 x (list entries streamed) + ref bytes compared + 64 x sites out
         probe_bytes = n * 2 * nkeys * 16 + 4 * (probe_stats[0] + probe_stats[1]) + probe_stats[3] + 64 * probe_stats[4]
-        if d_ms >= p_ms:
-            dom, dom_ms, dom_bytes = "msa_fill_fast_kernel", d_ms, dp_bytes
+        if w_ms >= p_ms:
+            dom, dom_ms, dom_bytes = "msa_fill_fast_kernel", w_ms, wave_bytes
         else:
-            dom, dom_ms, dom_bytes = "probe_kernel", p_ms, probe_bytes
+            dom, dom_ms, dom_bytes = "probe_wave_kernel", p_ms, probe_bytes
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -266,9 +276,11 @@ def main():
             "config": {"workload": "configs[1]: synthetic E. coli K-12 sized reference (%d bp, seed 1), %d x %d-bp SE reads per GPU "
                                    "(seed 2, mutated mix), k=%d index resident in HBM; per step: reverse complement -> index probe "
                                    "(BBIndex.findAdvanced) -> ungapped site filter -> slow-align DP + traceback for the sites that "
-                                   "need it" % (ref_len, n, read_len, k),
+                                   "need it (gapped-reference DP for sites with gap arrays)" % (ref_len, n, read_len, k),
                        "reads_per_gpu_per_step": n, "read_len": read_len, "keys_per_read": nkeys,
-                       "dp_jobs_per_step": njobs, "reads_finished_without_dp": int(cnt[1]), "reads_without_site": int(cnt[3]),
+                       "dp_jobs_per_step": njobs, "dp_jobs_by_kernel": split, "gapped_dp_jobs_per_step": ngapped,
+                       "gapped_dp_cells_per_step": gcells,
+                       "reads_finished_without_dp": int(cnt[1]), "reads_without_site": int(cnt[3]),
                        "mapped_fraction": mapped / n, "dp_cells_per_step": cells,
                        "dp_gcups": (cells / (d_ms * 1e-3) / 1e9) if d_ms > 0 else 0.0,
                        "probe_list_entries_per_step": int(probe_stats[0] + probe_stats[1]),
@@ -277,8 +289,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": dom, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(dom_bytes),
-                         "kernels": {"probe_kernel": {"ms": p_ms, "algorithmic_bytes": int(probe_bytes)},
-                                     "msa_fill_fast_kernel": {"ms": d_ms, "algorithmic_bytes": int(dp_bytes)}}},
+                         "kernels": {"probe_wave_kernel": {"ms": p_ms, "algorithmic_bytes": int(probe_bytes)},
+                                     "msa_fill_fast_kernel": {"ms": w_ms, "algorithmic_bytes": int(wave_bytes)},
+                                     "msa_fill_narrow_kernel": {"ms": n_ms, "algorithmic_bytes": int(dp_bytes - wave_bytes)},
+                                     "gapped_dp_kernels": {"ms": g_ms}}},
         }
         if cpu is not None:
             out_json["cpu_baseline"] = cpu

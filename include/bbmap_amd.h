@@ -135,6 +135,8 @@ int bbmsa_align_gapped_batch(bbmsa_ctx *ctx, int64_t n_jobs, const bbmsa_job *jo
 /* Timing of the last bbmsa_align_batch_device launch sequence on this context, measured with
  * HIP events on the launch stream.  Valid after the stream has been synchronised. */
 int bbmsa_last_kernel_ms(bbmsa_ctx *ctx, float *ms_fast, float *ms_slow);
+/* The same per kernel: ms3 = {narrow-window kernel, wavefront kernel, generic kernel}. */
+int bbmsa_last_kernel_ms3(bbmsa_ctx *ctx, float *ms3);
 /* Which kernel took how many jobs of the last launch sequence: counts4 = {finished by the narrow-window kernel (one job
  * per lane, a band of diagonals in registers), candidates it handed on because their window left the band, jobs given
  * to the wavefront kernel in total, jobs the wavefront kernel handed to the generic kernel}. */
