@@ -42,6 +42,8 @@ struct WaveLds {
     uint8_t base[2][WMAXLEN + 8]; // [0] the read as given, [1] its reverse complement
     int8_t bsc[WMAXLEN + 8];      // base scores of the plus strand
     int8_t code[WMAXLEN + 8];     // AminoAcid.baseToNumber of the plus strand (-1 = undefined)
+    int hits[8][64];              // block 0's list heads per key lane, plus then minus strand {cnt, start, len, first}:
+                                  // long-lived, rarely read -> parked here instead of 8 VGPRs (which the compiler spilled)
 };
 
 // wave-uniform state of one read
@@ -783,11 +785,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
             if (lane < n) { offM = blen - (so + p.k); keyM = rc_key(sk, p.k); kscM = ss; }
         }
         // block 0's list heads for both strands come from the records already in registers; further blocks reload
-        KeyHit hitP0, hitM0;
-        hitP0.cnt = cnt; hitP0.start = e.startF; hitP0.len = e.lenF; hitP0.first = e.firstF;
-        hitM0 = minusView(lane, n, e.cntRC, e.startR, e.lenR, e.firstR);
+        {
+            const KeyHit hm = minusView(lane, n, e.cntRC, e.startR, e.lenR, e.firstR);
+            S.hits[0][lane] = cnt; S.hits[1][lane] = e.startF; S.hits[2][lane] = e.lenF; S.hits[3][lane] = e.firstF;
+            S.hits[4][lane] = hm.cnt; S.hits[5][lane] = hm.start; S.hits[6][lane] = hm.len; S.hits[7][lane] = hm.first;
+            wsync();
+        }
         auto keyHits = [&](int block, int strand) -> KeyHit {
-            if (block == 0) return strand ? hitM0 : hitP0;
+            if (block == 0) {
+                KeyHit h; const int o = strand ? 4 : 0;
+                h.cnt = S.hits[o][lane]; h.start = S.hits[o + 1][lane]; h.len = S.hits[o + 2][lane]; h.first = S.hits[o + 3][lane];
+                return h;
+            }
             KeyEntry eb; eb.cnt = eb.cntRC = eb.startF = eb.lenF = eb.firstF = eb.startR = eb.lenR = eb.firstR = 0;
             if (lane < n && key >= 0) eb = ix.fused[block][key];
             if (strand) return minusView(lane, n, eb.cntRC, eb.startR, eb.lenR, eb.firstR);
