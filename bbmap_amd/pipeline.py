@@ -66,6 +66,7 @@ class MapPipeline:
         self.gresults = torch.zeros(self.gap_cap * M.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
         self.gmatch = torch.zeros(self.gap_cap * self.gmatch_stride, dtype=torch.uint8, device=self.dev)
         self.max_rows = max_rows
+        self.side_stream = torch.cuda.Stream(device=self.dev) if __import__("os").environ.get("BBPIPE_SIDE_STREAM", "0") != "0" else None
         self.last_counters = None
         self.last_ms = {}
 
@@ -92,21 +93,31 @@ class MapPipeline:
                    "bbpipe_select_jobs_device")
         cnt = self.counters.cpu().numpy()                     # the one host round trip: how many DP jobs
         njobs = int(cnt[0])
-        if njobs:
-            self.msa.align_batch_device(njobs, self.jobs.data_ptr(), plus, self.refs.data_ptr(), self.results.data_ptr(),
-                                        self.match.data_ptr(), self.match_stride, stream)
         ngap = int(cnt[2])
         if ngap > self.gap_cap:
             raise RuntimeError("more gapped sites (%d) than the pipeline's gapped-job capacity (%d)" % (ngap, self.gap_cap))
+        # the few gapped-reference jobs (wide unlimited fills) go to a side stream so that they share the chip with the
+        # main DP launch instead of running behind it
+        side = None
+        if ngap and njobs and self.side_stream is not None:
+            side = self.side_stream
+            side.wait_stream(torch.cuda.current_stream())
+        if njobs:
+            self.msa.align_batch_device(njobs, self.jobs.data_ptr(), plus, self.refs.data_ptr(), self.results.data_ptr(),
+                                        self.match.data_ptr(), self.match_stride, stream)
         if ngap:
+            if side is not None:
+                stream = side.cuda_stream
             if self.msa_gapped is None:
                 # fast_cols = the whole width: a gapped window that falls to the one-thread-per-job generic kernel costs ~1 ms
                 self.msa_gapped = M.MSAContext(maxRows=self.max_rows, maxColumns=self.gap_columns, device=self.dev.index or 0,
-                                               fast_cols=self.gap_columns)
+                                               fast_cols=self.gap_columns, lanes_per_job=int(__import__('os').environ.get('BBPIPE_GAPPED_LANES', '64')))
             rc = L.bbmsa_align_gapped_batch_device(self.msa_gapped.h, C.c_void_p(stream), ngap, self.gjobs.data_ptr(),
                                                    self.ggaps.data_ptr(), plus, self.refs.data_ptr(), self.gresults.data_ptr(),
                                                    self.gmatch.data_ptr(), self.gmatch_stride)
             _lib.check(rc, "bbmsa_align_gapped_batch_device")
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
         self.last_counters = cnt
         return njobs
 
