@@ -16,7 +16,7 @@ EXPORTS = [
     "bbmsa_last_kernel_ms", "bbmsa_last_kernel_ms3", "bbmsa_last_counts", "bbmsa_align_gapped_batch_device", "bbmsa_align_gapped_batch",
     "bbband_create", "bbband_destroy", "bbband_align_batch_device", "bbband_align_batch",
     "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch", "bbidx_last_stats", "bbidx_set_kernel",
-    "bbpipe_revcomp_device", "bbpipe_select_jobs_device",
+    "bbpipe_revcomp_device", "bbpipe_select_jobs_device", "bbpipe_quick_rescue_device",
 ]
 
 
@@ -110,6 +110,9 @@ def load():
                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bbpipe_select_jobs_device.restype = C.c_int
+    L.bbpipe_quick_rescue_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.bbpipe_quick_rescue_device.restype = C.c_int
     _lib = L
     return L
 

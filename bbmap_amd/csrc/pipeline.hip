@@ -15,6 +15,7 @@
 // Sites that carry a gap array go to a second job list (bbmsa_align_gapped_batch_device builds their gapped reference).
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdio>
 
 #include "bbmap_amd.h"
@@ -230,6 +231,110 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
     if (threadIdx.x < 2 && blockCnt[threadIdx.x]) atomicAdd(&P.counters[threadIdx.x == 0 ? 1 : 3], blockCnt[threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Paired-read rescue scan: AbstractMapThread.quickRescue (current/align2/AbstractMapThread.java:2300-2391).
+// The mate of a mapped read is slid over up to searchDist reference positions; per start the reference counts
+// mismatches (giving up once they exceed the best count so far) and the longest completed match run, and keeps the
+// best (length - mismatches + run) with the start closest to idealStart as tie-break; a perfect hit narrows the
+// remaining search range.  Here: one wavefront per job, 64 consecutive starts per step.  Lane s compares the read
+// (LDS, broadcast) with ref[start_s + j] (consecutive lanes -> consecutive bytes: coalesced).  The acceptance rule is
+// order-dependent, so the (few) lanes whose count stayed within the cap are replayed in search order with readlanes.
+struct RescueParams {
+    const bbresc_job *jobs;
+    const uint8_t *reads;
+    const long long *chromOff;
+    const int *chromLen, *chromMin;
+    const uint8_t *refs;
+    bbresc_result *results;
+    long long njobs;
+    int pointsMatch, pointsMatch2, useAffine, baseHitScore;
+};
+
+constexpr int RESC_WAVES = 4, RESC_MAXLEN = 608;
+
+__global__ __launch_bounds__(64 * RESC_WAVES) void quick_rescue_kernel(const RescueParams P) {
+    __shared__ uint8_t rdbuf[RESC_WAVES][RESC_MAXLEN];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long long jx = (long long)blockIdx.x * RESC_WAVES + wave;
+    if (jx >= P.njobs) return;                                   // whole wave; the kernel has no block-level barrier
+    const bbresc_job jb = P.jobs[jx];
+    bbresc_result res;
+    res.found = 0; res.start = 0; res.stop = 0; res.score = 0; res.mismatches = 0; res.perfect = 0; res.semiperfect = 0; res.maxContig = 0;
+    const int len = jb.read_len;
+    if (len < 10 || len > RESC_MAXLEN - 8 || jb.chrom < 1) { if (lane == 0) { res.found = len > RESC_MAXLEN - 8 ? -2 : 0; P.results[jx] = res; } return; }
+    const uint8_t *bases = P.reads + jb.read_off;
+    const uint8_t *ref = P.refs + P.chromOff[jb.chrom];
+    const int reflen = P.chromLen[jb.chrom], minIndex = P.chromMin[jb.chrom];
+    uint8_t *rd = rdbuf[wave];
+    for (int i = lane; i < len; i += 64) rd[i] = bases[i];
+    wsync();
+    const bool right = (jb.flags & 1) != 0;
+    int lower, upper;
+    if (right) { lower = max(minIndex, jb.loc); upper = min(reflen - len, jb.loc + jb.searchDist); }
+    else { lower = max(minIndex, jb.loc - jb.searchDist); upper = min(reflen - len, jb.loc); }
+    int minMM = jb.maxAllowedMismatches + 1, maxContig = 0, bestScore = 0, bestStart = -1, bestAbsdif = INT_MAX;
+    bool finished = false;
+    for (int base = 0; !finished; base += 64) {
+        const int start = right ? lower + base + lane : upper - base - lane;
+        const bool valid = start >= lower && start <= upper;
+        if (!__ballot(valid)) break;
+        const int cap = minMM;
+        int mm = 0, contig = 0, cur = 0;
+        for (int j = 0; j < len; j++) {
+            const bool on = valid && mm <= cap;
+            if (!__ballot(on)) break;
+            const int c = rd[j];
+            if (on) {
+                const int r = ref[start + j];
+                if (c != r || c == 'N') { mm++; contig = max(contig, cur); cur = 0; } else cur++;
+            }
+        }
+        for (u64 m = __ballot(valid && mm <= cap); m; m &= m - 1) {
+            const int s = __builtin_ctzll(m);
+            const int st = rl(start, s), ms = rl(mm, s), ct = rl(contig, s);
+            if (right ? st > upper : st < lower) { finished = true; break; }      // a perfect hit narrowed the range
+            if (ms > minMM) continue;
+            const int score = (len - ms) + ct;
+            const int ad = st > jb.idealStart ? st - jb.idealStart : jb.idealStart - st;
+            if (score > bestScore || (score == bestScore && ad < bestAbsdif)) {
+                bestStart = st; minMM = ms; maxContig = ct; bestScore = score; bestAbsdif = ad;
+                if (ms == 0) { if (right) upper = min(upper, jb.idealStart + ad); else lower = max(lower, jb.idealStart - ad); }
+            }
+        }
+    }
+    if (bestStart >= 0) {
+        res.found = 1; res.start = bestStart; res.stop = bestStart + len - 1; res.mismatches = minMM; res.maxContig = maxContig;
+        res.score = P.useAffine ? P.pointsMatch + P.pointsMatch2 * (len - 1 - minMM) : maxContig + P.baseHitScore * (len - minMM);
+        // SiteScore.setPerfect (current/stream/SiteScore.java:239-292), order-independent form (see index_probe_wave.hip)
+        bool perfect = true;
+        int refloc = res.start, readloc = 0, N = 0;
+        const int mx = min(res.stop, reflen - 1), nlimit = len / 2;
+        if (res.start < 0) { N -= res.start; readloc -= res.start; refloc -= res.start; perfect = false; }
+        if (res.stop >= reflen) { N += (res.stop - reflen + 1); perfect = false; }
+        bool anyHard = false, anyCN = false, anyBad = false;
+        if (N <= nlimit) {
+            for (int j0 = 0; refloc + j0 <= mx; j0 += 64) {
+                const int j = j0 + lane;
+                bool bad = false, hard = false, cn = false;
+                if (refloc + j <= mx) {
+                    const int c = rd[readloc + j], r = ref[refloc + j];
+                    bad = (c != r || c == 'N'); hard = bad && r != 'N'; cn = bad && c == 'N';
+                }
+                const u64 badM = __ballot(bad);
+                if (badM) {
+                    anyBad = true;
+                    if (__ballot(hard)) { anyHard = true; break; }
+                    if (__ballot(cn)) anyCN = true;
+                    N += popc(badM);
+                    if (N > nlimit) break;
+                }
+            }
+            if (!anyHard && N <= nlimit) { res.semiperfect = anyCN ? 0 : 1; res.perfect = (perfect && !anyBad && !anyCN && N == 0) ? 1 : 0; }
+        }
+    }
+    if (lane == 0) P.results[jx] = res;
+}
+
 }  // namespace bbpipe
 
 static thread_local char g_perr[256];
@@ -270,6 +375,25 @@ extern "C" int bbpipe_select_jobs_device(void *stream_, int64_t n_reads, const b
     const long long per_block = bbpipe::SEL_WAVES * bbpipe::SEL_READS_PER_WAVE;
     const long long blocks = (n_reads + per_block - 1) / per_block;
     hipLaunchKernelGGL(bbpipe::select_jobs_kernel, dim3((unsigned)blocks), dim3(64 * bbpipe::SEL_WAVES), 0, stream, P);
+    PHIP(hipGetLastError());
+    return BBMAP_OK;
+}
+
+extern "C" int bbpipe_quick_rescue_device(void *stream_, int64_t n_jobs, const bbresc_job *jobs, const uint8_t *reads,
+                                          const int64_t *chrom_off, const int32_t *chrom_len, const int32_t *chrom_min_index,
+                                          const uint8_t *refs, bbresc_result *results,
+                                          int32_t points_match, int32_t points_match2, int32_t use_affine, int32_t base_hit_score) {
+    if (n_jobs < 0) { bbmap_set_error("bbpipe_quick_rescue_device: bad size"); return BBMAP_E_ARG; }
+    if (n_jobs == 0) return BBMAP_OK;
+    if (!jobs || !reads || !chrom_off || !chrom_len || !chrom_min_index || !refs || !results) {
+        bbmap_set_error("bbpipe_quick_rescue_device: null buffer"); return BBMAP_E_ARG;
+    }
+    bbpipe::RescueParams P;
+    P.jobs = jobs; P.reads = reads; P.chromOff = (const long long *)chrom_off; P.chromLen = chrom_len; P.chromMin = chrom_min_index;
+    P.refs = refs; P.results = results; P.njobs = n_jobs;
+    P.pointsMatch = points_match; P.pointsMatch2 = points_match2; P.useAffine = use_affine; P.baseHitScore = base_hit_score;
+    const long long blocks = (n_jobs + bbpipe::RESC_WAVES - 1) / bbpipe::RESC_WAVES;
+    hipLaunchKernelGGL(bbpipe::quick_rescue_kernel, dim3((unsigned)blocks), dim3(64 * bbpipe::RESC_WAVES), 0, (hipStream_t)stream_, P);
     PHIP(hipGetLastError());
     return BBMAP_OK;
 }

@@ -294,6 +294,24 @@ int bbpipe_select_jobs_device(void *stream, int64_t n_reads, const bbidx_read *r
                               bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score,
                               bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src);
 
+/* Paired-read rescue scan: AbstractMapThread.quickRescue(bases, chrom, strand, loc, searchDist, searchRight, idealStart,
+ * maxAllowedMismatches, POINTS_MATCH, POINTS_MATCH2) (current/align2/AbstractMapThread.java:2300-2391), batched.  `reads`
+ * holds the mate's bases already on the strand to search; chromosome c occupies refs[chrom_off[c] .. + chrom_len[c]) and
+ * chrom_min_index[c] is ChromosomeArray.minIndex.  result.found: 1 = a SiteScore (start, stop, score; mismatches is what
+ * the reference parks in ss.slowScore; perfect/semiperfect from SiteScore.setPerfect), 0 = null, -2 = read longer than
+ * 600.  use_affine selects the reference's USE_AFFINE_SCORE score formula (:2376-2380). */
+typedef struct bbresc_job {
+    int64_t read_off;
+    int32_t read_len, chrom, loc, searchDist, idealStart, maxAllowedMismatches;
+    int32_t flags;            /* bit 0: searchRight */
+    int32_t reserved;
+} bbresc_job;                 /* 40 bytes */
+typedef struct bbresc_result { int32_t found, start, stop, score, mismatches, perfect, semiperfect, maxContig; } bbresc_result;   /* 32 bytes */
+int bbpipe_quick_rescue_device(void *stream, int64_t n_jobs, const bbresc_job *jobs, const uint8_t *reads,
+                               const int64_t *chrom_off, const int32_t *chrom_len, const int32_t *chrom_min_index,
+                               const uint8_t *refs, bbresc_result *results,
+                               int32_t points_match, int32_t points_match2, int32_t use_affine, int32_t base_hit_score);
+
 #ifdef __cplusplus
 }
 #endif

@@ -314,3 +314,17 @@ def make_offsets(readlen, k, density=1.9, min_keys=2):
     L.orc_make_offsets.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, c_i32p, C.c_int]
     n = L.orc_make_offsets(readlen, k, density, min_keys, _p(out, c_i32p), 256)
     return out[:n].tolist()
+
+
+def quick_rescue(bases, ref, minIndex, loc, searchDist, searchRight, idealStart, maxAllowedMismatches,
+                 pointsMatch=70, pointsMatch2=100, useAffine=True, baseHitScore=100):
+    """AbstractMapThread.quickRescue; returns None or dict(start, stop, score, mismatches, perfect, semiperfect, contig)."""
+    b, f = _u8(bases), _u8(ref)
+    out = np.zeros(8, np.int32)
+    lib().orc_quick_rescue(_p(b, c_u8p), len(bases), _p(f, c_u8p), len(ref), minIndex, loc, searchDist,
+                           1 if searchRight else 0, idealStart, maxAllowedMismatches, pointsMatch, pointsMatch2,
+                           1 if useAffine else 0, baseHitScore, _p(out, c_i32p))
+    if not out[0]:
+        return None
+    return dict(start=int(out[1]), stop=int(out[2]), score=int(out[3]), mismatches=int(out[4]), perfect=int(out[5]),
+                semiperfect=int(out[6]), contig=int(out[7]))
