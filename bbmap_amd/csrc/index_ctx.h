@@ -1,0 +1,25 @@
+// Host-side context of the index-probe entry points (index_probe.hip, index_build.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "bbmap_amd.h"
+#include "index_common.h"
+
+struct bbidx_ctx {
+    int device;
+    bbidx::DevIndex dev;
+    std::vector<void *> allocs;
+    unsigned int *d_queue;
+    unsigned long long *d_stats;
+    int blocks;
+    hipEvent_t ev[2];
+    bool timed;
+    int kernelKind;       // BBIDX_KERNEL_*
+};
+
+
+// Shared tail of bbidx_create / bbidx_build: the fused key table (from the per-block device arrays), queue, work counters,
+// events.  `starts` / `sites` are the per-block DEVICE pointers, already recorded in c->allocs.
+int bbidx_finish_create(bbidx_ctx *c, const std::vector<const int *> &starts, const std::vector<const int *> &sites);

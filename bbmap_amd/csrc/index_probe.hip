@@ -700,17 +700,7 @@ __global__ void build_fused_kernel(KeyEntry *out, const int *starts, const int *
 }  // namespace bbidx
 
 // ------------------------------------------------------------------------------------------------ host side
-struct bbidx_ctx {
-    int device;
-    bbidx::DevIndex dev;
-    std::vector<void *> allocs;
-    unsigned int *d_queue;
-    unsigned long long *d_stats;
-    int blocks;
-    hipEvent_t ev[2];
-    bool timed;
-    int kernelKind;       // BBIDX_KERNEL_*
-};
+#include "index_ctx.h"
 
 static thread_local char g_ierr[256];
 #define IHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(g_ierr, sizeof g_ierr, "%s failed: %s", #expr, hipGetErrorString(e_)); bbmap_set_error(g_ierr); return BBMAP_E_HIP; } } while (0)
@@ -724,6 +714,35 @@ static int upload(bbidx_ctx *c, const T *host, size_t count, const T **dev) {
     if (count > 0) IHIP(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
     *dev = (const T *)d;
     return BBMAP_OK;
+}
+
+int bbidx_finish_create(bbidx_ctx *c, const std::vector<const int *> &hs, const std::vector<const int *> &hsi) {
+    const bbidx_params &p = c->dev.p;
+    const size_t keyspace = (size_t)1 << (2 * p.k);
+    const int nblocks = c->dev.nblocks;
+    int rc = BBMAP_OK;
+    {
+        // fused per-key records for the wave kernel; if HBM cannot hold them the context stays on the per-lane kernel
+        std::vector<const bbidx::KeyEntry *> hf((size_t)nblocks, nullptr);
+        bool ok = true;
+        for (int b = 0; b < nblocks && ok; b++) {
+            void *f = nullptr;
+            if (hipMalloc(&f, keyspace * sizeof(bbidx::KeyEntry)) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+            c->allocs.push_back(f);
+            hf[(size_t)b] = (const bbidx::KeyEntry *)f;
+            hipLaunchKernelGGL(bbidx::build_fused_kernel, dim3((unsigned)((keyspace + 255) / 256)), dim3(256), 0, nullptr,
+                               (bbidx::KeyEntry *)f, hs[(size_t)b], hsi[(size_t)b], c->dev.counts, p.k, (long long)keyspace);
+            if (hipGetLastError() != hipSuccess) ok = false;
+        }
+        if (ok && hipDeviceSynchronize() != hipSuccess) ok = false;
+        c->dev.fused = nullptr;
+        if (ok) rc = upload(c, hf.data(), hf.size(), (const bbidx::KeyEntry *const **)&c->dev.fused);
+        else c->kernelKind = BBIDX_KERNEL_LANE;
+    }
+    if (rc == BBMAP_OK && hipMalloc(&c->d_queue, 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
+    if (rc == BBMAP_OK && hipMalloc(&c->d_stats, bbidx::STAT_SHARDS * 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
+    if (rc == BBMAP_OK && (hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess)) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipEventCreate failed");
+    return rc;
 }
 
 extern "C" int bbidx_create(int32_t device, const bbidx_index_desc *d, bbidx_ctx **out) {
@@ -761,27 +780,7 @@ extern "C" int bbidx_create(int32_t device, const bbidx_index_desc *d, bbidx_ctx
     if (rc == BBMAP_OK) rc = upload(c, d->lengthHistogram, (size_t)1001, &c->dev.lengthHistogram);
     if (rc == BBMAP_OK) rc = upload(c, d->chromArrLen, (size_t)d->nchroms + 1, &c->dev.chromArrLen);
     if (rc == BBMAP_OK) rc = upload(c, d->chromLengths, (size_t)d->nchroms + 1, &c->dev.chromLengths);
-    if (rc == BBMAP_OK) {
-        // fused per-key records for the wave kernel; if HBM cannot hold them the context stays on the per-lane kernel
-        std::vector<const bbidx::KeyEntry *> hf((size_t)d->nblocks, nullptr);
-        bool ok = true;
-        for (int b = 0; b < d->nblocks && ok; b++) {
-            void *f = nullptr;
-            if (hipMalloc(&f, keyspace * sizeof(bbidx::KeyEntry)) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
-            c->allocs.push_back(f);
-            hf[(size_t)b] = (const bbidx::KeyEntry *)f;
-            hipLaunchKernelGGL(bbidx::build_fused_kernel, dim3((unsigned)((keyspace + 255) / 256)), dim3(256), 0, nullptr,
-                               (bbidx::KeyEntry *)f, hs[(size_t)b], hsi[(size_t)b], c->dev.counts, p.k, (long long)keyspace);
-            if (hipGetLastError() != hipSuccess) ok = false;
-        }
-        if (ok && hipDeviceSynchronize() != hipSuccess) ok = false;
-        c->dev.fused = nullptr;
-        if (ok) rc = upload(c, hf.data(), hf.size(), (const bbidx::KeyEntry *const **)&c->dev.fused);
-        else c->kernelKind = BBIDX_KERNEL_LANE;
-    }
-    if (rc == BBMAP_OK && hipMalloc(&c->d_queue, 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
-    if (rc == BBMAP_OK && hipMalloc(&c->d_stats, bbidx::STAT_SHARDS * 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
-    if (rc == BBMAP_OK && (hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess)) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipEventCreate failed");
+    if (rc == BBMAP_OK) rc = bbidx_finish_create(c, hs, hsi);
     if (rc != BBMAP_OK) { bbidx_destroy(c); return rc; }
     *out = c;
     return BBMAP_OK;

@@ -280,8 +280,70 @@ SITE_DTYPE = np.dtype([("chrom", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("
 assert C.sizeof(bbidx_params) == 88 and READ_DTYPE.itemsize == 24 and SITE_DTYPE.itemsize == 100
 
 
+class BuiltIndexInfo:
+    """What the rest of the Python plumbing needs to know about an index that was built on the device (bbidx_build):
+    the chromosomes (host copies, for reference blobs and oracles), k, chromBits and the derived tunables."""
+
+    def __init__(self, chroms, k, chromBits, params):
+        self.chroms, self.k, self.chromBits, self.params = chroms, k, chromBits, params
+        self.nchroms = len(chroms)
+        self.nblocks = (self.nchroms >> chromBits) + 1
+
+
 class DeviceIndex:
-    """Uploads a HostIndex to the GPU (bbidx_create) and runs batched probes."""
+    """Uploads a HostIndex to the GPU (bbidx_create) -- or builds the index there (DeviceIndex.build) -- and runs
+    batched probes."""
+
+    @classmethod
+    def build(cls, chroms, k=13, chromBits=None, device=0):
+        """IndexMaker4 + analyzeIndex on the device (bbidx_build); returns a DeviceIndex whose .host is a BuiltIndexInfo."""
+        self = cls.__new__(cls)
+        self.L = _lib.load()
+        arrs = [np.ascontiguousarray(np.frombuffer(bytes(c), np.uint8)) if not isinstance(c, np.ndarray)
+                else np.ascontiguousarray(c, dtype=np.uint8) for c in chroms]
+        ptrs = (C.c_void_p * (len(arrs) + 1))(*([0] + [a.ctypes.data for a in arrs]))
+        lens = np.array([0] + [len(a) for a in arrs], np.int32)
+        h = C.c_void_p()
+        self.L.bbidx_build.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p,
+                                       C.POINTER(C.c_void_p)]
+        self.L.bbidx_build.restype = C.c_int
+        _lib.check(self.L.bbidx_build(device, k, -1 if chromBits is None else chromBits, len(arrs), ptrs, lens.ctypes.data,
+                                      C.byref(h)), "bbidx_build")
+        self.h = h
+        self._bind()
+        p = bbidx_params()
+        _lib.check(self.L.bbidx_get_params(self.h, C.byref(p)), "bbidx_get_params")
+        params = {n: int(getattr(p, n)) for n, _ in bbidx_params._fields_}
+        self.host = BuiltIndexInfo(arrs, k, params["chromBits"], params)
+        return self
+
+    def export_block(self, block=0):
+        """(starts, sites, counts, lengthHistogram) of one block, copied back from the device."""
+        nkeys = 1 << (2 * self.host.k)
+        starts = np.zeros(nkeys + 1, np.int32)
+        counts = np.zeros(nkeys, np.int32)
+        hist = np.zeros(1001, np.int32)
+        _lib.check(self.L.bbidx_export_block(self.h, block, starts.ctypes.data, None, 0, counts.ctypes.data, hist.ctypes.data),
+                   "bbidx_export_block")
+        sites = np.zeros(max(1, int(starts[nkeys])), np.int32)
+        _lib.check(self.L.bbidx_export_block(self.h, block, None, sites.ctypes.data, len(sites), None, None), "bbidx_export_block")
+        return starts, sites[: int(starts[nkeys])], counts, hist
+
+    def _bind(self):
+        L = self.L
+        L.bbidx_destroy.argtypes = [C.c_void_p]
+        L.bbidx_find_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
+        L.bbidx_find_batch.restype = C.c_int
+        L.bbidx_find_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.bbidx_find_batch_device.restype = C.c_int
+        L.bbidx_set_kernel.argtypes = [C.c_void_p, C.c_int32]
+        L.bbidx_set_kernel.restype = C.c_int
+        L.bbidx_get_params.argtypes = [C.c_void_p, C.POINTER(bbidx_params)]
+        L.bbidx_get_params.restype = C.c_int
+        L.bbidx_export_block.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.bbidx_export_block.restype = C.c_int
 
     def __init__(self, host, device=0):
         self.L = _lib.load()
@@ -313,8 +375,7 @@ class DeviceIndex:
         self.L.bbidx_find_batch_device.restype = C.c_int
         _lib.check(self.L.bbidx_create(device, C.byref(d), C.byref(h)), "bbidx_create")
         self.h = h
-        self.L.bbidx_set_kernel.argtypes = [C.c_void_p, C.c_int32]
-        self.L.bbidx_set_kernel.restype = C.c_int
+        self._bind()
 
     def set_kernel(self, kind):
         """kind: "auto" (one read per wavefront, per-lane kernel for the reads that do not fit) or "lane"."""

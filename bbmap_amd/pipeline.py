@@ -19,8 +19,13 @@ class MapPipeline:
                  max_columns=256, pad=4, min_ratio=0.56):
         self.L = _lib.load()
         self.dev = torch.device("cuda", device)
+        # host_index: a HostIndex (arrays built on the host, uploaded by bbidx_create) or an already built DeviceIndex
+        if isinstance(host_index, DeviceIndex):
+            self.di = host_index
+            host_index = self.di.host
+        else:
+            self.di = DeviceIndex(host_index, device)
         self.hi = host_index
-        self.di = DeviceIndex(host_index, device)
         self.n, self.read_len, self.max_sites, self.pad, self.min_ratio = n_reads, read_len, max_sites, pad, min_ratio
         self.max_columns = max_columns
         max_rows = ((read_len + 31) // 32) * 32

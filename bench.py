@@ -161,7 +161,7 @@ def main():
     import torch
     from bbmap_amd import msa as M
     from bbmap_amd import workload as W
-    from bbmap_amd.index import HostIndex
+    from bbmap_amd.index import DeviceIndex
     from bbmap_amd.pipeline import MapPipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,9 +193,11 @@ def main():
 
     n = args.reads
     t_ix = time.perf_counter()
-    hi = HostIndex([ref], k=k, backend="torch", device=local_rank)
+    di = DeviceIndex.build([ref], k=k, device=local_rank)          # IndexMaker4 + analyzeIndex on the device (bbidx_build)
+    torch.cuda.synchronize()
     t_ix = time.perf_counter() - t_ix
-    pipe = MapPipeline(hi, n, read_len, offsets, key_scores, device=local_rank, max_sites=max_sites, max_columns=max_cols)
+    hi = di.host
+    pipe = MapPipeline(di, n, read_len, offsets, key_scores, device=local_rank, max_sites=max_sites, max_columns=max_cols)
     pipe.load_reads(reads)
 
     for _ in range(args.warmup):

@@ -264,6 +264,21 @@ int bbidx_find_batch(bbidx_ctx *ctx, int64_t n_reads, const bbidx_read *reads,
  * reference bytes compared, site records written}. */
 int bbidx_last_stats(bbidx_ctx *ctx, int64_t *stats5, float *kernel_ms);
 
+/* Index construction on the device: align2.IndexMaker4 (current/align2/IndexMaker4.java:303-421: count -> prefix sum ->
+ * fill, lists in genome order) + BBIndex.analyzeIndex (current/align2/BBIndex.java:101-191: COUNTS, clumpy keys, length
+ * histogram, MAX_USABLE_LENGTH) + the genome-size tuning of BBMap.loadIndex (current/align2/BBMap.java:367-381).
+ * chromArr[1..nchroms] are host pointers to the chromosome byte arrays (entry 0 unused); chromBits < 0 = automatic
+ * (BBMap.java:317-321).  The result is a ready-to-probe context; nothing but a few thousand histogram counters visits the
+ * host. */
+int bbidx_build(int32_t device, int32_t k, int32_t chromBits, int32_t nchroms,
+                const uint8_t *const *chromArr, const int32_t *chromArrLen, bbidx_ctx **out);
+/* The tunables a context works with (derived by bbidx_build, or as given to bbidx_create). */
+int bbidx_get_params(bbidx_ctx *ctx, bbidx_params *out);
+/* Copies one block's arrays back to the host (any pointer may be NULL): starts 4^k+1 ints, sites starts[4^k] ints
+ * (sites_cap = capacity of the buffer), counts 4^k ints, lengthHistogram 1001 ints. */
+int bbidx_export_block(bbidx_ctx *ctx, int32_t block, int32_t *starts, int32_t *sites, int64_t sites_cap,
+                       int32_t *counts, int32_t *lengthHistogram);
+
 /* Which probe kernel a context launches.  AUTO (default): one read per wavefront (registers + LDS), with the
  * one-read-per-lane kernel taking the reads that do not fit it (more than 64 keys).  LANE: the per-lane kernel
  * for every read (any shape up to BBIDX_MAX_KEYS / BBIDX_MAX_READ_LEN; kept as the cross-check). */

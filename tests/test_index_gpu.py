@@ -84,3 +84,28 @@ def test_dense_repeats_long_lists():
     reads = make_reads(13, genomes, 400, k=11)
     run_case(genomes, 11, None, reads, cap=160)
     run_case(genomes, 11, None, reads[:200], tweak={"maxUsableLength": 4000, "maxUsableLength2": 8000}, cap=24)
+
+
+def test_device_build_matches_host_builder():
+    """bbidx_build (emit -> radix sort -> scan -> COUNTS / clumpy / histogram / tunables on the device) against the numpy
+    builder array by array, then probes through the device-built index against the oracle."""
+    import numpy as np
+    genomes = [make_genome(81, 120000), make_genome(82, 70000), make_genome(83, 40000)]
+    for k, cb in ((12, None), (10, 1)):
+        hi = HostIndex(genomes, k=k, chromBits=cb, backend="numpy")
+        di = DeviceIndex.build(genomes, k=k, chromBits=cb)
+        assert di.host.chromBits == hi.chromBits and di.host.nblocks == hi.nblocks
+        for b in range(hi.nblocks):
+            starts, sites, counts, hist = di.export_block(b)
+            assert np.array_equal(starts, hi.starts[b])
+            assert np.array_equal(sites, hi.sites[b])
+            assert np.array_equal(counts, hi.counts)
+            assert np.array_equal(hist, hi.length_histogram)
+        for name, val in hi.params.items():
+            assert di.host.params[name] == int(val), name
+        oi = OracleIndex(genomes, k=k, chromBits=cb)
+        reads = make_reads(14, genomes, 200, k=k)
+        got = di.find_batch([(bp, bs, ks, offs) for bp, bm, bs, ks, offs, t in reads], max_sites=48)
+        for (bp, bm, bs, ks, offs, t), g in zip(reads, got):
+            assert g == oi.find(bp, bm, bs, ks, offs, cap=48)
+        di.close()
