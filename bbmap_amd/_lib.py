@@ -13,7 +13,7 @@ SO_PATH = os.path.join(HERE, "libbbmap_amd.so")
 EXPORTS = [
     "bbmap_last_error", "bbmap_abi_version",
     "bbmsa_create", "bbmsa_destroy", "bbmsa_align_batch_device", "bbmsa_align_batch",
-    "bbmsa_last_kernel_ms", "bbmsa_last_kernel_ms3", "bbmsa_last_counts", "bbmsa_align_gapped_batch_device", "bbmsa_align_gapped_batch",
+    "bbmsa_fill_packed", "bbmsa_last_kernel_ms", "bbmsa_last_kernel_ms3", "bbmsa_last_counts", "bbmsa_align_gapped_batch_device", "bbmsa_align_gapped_batch",
     "bbband_create", "bbband_destroy", "bbband_align_batch_device", "bbband_align_batch",
     "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch", "bbidx_last_stats", "bbidx_set_kernel", "bbidx_build", "bbidx_get_params", "bbidx_export_block",
     "bbpipe_revcomp_device", "bbpipe_select_jobs_device", "bbpipe_quick_rescue_device",
@@ -90,6 +90,9 @@ def load():
     L.bbmsa_align_gapped_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
     L.bbmsa_align_gapped_batch.restype = C.c_int
+    L.bbmsa_fill_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
+    L.bbmsa_fill_packed.restype = C.c_int
     L.bbmsa_last_kernel_ms3.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.bbmsa_last_kernel_ms3.restype = C.c_int
     L.bbmsa_last_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]

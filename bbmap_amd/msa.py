@@ -87,6 +87,19 @@ class MSAContext:
         _lib.check(rc, "bbmsa_align_gapped_batch")
         return res, match
 
+    def fill_packed(self, read, ref, a, b, minScore, limited, packed):
+        """The legacy per-call fill: writes the planes into `packed` (int32 array of 3*(maxRows+1)*(maxColumns+1)).
+        Returns (result[5], iterations)."""
+        r = np.frombuffer(bytes(read), np.uint8)
+        f = np.frombuffer(bytes(ref), np.uint8)
+        res = np.zeros(5, np.int32)
+        it = C.c_int64(0)
+        rc = self.L.bbmsa_fill_packed(self.h, r.ctypes.data, len(r), f.ctypes.data, len(f), a, b, minScore,
+                                      FILL_LIMITED_RAW if limited else FILL_UNLIMITED_RAW, res.ctypes.data, C.byref(it),
+                                      packed.ctypes.data)
+        _lib.check(rc, "bbmsa_fill_packed")
+        return res.tolist(), it.value
+
     # -- device buffers (torch tensors or raw pointers) --------------------------------------
     def align_batch_device(self, n_jobs, jobs_ptr, reads_ptr, refs_ptr, results_ptr, match_ptr=0,
                            match_stride=0, stream=0):

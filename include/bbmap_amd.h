@@ -114,6 +114,16 @@ int bbmsa_align_batch(bbmsa_ctx *ctx, int64_t n_jobs, const bbmsa_job *jobs,
                       const uint8_t *refs, int64_t refs_bytes,
                       bbmsa_result *results, uint8_t *match, int32_t match_stride);
 
+/* Legacy per-call shape: ONE raw fill (mode = BBMSA_FILL_LIMITED_RAW or BBMSA_FILL_UNLIMITED_RAW) that also writes the
+ * three score planes into the caller's `packed` array exactly where the reference's native code leaves them
+ * (state * (maxRows+1)*(maxColumns+1) + row * (maxColumns+1) + col; jni/MultiStateAligner11tsJNI.c:124-127, :707-812), so
+ * that the unmodified Java score2 / traceback2 (current/align2/MultiStateAligner11tsJNI.java:376-658) can read them.  This
+ * is what a drop-in Java_align2_MultiStateAligner11tsJNI_fill*JNI symbol calls; it copies
+ * 12 bytes per matrix cell back per call and is slow by construction.  `*iterations` is incremented. */
+int bbmsa_fill_packed(bbmsa_ctx *ctx, const uint8_t *read, int32_t read_len, const uint8_t *ref, int32_t ref_len,
+                      int32_t refStartLoc, int32_t refEndLoc, int32_t minScore, int32_t mode,
+                      int32_t *result5, int64_t *iterations, int32_t *packed);
+
 /* Gapped reference windows: job i is MSA.fillAndScoreLimited(read, ref, refStartLoc, refEndLoc, minScore, gaps)
  * (current/align2/MSA.java:103-134) for a SiteScore that carries a gap array.  When gaps[i].ngaps > 0 the library
  * builds the gapped reference (MultiStateAligner11tsJNI.makeGref, current/align2/MultiStateAligner11tsJNI.java:

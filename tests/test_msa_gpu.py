@@ -217,3 +217,50 @@ def test_gapped_reference_jobs():
             tb = om.traceback(p[0], p[1], max(0, p[2]), min(len(p[1]) - 1, p[3]), mx[0], mx[1], mx[2], gapped=p[5] is not None)
             assert g["match"] == tb
     assert nonnull > 30
+
+
+def test_legacy_packed_matrix_feeds_the_java_walkers():
+    """bbmsa_fill_packed: the planes land in the Java layout; score2 / traceback2 (the oracle's restatement of the Java
+    walkers, which read `packed`) run on OUR matrix and must give what they give on the oracle's own fill."""
+    import ctypes as C
+    import random
+    import numpy as np
+    from oracle.oracle import OracleMSA
+    rng = random.Random(91)
+    maxRows, maxCols = 160, 300
+    ctx = M.MSAContext(maxRows=maxRows, maxColumns=maxCols)
+    ref = bytes(rng.choice(b"ACGT") for _ in range(3000))
+    n_int = 3 * (maxRows + 1) * (maxCols + 1)
+    done = 0
+    for i in range(24):
+        L = rng.choice([60, 100, 150])
+        st = rng.randrange(50, 2500)
+        rd = bytearray(ref[st:st + L + 10])
+        if i % 3 == 1:
+            rd[rng.randrange(L)] = ord("N")
+            rd[rng.randrange(L)] = rng.choice(b"ACGT")
+        if i % 3 == 2:
+            del rd[L // 2:L // 2 + rng.randint(1, 6)]
+        rd = bytes(rd[:L])
+        a, b = st - 4, st + L + 8
+        limited = i % 4 != 3
+        ms = int(0.5 * (70 + 100 * (L - 1)))
+        om = OracleMSA(maxRows, maxCols)
+        if limited:
+            exp, exp_it = om.fill_limited_raw(rd, ref, a, b, ms)
+        else:
+            exp, exp_it = om.fill_unlimited_raw(rd, ref, a, b)
+            exp = exp + [0]
+        packed = np.zeros(n_int, np.int32)
+        got, it = ctx.fill_packed(rd, ref, a, b, ms, limited, packed)
+        assert got[:4] == exp[:4] and (not limited or got[4] == exp[4]) and it == exp_it
+        if limited and exp[4] == 1:
+            continue
+        want_score = om.score(rd, ref, a, b, exp[0], exp[1], exp[2])
+        want_tb = om.traceback(rd, ref, a, b, exp[0], exp[1], exp[2])
+        # same walkers, our matrix: overwrite the oracle's packed with the planes the GPU produced
+        C.memmove(om.s.packed, packed.ctypes.data, n_int * 4)
+        assert om.score(rd, ref, a, b, got[0], got[1], got[2]) == want_score
+        assert om.traceback(rd, ref, a, b, got[0], got[1], got[2]) == want_tb
+        done += 1
+    assert done > 12
