@@ -109,6 +109,9 @@ static void *map_worker(void *p) {
     map_arg *w = (map_arg *)p;
     const int L = w->L;
     orc_msa *m = orc_msa_new(((L + 31) / 32) * 32, w->maxColumns);
+    orc_msa *mg = NULL;                       /* wider aligner for sites with gap arrays (gapped references), made on demand */
+    const int gapColumns = w->maxColumns > 1024 ? w->maxColumns : 1024;
+    uint8_t *msg = NULL;
     uint8_t *bm = (uint8_t *)malloc((size_t)L), *ms = (uint8_t *)malloc((size_t)L + w->maxColumns + 64);
     int8_t *bs = (int8_t *)calloc((size_t)L, 1);
     const uint8_t *ref = w->ix->chromArr[1];
@@ -138,11 +141,22 @@ static void *map_worker(void *p) {
             int ok = near > 0;
             if ((force ? -near : near) < 1) {
                 for (int s = 0; s < ns; s++) {
-                    if (!(sw[s] < maxImp && !sites[s].semiperfect) || sites[s].ngaps > 0) continue;
+                    if (!(sw[s] < maxImp && !sites[s].semiperfect)) continue;
                     const uint8_t *bases = sites[s].strand ? bm : bp;
                     const uint8_t *c = w->ix->chromArr[sites[s].chrom];
                     const int clen = w->ix->chromArrLen[sites[s].chrom];
                     int32_t sc[8], mx[4];
+                    if (sites[s].ngaps > 0) {             /* MSA.fillAndScoreLimited(..., gaps) + traceback(gapped) */
+                        if (!mg) { mg = orc_msa_new(((L + 31) / 32) * 32, gapColumns); msg = (uint8_t *)malloc((size_t)L + gapColumns + 64 + 128 * 16); }
+                        const int ga = sites[s].start - 4, gb = sites[s].stop + 4;
+                        const int gmin = sw[s] > minMsaLimit ? sw[s] : minMsaLimit;
+                        w->dpJobs++;
+                        if (orc_fill_and_score_limited(mg, bases, L, c, clen, ga, gb, gmin, sites[s].gaps, sites[s].ngaps, sc, mx)) {
+                            ok = 1;
+                            orc_traceback(mg, bases, c, ga < 0 ? 0 : ga, gb > clen - 1 ? clen - 1 : gb, mx[0], mx[1], mx[2], 1, msg, L + gapColumns + 64 + 128 * 16);
+                        }
+                        continue;
+                    }
                     int a = sites[s].start - 4, b = sites[s].stop + 4;
                     if (b - a + 1 > w->maxColumns) b = a + w->maxColumns - 1;
                     const int minscore = sw[s] > minMsaLimit ? sw[s] : minMsaLimit;
@@ -158,6 +172,7 @@ static void *map_worker(void *p) {
     }
     (void)ref; (void)reflen;
     w->cells = m->iterationsLimited + m->iterationsUnlimited;
+    if (mg) { w->cells += mg->iterationsLimited + mg->iterationsUnlimited; orc_msa_free(mg); free(msg); }
     free(bm); free(ms); free(bs);
     orc_msa_free(m);
     return NULL;
