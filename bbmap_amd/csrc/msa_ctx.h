@@ -19,6 +19,12 @@ struct bbmsa_ctx {
     int genThreads;
     int *d_matrix;
     int *d_limits;
+    // wide pass: the wavefront kernel again, 64 lanes per job and one job per 64-thread block, with an LDS column buffer as
+    // wide as maxColumns, for the jobs the first pass found too wide for its own buffer (0 blocks = not needed)
+    int wideR, wideCols, wideTmpBytes, wideBlocks, wideLdsBytes;
+    long long wideDirSlotDwords;
+    unsigned int *d_wideDir;
+    int *d_slowList2;
     // narrow-window kernel (msa_fill_narrow.hip): one job per lane
     int narrowBlocks, narrowSlack;     // 0 blocks = disabled
     unsigned long long *d_narrowDir;

@@ -113,6 +113,26 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     c->genThreads = (int)threads;
     HIP_TRY(hipMalloc(&c->d_matrix, (size_t)(threads * perThread)));
     HIP_TRY(hipMalloc(&c->d_limits, (size_t)(threads * (cfg->maxRows + cfg->maxColumns + 4) * 4)));
+    // wide pass geometry (only when some windows can exceed the first pass's column buffer)
+    c->wideBlocks = 0;
+    if (cfg->maxColumns > fastCols) {
+        c->wideR = (cfg->maxRows + 63) / 64;
+        c->wideCols = cfg->maxColumns;
+        c->wideTmpBytes = ((64 * c->wideR + c->wideCols + 8) + 3) & ~3;
+        const int perJob = (c->wideCols + 2) * 2 + c->wideTmpBytes / 4;
+        c->wideLdsBytes = (bbmsa::kLdsTableInts + perJob) * 4;
+        const void *wfn = bbmsa::fast_kernel_for(c->wideR, c->banded);
+        if (wfn && c->wideLdsBytes <= 160 * 1024) {
+            if (c->wideLdsBytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(wfn, hipFuncAttributeMaxDynamicSharedMemorySize, c->wideLdsBytes));
+            int per = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, wfn, 64, c->wideLdsBytes));
+            if (per < 1) per = 1;
+            if (per > 8) per = 8;
+            c->wideBlocks = c->numCUs * per;
+            c->wideDirSlotDwords = (long long)(((c->wideCols + 64 - 1) >> 3) + 1) * c->wideR * 64;
+            HIP_TRY(hipMalloc(&c->d_wideDir, (size_t)((long long)c->wideBlocks * c->wideDirSlotDwords * 4)));
+        }
+    }
     // narrow-window kernel: only without a band (a band changes the window rule); BBMSA_NARROW=0 disables it
     c->narrowBlocks = 0;
     c->narrowSlack = env_int("BBMSA_NARROW_SLACK", 2000);
@@ -137,6 +157,8 @@ extern "C" void bbmsa_destroy(bbmsa_ctx *c) {
     if (c->d_slowList) (void)hipFree(c->d_slowList);
     if (c->d_matrix) (void)hipFree(c->d_matrix);
     if (c->d_limits) (void)hipFree(c->d_limits);
+    if (c->d_wideDir) (void)hipFree(c->d_wideDir);
+    if (c->d_slowList2) (void)hipFree(c->d_slowList2);
     if (c->d_narrowDir) (void)hipFree(c->d_narrowDir);
     if (c->d_fastList) (void)hipFree(c->d_fastList);
     if (c->d_gref) (void)hipFree(c->d_gref);
@@ -158,7 +180,9 @@ extern "C" int bbmsa_align_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_j
     HIP_TRY(hipSetDevice(c->device));
     if (n_jobs > c->slowCap) {
         if (c->d_slowList) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_slowList)); c->d_slowList = nullptr; }
+        if (c->d_slowList2) { HIP_TRY(hipFree(c->d_slowList2)); c->d_slowList2 = nullptr; }
         HIP_TRY(hipMalloc(&c->d_slowList, (size_t)n_jobs * 4));
+        if (c->wideBlocks > 0) HIP_TRY(hipMalloc(&c->d_slowList2, (size_t)n_jobs * 4));
         c->slowCap = n_jobs;
     }
     if (c->narrowBlocks > 0 && n_jobs > c->fastCap) {
@@ -199,11 +223,25 @@ extern "C" int bbmsa_align_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_j
     if (blocks > c->blocks) blocks = c->blocks;
     void *args[] = {&fp};
     HIP_TRY(hipLaunchKernel(bbmsa::fast_kernel_for(c->R, c->banded), dim3((unsigned)blocks), dim3(256), args, (size_t)c->ldsBytes, stream));
+    const int *genList = c->d_slowList;
+    const unsigned int *genCount = c->d_counters + 1;
+    if (c->wideBlocks > 0) {
+        // wide pass over the first pass's hand-overs; what it cannot take either (banded rows with holes) goes on to the
+        // generic kernel through the second list ([7] = its count, [8] = wide queue)
+        bbmsa::FillParams wp = fp;
+        wp.queue = c->d_counters + 8; wp.dirbuf = c->d_wideDir; wp.dir_slot_dwords = c->wideDirSlotDwords;
+        wp.list = c->d_slowList; wp.list_count = c->d_counters + 1;
+        wp.slow_list = c->d_slowList2; wp.slow_count = c->d_counters + 7;
+        wp.lanesPerJob = 64; wp.fastCols = c->wideCols; wp.tmpBytes = c->wideTmpBytes;
+        void *wargs[] = {&wp};
+        HIP_TRY(hipLaunchKernel(bbmsa::fast_kernel_for(c->wideR, c->banded), dim3((unsigned)c->wideBlocks), dim3(64), wargs, (size_t)c->wideLdsBytes, stream));
+        genList = c->d_slowList2; genCount = c->d_counters + 7;
+    }
     HIP_TRY(hipEventRecord(c->ev[1], stream));
 
     bbmsa::GenericParams gp;
     gp.jobs = jobs; gp.reads = reads; gp.refs = refs; gp.results = results; gp.match = match;
-    gp.list = c->d_slowList; gp.list_count = c->d_counters + 1; gp.njobs = n_jobs;
+    gp.list = genList; gp.list_count = genCount; gp.njobs = n_jobs;
     gp.matrix = c->d_matrix; gp.limits = c->d_limits; gp.queue = c->d_counters + 2;
     gp.match_stride = match_stride; gp.maxRows = c->cfg.maxRows; gp.maxColumns = c->cfg.maxColumns;
     gp.bandwidth = c->cfg.bandwidth; gp.bandwidthRatio = c->cfg.bandwidthRatio;
@@ -242,7 +280,7 @@ extern "C" int bbmsa_last_counts(bbmsa_ctx *c, int64_t *counts4) {
     HIP_TRY(hipEventSynchronize(c->ev[2]));
     unsigned h[16];
     HIP_TRY(hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
-    counts4[0] = h[5]; counts4[1] = h[6]; counts4[2] = c->narrowBlocks > 0 ? h[4] : 0; counts4[3] = h[1];
+    counts4[0] = h[5]; counts4[1] = h[6]; counts4[2] = c->narrowBlocks > 0 ? h[4] : 0; counts4[3] = c->wideBlocks > 0 ? h[7] : h[1];
     return BBMAP_OK;
 }
 

@@ -62,7 +62,10 @@ class MapPipeline:
         # second job list: sites whose index hit spans a long deletion (gap arrays) align against a gapped reference
         # (makeGref) that can be much wider than an ordinary window, so they get their own, wider MSA context
         self.gap_cap = max(1024, n_reads // 16)
-        self.gap_columns = max(1024, max_columns)
+        # BBMap's own maxColumns (BBMapThread.java:27-28); windows beyond the first pass's 1024-column LDS buffer (a handful
+        # per million reads) are taken by the context's wide pass
+        self.gap_columns = max(3000, max_columns)
+        self.gap_fast_cols = max(1024, max_columns)
         self.msa_gapped = None
         self.gjobs = torch.zeros(self.gap_cap * M.JOB_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
         self.ggaps = torch.zeros(self.gap_cap * M.GAPS_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
@@ -116,7 +119,7 @@ class MapPipeline:
             if self.msa_gapped is None:
                 # fast_cols = the whole width: a gapped window that falls to the one-thread-per-job generic kernel costs ~1 ms
                 self.msa_gapped = M.MSAContext(maxRows=self.max_rows, maxColumns=self.gap_columns, device=self.dev.index or 0,
-                                               fast_cols=self.gap_columns, lanes_per_job=int(__import__('os').environ.get('BBPIPE_GAPPED_LANES', '64')))
+                                               fast_cols=self.gap_fast_cols, lanes_per_job=int(__import__('os').environ.get('BBPIPE_GAPPED_LANES', '64')))
             rc = L.bbmsa_align_gapped_batch_device(self.msa_gapped.h, C.c_void_p(stream), ngap, self.gjobs.data_ptr(),
                                                    self.ggaps.data_ptr(), plus, self.refs.data_ptr(), self.gresults.data_ptr(),
                                                    self.gmatch.data_ptr(), self.gmatch_stride)

@@ -110,7 +110,7 @@ static void *map_worker(void *p) {
     const int L = w->L;
     orc_msa *m = orc_msa_new(((L + 31) / 32) * 32, w->maxColumns);
     orc_msa *mg = NULL;                       /* wider aligner for sites with gap arrays (gapped references), made on demand */
-    const int gapColumns = w->maxColumns > 1024 ? w->maxColumns : 1024;
+    const int gapColumns = w->maxColumns > 3000 ? w->maxColumns : 3000;   /* BBMap's maxColumns, as the GPU pipeline's gapped context */
     uint8_t *msg = NULL;
     uint8_t *bm = (uint8_t *)malloc((size_t)L), *ms = (uint8_t *)malloc((size_t)L + w->maxColumns + 64);
     int8_t *bs = (int8_t *)calloc((size_t)L, 1);

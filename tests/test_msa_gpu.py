@@ -264,3 +264,31 @@ def test_legacy_packed_matrix_feeds_the_java_walkers():
         assert om.traceback(rd, ref, a, b, got[0], got[1], got[2]) == want_tb
         done += 1
     assert done > 12
+
+
+def test_wide_pass_takes_windows_beyond_the_first_column_buffer():
+    """Windows wider than the first pass's LDS buffer (fast_cols) run in the wide pass (64 lanes per job, buffer as wide as
+    maxColumns), not in the one-thread-per-job generic kernel; results are the same bits."""
+    import random
+    from oracle.oracle import OracleMSA
+    rng = random.Random(123)
+    ref = bytes(rng.choice(b"ACGT") for _ in range(6000))
+    probs = []
+    for i in range(40):
+        L = rng.choice([100, 150])
+        st = rng.randrange(100, 2000)
+        rd = bytearray(ref[st:st + L])
+        for _ in range(rng.randint(0, 4)):
+            rd[rng.randrange(L)] = rng.choice(b"ACGT")
+        width = rng.choice([300, 700, 1500, 2600])                  # 300 fits the first pass, the others do not
+        probs.append((bytes(rd), ref, st - rng.randrange(0, 50), st + width, int(0.4 * (70 + 100 * (L - 1)))))
+    al = M.MultiStateAligner11ts(maxRows=160, maxColumns=3000, fast_cols=512)
+    got = al.align(probs)
+    om = OracleMSA(160, 3000)
+    for p, g in zip(probs, got):
+        sv, mx = om.fillAndScoreLimited(*p)
+        assert g["score"] == sv
+        if sv is not None:
+            assert g["match"] == om.traceback(p[0], p[1], max(0, p[2]), p[3], mx[0], mx[1], mx[2])
+    counts = al.ctx.last_counts()
+    assert counts["generic"] == 0, counts

@@ -38,7 +38,7 @@ def test_pipeline_matches_emulation():
     assert len(by_src) == njobs
     by_gsrc = {int(s): i for i, s in enumerate(out["gsrc"])}
     assert len(by_gsrc) == cnt[2]
-    omg = OracleMSA(160, 1024)
+    omg = OracleMSA(160, 3000)
     checked_jobs = checked_gapped = 0
     for r in range(600):
         bp = reads[r * L:(r + 1) * L].tobytes()
