@@ -97,15 +97,27 @@ __global__ void zero_clumpy(const unsigned *clump, const int *countsIn, int *cou
     const int ln = countsIn[key];
     if (ln > 2000 && (float)cc > __fmul_rn(0.75f, (float)ln)) { countsOut[key] = 0; countsOut[rc_key((int)key, k)] = 0; }
 }
+// grid-stride: one atomic per wave at the very end
 __global__ void max_kernel(const int *v, long long n, int *out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int m = i < n ? v[i] : 0;
+    int m = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = max(m, v[i]);
     for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
 }
-__global__ void bincount_kernel(const int *v, long long n, unsigned long long *bins) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&bins[v[i]], 1ull);
+// Histogram of COUNTS.  Almost every key of a small genome has count 0 (never needed: the histogram weights a bin by its
+// value) or a tiny count, so the low bins are first accumulated per block in LDS; only long lists hit global atomics.
+constexpr int BIN_LDS = 2048;
+__global__ void bincount_kernel(const int *v, long long n, unsigned long long *bins, int nbins) {
+    __shared__ unsigned low[BIN_LDS];
+    for (int i = threadIdx.x; i < BIN_LDS; i += blockDim.x) low[i] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = v[i];
+        if (x <= 0) continue;
+        if (x < BIN_LDS) atomicAdd(&low[x], 1u); else atomicAdd(&bins[x], 1ull);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BIN_LDS && i < nbins; i += blockDim.x) if (low[i]) atomicAdd(&bins[i], (unsigned long long)low[i]);
 }
 
 }  // namespace bbidxb
@@ -273,13 +285,13 @@ extern "C" int bbidx_build(int32_t device, int32_t k, int32_t chromBits, int32_t
         hipLaunchKernelGGL(bbidxb::combine_counts, dim3(kb), dim3(256), 0, nullptr, d_total, d_countsRaw, k, nkeys);
         BHIP(hipMemcpy(d_counts, d_countsRaw, (size_t)nkeys * 4, hipMemcpyDeviceToDevice));
         hipLaunchKernelGGL(bbidxb::zero_clumpy, dim3(kb), dim3(256), 0, nullptr, d_clump, d_countsRaw, d_counts, k, nkeys);
-        hipLaunchKernelGGL(bbidxb::max_kernel, dim3(kb), dim3(256), 0, nullptr, d_counts, nkeys, d_max);
+        hipLaunchKernelGGL(bbidxb::max_kernel, dim3(2048), dim3(256), 0, nullptr, d_counts, nkeys, d_max);
         BHIP(hipGetLastError());
         int mx = 0;
         BHIP(hipMemcpy(&mx, d_max, 4, hipMemcpyDeviceToHost));
         BHIP(hipMalloc(&d_bins, (size_t)(mx + 1) * 8));
         BHIP(hipMemset(d_bins, 0, (size_t)(mx + 1) * 8));
-        hipLaunchKernelGGL(bbidxb::bincount_kernel, dim3(kb), dim3(256), 0, nullptr, d_counts, nkeys, d_bins);
+        hipLaunchKernelGGL(bbidxb::bincount_kernel, dim3(2048), dim3(256), 0, nullptr, d_counts, nkeys, d_bins, mx + 1);
         BHIP(hipGetLastError());
         std::vector<unsigned long long> bins((size_t)mx + 1);
         BHIP(hipMemcpy(bins.data(), d_bins, (size_t)(mx + 1) * 8, hipMemcpyDeviceToHost));

@@ -115,23 +115,19 @@ struct SelectParams {
     int *gjobSrc;
 };
 
-constexpr int SEL_WAVES = 4, SEL_READS_PER_WAVE = 8, SEL_CAP = 128;
+constexpr int SEL_WAVES = 4, SEL_READS_PER_WAVE = 16, SEL_CAP = 128;
 
 // One wavefront takes SEL_READS_PER_WAVE consecutive reads; the DP jobs it selects are parked in LDS as
 // (read * maxSites + site, minScore) and written out behind ONE reservation on the global job counter per flush.
 __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const SelectParams P) {
     __shared__ int pendSrc[SEL_WAVES][SEL_CAP], pendMin[SEL_WAVES][SEL_CAP];
-    __shared__ unsigned blockCnt[2];
+    __shared__ unsigned blockCnt[2], waveCnt[SEL_WAVES], blockBase;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x < 2) blockCnt[threadIdx.x] = 0;
     __syncthreads();
     int npend = 0;
     unsigned cDone = 0, cNoSite = 0;
-    auto flush = [&]() {
-        if (npend == 0) return;
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&P.counters[0], (unsigned)npend);
-        base = __builtin_amdgcn_readfirstlane(base);
+    auto write_jobs = [&](unsigned base) {
         for (int j = lane; j < npend; j += 64) {
             const int src = pendSrc[wave][j];
             const long long r = src / P.maxSites;
@@ -151,6 +147,12 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
         }
         wsync();
         npend = 0;
+    };
+    auto flush = [&]() {                                  // mid-run overflow of the parking area: reserve for this wave alone
+        if (npend == 0) return;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&P.counters[0], (unsigned)npend);
+        write_jobs(__builtin_amdgcn_readfirstlane(base));
     };
     const long long r0 = ((long long)blockIdx.x * SEL_WAVES + wave) * SEL_READS_PER_WAVE;
     for (int q = 0; q < SEL_READS_PER_WAVE; q++) {
@@ -223,11 +225,22 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
             wsync();
         }
     }
-    // make this wave's site updates visible to its own flush (same wave, program order) and write the jobs out
+    // one reservation on the global job counter per BLOCK (a single word takes ~88 returning atomics per microsecond:
+    // per-wave reservations alone cost more than the scoring), then every wave writes its parked jobs
     __threadfence_block();
-    flush();
-    if (lane == 0) { atomicAdd(&blockCnt[0], cDone); atomicAdd(&blockCnt[1], cNoSite); }
+    if (lane == 0) { waveCnt[wave] = (unsigned)npend; atomicAdd(&blockCnt[0], cDone); atomicAdd(&blockCnt[1], cNoSite); }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned total = 0;
+        for (int w = 0; w < SEL_WAVES; w++) total += waveCnt[w];
+        blockBase = total ? atomicAdd(&P.counters[0], total) : 0u;
+    }
+    __syncthreads();
+    {
+        unsigned base = blockBase;
+        for (int w = 0; w < wave; w++) base += waveCnt[w];
+        write_jobs(base);
+    }
     if (threadIdx.x < 2 && blockCnt[threadIdx.x]) atomicAdd(&P.counters[threadIdx.x == 0 ? 1 : 3], blockCnt[threadIdx.x]);
 }
 
