@@ -95,6 +95,7 @@ struct NarrowParams {
     int bandwidth;
     float bandwidthRatio;
     int maxSlack;                 // candidate filter: maxQuality(rows) - minScore (points) at most this
+    int tightSlack;               // BBMSA_NO_ITERATIONS jobs beyond maxSlack are first tried with minScore = maxQuality - this
 };
 
 struct GenericParams {

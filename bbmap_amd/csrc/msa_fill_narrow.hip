@@ -145,6 +145,7 @@ __global__ __launch_bounds__(64) void msa_fill_narrow_kernel(const NarrowParams 
         bbmsa_job jb;
         jb.read_off = 0; jb.ref_off = 0; jb.read_len = 0; jb.ref_len = 0; jb.refStartLoc = 0; jb.refEndLoc = -1; jb.minScore = 0; jb.flags = 0;
         int rows = 0, a = 0, b = -1, columns = 0, minScore = 0, mode = 0;
+        bool tight = false;
         for (;;) {
             const long long q = (long long)atomicAdd(p.queue, 1u);
             if (q >= p.njobs) break;
@@ -163,8 +164,17 @@ __global__ __launch_bounds__(64) void msa_fill_narrow_kernel(const NarrowParams 
                 if (tmin < 1 || (tcols + trows < 90) || (tcols > trows + min(170, trows + 20))) cand = false;
                 else tmin -= 120;
             }
-            if (cand) cand = (70 + 100 * (trows - 1)) - tmin <= p.maxSlack;
-            if (cand) { j = q; jb = t; rows = trows; a = ta; b = tb; columns = tcols; minScore = tmin; mode = tmode; break; }
+            bool ttight = false;
+            if (cand && (70 + 100 * (trows - 1)) - tmin > p.maxSlack) {
+                // Too much slack for a 16-diagonal window.  If the caller does not need the visited-cell count, try the fill
+                // with a TIGHTER minScore: the pruning of fillLimitedX is admissible (a cell is only dropped when no path
+                // through it can reach minScore), so whenever the best score turns out >= the tighter bound, every cell on
+                // every optimal path -- hence result[], score2 and traceback2 -- is what the looser bound gives; only
+                // `iterations` differs.  If the tighter fill fails, the job goes to the wavefront kernel with its own bound.
+                if ((t.flags & BBMSA_NO_ITERATIONS) && p.tightSlack > 0) { ttight = true; tmin = (70 + 100 * (trows - 1)) - p.tightSlack; }
+                else cand = false;
+            }
+            if (cand) { j = q; jb = t; rows = trows; a = ta; b = tb; columns = tcols; minScore = tmin; mode = tmode; tight = ttight; break; }
             const unsigned k = atomicAdd(p.fast_count, 1u);
             p.fast_list[k] = (int)q;
         }
@@ -323,6 +333,12 @@ __global__ __launch_bounds__(64) void msa_fill_narrow_kernel(const NarrowParams 
         else if (bScore < minScoreOff) { res1 = bCol; res2 = bState; res3 = bScore; res4 = 1; fillNull = true; }
         else { res1 = bCol; res2 = bState; res3 = bScore >> kScoreOffset; }
 
+        if (active && tight && fillNull) {                       // the tighter bound was too tight: redo with the job's own
+            active = false;
+            const unsigned k = atomicAdd(p.fast_count, 1u);
+            p.fast_list[k] = (int)j;
+            nLeft++;
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // direction words are written before the walk reads them
 
         // ------------------------------------------------------------------ score2 + traceback2 on the records, per lane
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(64) void msa_fill_narrow_kernel(const NarrowParams 
             bbmsa_result r;
             r.result[0] = rows; r.result[1] = res1; r.result[2] = res2; r.result[3] = res3; r.result[4] = res4;
             r.status = (fillNull && mode == BBMSA_FILL_LIMITED) ? BBMSA_ST_NULL : BBMSA_ST_OK;
-            r.iterations = iters;
+            r.iterations = tight ? -1 : iters;
             for (int i = 0; i < 8; i++) r.score[i] = 0;
             r.score_len = 0; r.match_len = 0; r.fill_kind = 0; r.columns = columns;
             if (!fillNull && (jb.flags & (BBMSA_DO_SCORE | BBMSA_DO_TRACEBACK))) {

@@ -110,6 +110,7 @@ struct SelectParams {
     int *jobSrc;                   // read * maxSites + site for each job
     unsigned int *counters;        // [0] jobs, [1] reads finished without DP, [2] gapped jobs (sites with gap arrays), [3] reads with no site
     int *noIndelScore;             // optional: per (read, site) ungapped score
+    int extraFlags;                // OR-ed into every job's flags (e.g. BBMSA_NO_ITERATIONS)
     bbmsa_job *gjobs;              // optional second list: jobs for sites that carry a gap array (need makeGref)
     bbmsa_gaps *ggaps;
     int *gjobSrc;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
             j_.read_len = rr.len; j_.ref_len = P.chromLen[ssj.chrom];
             j_.refStartLoc = start - P.pad; j_.refEndLoc = stop + P.pad;
             j_.minScore = pendMin[wave][j];
-            j_.flags = BBMSA_FILL_AND_SCORE_LIMITED | BBMSA_DO_TRACEBACK;
+            j_.flags = BBMSA_FILL_AND_SCORE_LIMITED | BBMSA_DO_TRACEBACK | P.extraFlags;
             P.jobs[base + j] = j_;
             P.jobSrc[base + j] = src;
         }
@@ -368,7 +369,7 @@ extern "C" int bbpipe_select_jobs_device(void *stream_, int64_t n_reads, const b
                                          const int64_t *chrom_off, const int32_t *chrom_len, const uint8_t *refs,
                                          int32_t pad, int32_t max_columns, float min_ratio,
                                          bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score,
-                                         bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src) {
+                                         bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src, int32_t extra_job_flags) {
     if (n_reads < 0 || max_sites < 1 || pad < 0 || max_columns < 1) { bbmap_set_error("bbpipe_select_jobs_device: bad size"); return BBMAP_E_ARG; }
     if (n_reads == 0) return BBMAP_OK;
     if (!reads || !bases || !nsites || !sites || !chrom_off || !chrom_len || !refs || !jobs || !job_src || !counters) {
@@ -385,6 +386,7 @@ extern "C" int bbpipe_select_jobs_device(void *stream_, int64_t n_reads, const b
         bbmap_set_error("bbpipe_select_jobs_device: the three gapped-list buffers go together"); return BBMAP_E_ARG;
     }
     P.gjobs = gapped_jobs; P.ggaps = gapped_gaps; P.gjobSrc = gapped_src;
+    P.extraFlags = extra_job_flags & BBMSA_NO_ITERATIONS;
     const long long per_block = bbpipe::SEL_WAVES * bbpipe::SEL_READS_PER_WAVE;
     const long long blocks = (n_reads + per_block - 1) / per_block;
     hipLaunchKernelGGL(bbpipe::select_jobs_kernel, dim3((unsigned)blocks), dim3(64 * bbpipe::SEL_WAVES), 0, stream, P);

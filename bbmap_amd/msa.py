@@ -17,6 +17,7 @@ FILL_LIMITED = 2
 CLAMP_WINDOW = 1 << 3
 DO_SCORE = 1 << 4
 DO_TRACEBACK = 1 << 5
+NO_ITERATIONS = 1 << 6
 FILL_AND_SCORE_LIMITED = FILL_LIMITED | CLAMP_WINDOW | DO_SCORE
 
 ST_OK, ST_NULL, ST_BAD_SHAPE = 0, 1, 2

@@ -16,7 +16,7 @@ from .index import READ_DTYPE, SITE_DTYPE, DeviceIndex
 
 class MapPipeline:
     def __init__(self, host_index, n_reads, read_len, offsets, key_scores, device=0, max_sites=8,
-                 max_columns=256, pad=4, min_ratio=0.56):
+                 max_columns=256, pad=4, min_ratio=0.56, no_iterations=False):
         self.L = _lib.load()
         self.dev = torch.device("cuda", device)
         # host_index: a HostIndex (arrays built on the host, uploaded by bbidx_create) or an already built DeviceIndex
@@ -28,6 +28,7 @@ class MapPipeline:
         self.hi = host_index
         self.n, self.read_len, self.max_sites, self.pad, self.min_ratio = n_reads, read_len, max_sites, pad, min_ratio
         self.max_columns = max_columns
+        self.no_iterations = no_iterations       # BBMSA_NO_ITERATIONS on every DP job (visited-cell counters not needed)
         max_rows = ((read_len + 31) // 32) * 32
         self.msa = M.MSAContext(maxRows=max_rows, maxColumns=max_columns, device=device)
         # reference blob = chromosomes back to back; chrom_off[c] = offset of chromosome c
@@ -97,35 +98,37 @@ class MapPipeline:
                                                self.chrom_off.data_ptr(), self.chrom_len.data_ptr(), self.refs.data_ptr(),
                                                self.pad, self.max_columns, self.min_ratio, self.jobs.data_ptr(),
                                                self.job_src.data_ptr(), self.counters.data_ptr(), self.no_indel.data_ptr(),
-                                               self.gjobs.data_ptr(), self.ggaps.data_ptr(), self.gjob_src.data_ptr()),
+                                               self.gjobs.data_ptr(), self.ggaps.data_ptr(), self.gjob_src.data_ptr(),
+                                               M.NO_ITERATIONS if self.no_iterations else 0),
                    "bbpipe_select_jobs_device")
         cnt = self.counters.cpu().numpy()                     # the one host round trip: how many DP jobs
         njobs = int(cnt[0])
         ngap = int(cnt[2])
         if ngap > self.gap_cap:
             raise RuntimeError("more gapped sites (%d) than the pipeline's gapped-job capacity (%d)" % (ngap, self.gap_cap))
-        # the few gapped-reference jobs (wide unlimited fills) go to a side stream so that they share the chip with the
-        # main DP launch instead of running behind it
+        # The gapped-reference jobs (a few thousand wide unlimited fills, plus a handful for the context's wide pass, whose
+        # single-job latency is ~1.5 ms) are submitted FIRST, on a side stream: their kernels take the chip for a moment,
+        # and their long, thin tail then runs underneath the main DP launch instead of behind it.
+        main_stream = stream
         side = None
-        if ngap and njobs and self.side_stream is not None:
-            side = self.side_stream
-            side.wait_stream(torch.cuda.current_stream())
-        if njobs:
-            self.msa.align_batch_device(njobs, self.jobs.data_ptr(), plus, self.refs.data_ptr(), self.results.data_ptr(),
-                                        self.match.data_ptr(), self.match_stride, stream)
         if ngap:
-            if side is not None:
+            if njobs and self.side_stream is not None:
+                side = self.side_stream
+                side.wait_stream(torch.cuda.current_stream())
                 stream = side.cuda_stream
             if self.msa_gapped is None:
-                # fast_cols = the whole width: a gapped window that falls to the one-thread-per-job generic kernel costs ~1 ms
                 self.msa_gapped = M.MSAContext(maxRows=self.max_rows, maxColumns=self.gap_columns, device=self.dev.index or 0,
-                                               fast_cols=self.gap_fast_cols, lanes_per_job=int(__import__('os').environ.get('BBPIPE_GAPPED_LANES', '64')))
+                                               fast_cols=self.gap_fast_cols,
+                                               lanes_per_job=int(__import__('os').environ.get('BBPIPE_GAPPED_LANES', '64')))
             rc = L.bbmsa_align_gapped_batch_device(self.msa_gapped.h, C.c_void_p(stream), ngap, self.gjobs.data_ptr(),
                                                    self.ggaps.data_ptr(), plus, self.refs.data_ptr(), self.gresults.data_ptr(),
                                                    self.gmatch.data_ptr(), self.gmatch_stride)
             _lib.check(rc, "bbmsa_align_gapped_batch_device")
-            if side is not None:
-                torch.cuda.current_stream().wait_stream(side)
+        if njobs:
+            self.msa.align_batch_device(njobs, self.jobs.data_ptr(), plus, self.refs.data_ptr(), self.results.data_ptr(),
+                                        self.match.data_ptr(), self.match_stride, main_stream)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         self.last_counters = cnt
         return njobs
 

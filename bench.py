@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--k", type=int, default=13)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=300)
+    ap.add_argument("--no-iterations", action="store_true",
+                    help="set BBMSA_NO_ITERATIONS on the DP jobs (scores and match strings unchanged, visited-cell counters not reported)")
     args = ap.parse_args()
 
     import torch
@@ -197,7 +199,8 @@ def main():
     torch.cuda.synchronize()
     t_ix = time.perf_counter() - t_ix
     hi = di.host
-    pipe = MapPipeline(di, n, read_len, offsets, key_scores, device=local_rank, max_sites=max_sites, max_columns=max_cols)
+    pipe = MapPipeline(di, n, read_len, offsets, key_scores, device=local_rank, max_sites=max_sites, max_columns=max_cols,
+                       no_iterations=args.no_iterations)
     pipe.load_reads(reads)
 
     for _ in range(args.warmup):

@@ -52,6 +52,10 @@ enum {
     BBMSA_CLAMP_WINDOW = 1 << 3,  /* a=max(0,start), b=min(ref_len-1,end), MSA.java:104-105,118-121 */
     BBMSA_DO_SCORE     = 1 << 4,  /* run score2 on a non-null fill                                  */
     BBMSA_DO_TRACEBACK = 1 << 5,  /* run traceback2 on a non-null fill, write the match string      */
+    BBMSA_NO_ITERATIONS = 1 << 6, /* the caller does not need result.iterations (the counter the native code adds to       */
+                                  /* iterationsLimited, used by the Java side for verbose statistics only): the library may  */
+                                  /* then fill with a tighter minScore first and reports iterations = -1 when it did;        */
+                                  /* result[], status, score[] and the match string are unchanged                            */
     BBMSA_INTERNAL_GAPPED = 1 << 8 /* set by the library on the jobs it derives for gapped references; never by callers */
 };
 /* the composite the mapper calls most: MSA.fillAndScoreLimited(read, ref, start, stop, minScore, null) */
@@ -311,13 +315,13 @@ int bbpipe_revcomp_device(void *stream, int64_t n_reads, const bbidx_read *reads
  * reverse-complemented reads at the same offsets.  no_indel_score (optional) receives the ungapped score of every
  * (read, site).  Sites with a gap array need a gapped reference: they are written to the second list
  * (gapped_jobs / gapped_gaps / gapped_src, for bbmsa_align_gapped_batch_device) when it is given, and only counted
- * when it is NULL. */
+ * when it is NULL.  extra_job_flags: BBMSA_NO_ITERATIONS or 0, OR-ed into the ordinary jobs' flags. */
 int bbpipe_select_jobs_device(void *stream, int64_t n_reads, const bbidx_read *reads, const uint8_t *bases,
                               int64_t minus_delta, const int32_t *nsites, bbidx_site *sites, int32_t max_sites,
                               const int64_t *chrom_off, const int32_t *chrom_len, const uint8_t *refs,
                               int32_t pad, int32_t max_columns, float min_ratio,
                               bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score,
-                              bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src);
+                              bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src, int32_t extra_job_flags);
 
 /* Paired-read rescue scan: AbstractMapThread.quickRescue(bases, chrom, strand, loc, searchDist, searchRight, idealStart,
  * maxAllowedMismatches, POINTS_MATCH, POINTS_MATCH2) (current/align2/AbstractMapThread.java:2300-2391), batched.  `reads`

@@ -292,3 +292,64 @@ def test_wide_pass_takes_windows_beyond_the_first_column_buffer():
             assert g["match"] == om.traceback(p[0], p[1], max(0, p[2]), p[3], mx[0], mx[1], mx[2])
     counts = al.ctx.last_counts()
     assert counts["generic"] == 0, counts
+
+
+def test_no_iterations_mode_keeps_scores_and_match_strings():
+    """BBMSA_NO_ITERATIONS lets the library try a tighter minScore first (narrow-window kernel).  Everything except the
+    visited-cell counter must stay bit-identical to the exact fill -- also where many alignments tie (low-complexity
+    sequence: indels inside homopolymers and dinucleotide repeats can be placed in several equally good ways)."""
+    import random
+    from oracle.oracle import OracleMSA
+    rng = random.Random(2024)
+
+    def lowcomplex(n):
+        out = bytearray()
+        while len(out) < n:
+            kind = rng.random()
+            if kind < 0.35:
+                out += bytes([rng.choice(b"ACGT")]) * rng.randint(3, 12)
+            elif kind < 0.6:
+                out += bytes(rng.choice(b"ACGT") for _ in range(2)) * rng.randint(2, 8)
+            else:
+                out += bytes(rng.choice(b"ACGT") for _ in range(rng.randint(4, 30)))
+        return bytes(out[:n])
+
+    refs = [lowcomplex(4000), bytes(rng.choice(b"ACGT") for _ in range(4000))]
+    probs = []
+    for i in range(6000):
+        ref = refs[i % 2]
+        L = rng.choice([100, 150, 150])
+        st = rng.randrange(50, 3500)
+        rd = bytearray(ref[st:st + L + 60])
+        span = L
+        ev = rng.random()
+        if ev < 0.45:
+            p = rng.randrange(10, L - 10); d = rng.choice([1, 1, 2, 3, 5, 8, 12, 20])
+            del rd[p:p + d]; span = L + d
+        elif ev < 0.8:
+            p = rng.randrange(10, L - 10); d = rng.choice([1, 1, 2, 3, 5, 9])
+            rd[p:p] = bytes(rng.choice(b"ACGT") for _ in range(d)); span = L - d
+        for _ in range(rng.choice([0, 0, 1, 2, 3])):
+            rd[rng.randrange(L)] = rng.choice(b"ACGTN")
+        rd = bytes(rd[:L])
+        ms = int(rng.choice([0.4, 0.56, 0.56, 0.7]) * (70 + 100 * (L - 1)))
+        probs.append((rd, ref, st - 4, st + span + 3, ms))
+    al = M.MultiStateAligner11ts(maxRows=160, maxColumns=320)
+    flags = M.FILL_AND_SCORE_LIMITED | M.DO_TRACEBACK
+    exact = al.align(probs, flags)
+    split_exact = al.ctx.last_counts()
+    relaxed = al.align(probs, flags | M.NO_ITERATIONS)
+    split_relaxed = al.ctx.last_counts()
+    assert split_relaxed["narrow"] > split_exact["narrow"] + 300, (split_exact, split_relaxed)     # the shortcut is really taken
+    shortcut = 0
+    for e, r in zip(exact, relaxed):
+        assert (r["status"], r["result"], r["score"], r["match"]) == (e["status"], e["result"], e["score"], e["match"])
+        if r["iterations"] == -1:
+            shortcut += 1
+        else:
+            assert r["iterations"] == e["iterations"]
+    assert shortcut > 300
+    om = OracleMSA(160, 320)                                             # and the exact run is the oracle's, on a sample
+    for p, e in list(zip(probs, exact))[:400]:
+        sv, mx = om.fillAndScoreLimited(*p)
+        assert e["score"] == sv
