@@ -19,9 +19,29 @@ START_PAD = 8000
 BASES = np.frombuffer(b"ACGT", np.uint8)
 
 
-def make_reference(length, seed, pad=START_PAD):
+def make_reference(length, seed, pad=START_PAD, repeat_frac=0.0, families=2000):
+    """Uniform ACGT of `length` bases between N pads.  repeat_frac > 0 adds the repeat model of SURVEY.md 8(d): that share of
+    the sequence is overwritten with copies of `families` repeat families (300-6000 bp, each copy diverged 1-15 %), so that
+    k-mer list lengths are skewed like a real genome's (long lists, greedy trimming, many candidate sites)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     body = BASES[rng.integers(0, 4, size=length, dtype=np.uint8)]
+    if repeat_frac > 0:
+        fam_len = rng.integers(300, 6001, size=families)
+        fams = [BASES[rng.integers(0, 4, size=int(n), dtype=np.uint8)] for n in fam_len]
+        target, placed = int(repeat_frac * length), 0
+        while placed < target:
+            f = fams[int(rng.integers(0, families))]
+            n = len(f)
+            if n + 1 >= length:
+                break
+            pos = int(rng.integers(0, length - n))
+            cp = f.copy()
+            nm = int(n * rng.uniform(0.01, 0.15))
+            if nm:
+                idx = rng.integers(0, n, size=nm)
+                cp[idx] = BASES[rng.integers(0, 4, size=nm, dtype=np.uint8)]
+            body[pos:pos + n] = cp
+            placed += n
     ref = np.full(length + 2 * pad, ord("N"), np.uint8)
     ref[pad:pad + length] = body
     return ref

@@ -53,7 +53,10 @@ def _emulate_read(oi, om, refb, bp, bm, offsets, key_scores, max_sites, L):
     maxSw = 70 + (L - 1) * 100
     maxImp = maxSw - 495
     minMsaLimit = -258 + int(np.float32(0.56) * np.float32(maxSw))
-    sites = oi.find(bp, bm, [0] * L, key_scores, offsets, cap=max_sites)
+    try:
+        sites = oi.find(bp, bm, [0] * L, key_scores, offsets, cap=max_sites)
+    except RuntimeError:                      # more than max_sites sites: the probe must report the overflow (nsites = -1)
+        return None, None, None
     near, force, sws = 0, False, []
     for e in sites:
         if e["perfect"]:
@@ -99,6 +102,9 @@ def parity_sample(pipe, out, reads, ref, hi, offsets, key_scores, count, max_sit
         bp_a = reads[r * L:(r + 1) * L]
         bp, bm = bp_a.tobytes(), comp[bp_a[::-1]].tobytes()
         sites, sws, dp = _emulate_read(oi, om, refb, bp, bm, offsets, key_scores, max_sites, L)
+        if sites is None:
+            bad += int(out["nsites"][r]) != -1
+            continue
         ok = int(out["nsites"][r]) == len(sites)
         for s, e in enumerate(sites if ok else []):
             g = out["sites"][r, s]
@@ -154,6 +160,8 @@ def main():
     ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU per step")
     ap.add_argument("--ref-len", type=int, default=0, help="reference length (default: E. coli K-12)")
     ap.add_argument("--k", type=int, default=13)
+    ap.add_argument("--max-sites", type=int, default=8)
+    ap.add_argument("--repeat-frac", type=float, default=0.0, help="share of the reference drawn from repeat families (SURVEY 8d repeat model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=300)
     ap.add_argument("--no-iterations", action="store_true",
@@ -173,13 +181,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     read_len, k = 150, args.k
     ref_len = args.ref_len or W.ECOLI_K12_LEN
-    ref = W.make_reference(ref_len, seed=1)
+    ref = W.make_reference(ref_len, seed=1, repeat_frac=args.repeat_frac)
     # every rank draws its own shard of reads (same generator, different stream); the index is replicated per GPU
     from bbmap_amd import dist as D
     reads, _, truth = W.make_reads_and_jobs(ref, args.reads, read_len=read_len, seed=D.shard_seed(2, rank))
     offsets = W.make_offsets(read_len, k, 1.9)
     key_scores = [100 * k] * len(offsets)          # GENERATE_KEY_SCORES_FROM_QUALITY needs qualities; synthetic reads have none
-    max_sites, max_cols = 8, 256
+    max_sites, max_cols = args.max_sites, 256
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         # host-only work, done before this process touches the GPU
@@ -278,7 +286,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic E. coli K-12 sized reference (%d bp, seed 1), %d x %d-bp SE reads per GPU "
+            "config": {"workload": ("configs[1]: synthetic E. coli K-12 sized reference" if ref_len == W.ECOLI_K12_LEN and args.repeat_frac == 0
+                                    else "synthetic reference, repeat fraction %g" % args.repeat_frac) + " (%d bp, seed 1), %d x %d-bp SE reads per GPU "
                                    "(seed 2, mutated mix), k=%d index resident in HBM; per step: reverse complement -> index probe "
                                    "(BBIndex.findAdvanced) -> ungapped site filter -> slow-align DP + traceback for the sites that "
                                    "need it (gapped-reference DP for sites with gap arrays)" % (ref_len, n, read_len, k),
