@@ -274,13 +274,18 @@ def main():
         else:
             dom, dom_ms, dom_bytes = "probe_wave_kernel", p_ms, probe_bytes
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
+        traffic, valu = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom + "_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom + "_bytes_per_launch")
+                vi = tj.get("valu_issue", {})
+                if dom in vi:       # the bound that actually binds these integer kernels (from the committed PMC profile, not live)
+                    valu = {"source": "profiles/traffic.json (rocprofv3 SQ_INSTS_VALU)", "frac_of_valu_issue_peak": vi[dom]["frac"],
+                            "peak_wave_inst_per_s": vi.get("peak_wave_inst_per_s")}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         out_json = {
             "metric": "aligned_reads_per_sec", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -302,7 +307,7 @@ def main():
                        "index_build_s_gpu": t_ix, "parity": parity},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": dom, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(dom_bytes),
+                         "kernel": dom, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(dom_bytes), "valu_issue": valu,
                          "kernels": {"probe_wave_kernel": {"ms": p_ms, "algorithmic_bytes": int(probe_bytes)},
                                      "msa_fill_fast_kernel": {"ms": w_ms, "algorithmic_bytes": int(wave_bytes)},
                                      "msa_fill_narrow_kernel": {"ms": n_ms, "algorithmic_bytes": int(dp_bytes - wave_bytes)},
