@@ -24,8 +24,10 @@ constexpr int kMinOffScore = (-(((1 << 20) - 1) - 2000)) * 2048;  // MINoff_SCOR
 constexpr int kNegInf = -(1 << 30);   // "no limit" for the unlimited fill; never reached by any score
 constexpr int kGapLen = 128;
 
-constexpr int kTableLen = 3072;       // delC / insC LDS tables: index time (<2048) + rows (<=640), never clamped
-constexpr int kLdsTableInts = 2 * kTableLen + 256;   // + delExt[128], insExt[32], subExt[8] (padded)
+constexpr int kTableLen = 3072;       // upper bound of the delC / insC LDS tables: index time (<2048) + rows (<=640)
+// A context's tables only need min(longer side + 2, 2048) + maxRows + 8 entries: a streak (time) never exceeds the longer
+// matrix side + 1 (and is clamped below 2048), the "still needed" indel length never exceeds the rows.  Ints of LDS in front of the per-job areas:
+__host__ __device__ inline int lds_table_ints(int tableLen) { return 2 * tableLen + 256; }   // + delExt[128], insExt[32], subExt[8] (padded)
 
 // closed forms of calcDelScoreOffset (jni/...c:316-336) and of the cumulative
 // POINTSoff_INS_ARRAY_C table (MultiStateAligner11tsJNI.java:1582-1601)
@@ -72,6 +74,7 @@ struct FillParams {
     int lanesPerJob;              // 16, 32 or 64
     int fastCols;                 // LDS capacity (columns) per job in the fast kernel
     int tmpBytes;                 // LDS bytes per job for the reversed match string
+    int tableLen;                 // entries of the delC / insC tables (see lds_table_ints)
     int maxRows, maxColumns;      // context limits (MSA(maxRows_, maxColumns_))
     int bandwidth;
     float bandwidthRatio;

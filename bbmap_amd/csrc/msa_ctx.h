@@ -9,7 +9,7 @@ struct bbmsa_ctx {
     int device;
     int numCUs;
     // fast kernel geometry
-    int G, R, fastCols, tmpBytes, blocks, ldsBytes;
+    int G, R, fastCols, tmpBytes, blocks, ldsBytes, tableLen;
     long long dirSlotDwords;
     unsigned int *d_dir;
     unsigned int *d_counters;   // [0]=fast queue, [1]=slow count, [2]=generic queue

@@ -59,20 +59,22 @@ __device__ __forceinline__ unsigned load_coherent(const unsigned *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// waves per SIMD the register allocator must leave room for (measured on MI355X: 3 waves beats 2 by 27% at R=5)
+// waves per SIMD the register allocator must leave room for (measured on MI355X at R=5: 3 waves beat 2 by 27 %; with the
+// context-sized LDS tables a 4th block fits a CU and 4 waves beat 3 by 7 %, 5 waves lose it again to spills)
 #ifndef BBMSA_MIN_WAVES
-#define BBMSA_MIN_WAVES(R) ((R) <= 5 ? 3 : ((R) <= 7 ? 2 : 1))
+#define BBMSA_MIN_WAVES(R) ((R) <= 5 ? 4 : ((R) <= 7 ? 2 : 1))
 #endif
 
 template <int R, bool BANDED>
 __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(const FillParams p) {
     extern __shared__ int lds[];
     int *delC = lds;
-    int *insC = lds + kTableLen;
-    int *delExt = lds + 2 * kTableLen;       // jni/...c:229-233 as a table of the streak (index <= 83)
+    const int TL = p.tableLen;
+    int *insC = lds + TL;
+    int *delExt = lds + 2 * TL;       // jni/...c:229-233 as a table of the streak (index <= 83)
     int *insExt = delExt + 128;               // POINTSoff_INS_ARRAY[streak+1], index min(streak,20)
     int *subExt = insExt + 32;                // POINTSoff_SUB_ARRAY[streak+1], index min(streak,5)
-    for (int i = threadIdx.x; i < kTableLen; i += blockDim.x) {
+    for (int i = threadIdx.x; i < TL; i += blockDim.x) {
         delC[i] = calc_del_off(i);
         insC[i] = calc_ins_cum_off(i);
     }
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
     const int groupBase = sub * G;           // first wave lane of my job group
 
     const int perJobLds = (p.fastCols + 2) * 2 + (p.tmpBytes + 3) / 4;   // ints
-    int *myLds = lds + kLdsTableInts + (wave * jobsPerWave + sub) * perJobLds;
+    int *myLds = lds + lds_table_ints(TL) + (wave * jobsPerWave + sub) * perJobLds;
     int2 *colinfo = reinterpret_cast<int2 *>(myLds);                      // [c] = {horizLimit[c], ref byte of column c}
     uint8_t *tmp = reinterpret_cast<uint8_t *>(myLds + (p.fastCols + 2) * 2);
 

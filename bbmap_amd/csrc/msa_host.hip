@@ -80,7 +80,13 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     c->tmpBytes = ((G * c->R + fastCols + 8) + 3) & ~3;
     const int jobsPerWave = 64 / G;
     const int perJobInts = (fastCols + 2) * 2 + c->tmpBytes / 4;
-    c->ldsBytes = (bbmsa::kLdsTableInts + 4 * jobsPerWave * perJobInts) * 4;
+    {   // index = time + needed: time <= min(longer side + 1, 2047 (clamped)), needed <= rows
+        const int side = (cfg->maxColumns > cfg->maxRows ? cfg->maxColumns : cfg->maxRows) + 2;
+        c->tableLen = (side < 2048 ? side : 2048) + cfg->maxRows + 8;
+    }
+    if (c->tableLen > bbmsa::kTableLen) c->tableLen = bbmsa::kTableLen;
+    c->tableLen = (c->tableLen + 3) & ~3;
+    c->ldsBytes = (bbmsa::lds_table_ints(c->tableLen) + 4 * jobsPerWave * perJobInts) * 4;
     if (c->ldsBytes > 160 * 1024) { delete c; return fail(BBMAP_E_ARG, "bbmsa_create: fast-path LDS budget exceeded; lower reserved[1] (fastCols)"); }
 
     c->banded = !(cfg->bandwidth < 1 && cfg->bandwidthRatio <= 0.0f);
@@ -120,7 +126,7 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
         c->wideCols = cfg->maxColumns;
         c->wideTmpBytes = ((64 * c->wideR + c->wideCols + 8) + 3) & ~3;
         const int perJob = (c->wideCols + 2) * 2 + c->wideTmpBytes / 4;
-        c->wideLdsBytes = (bbmsa::kLdsTableInts + perJob) * 4;
+        c->wideLdsBytes = (bbmsa::lds_table_ints(c->tableLen) + perJob) * 4;
         const void *wfn = bbmsa::fast_kernel_for(c->wideR, c->banded);
         if (wfn && c->wideLdsBytes <= 160 * 1024) {
             if (c->wideLdsBytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(wfn, hipFuncAttributeMaxDynamicSharedMemorySize, c->wideLdsBytes));
@@ -215,7 +221,7 @@ extern "C" int bbmsa_align_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_j
     fp.queue = c->d_counters; fp.dirbuf = c->d_dir; fp.dir_slot_dwords = c->dirSlotDwords;
     fp.list = c->narrowBlocks > 0 ? c->d_fastList : nullptr; fp.list_count = c->d_counters + 4;
     fp.slow_list = c->d_slowList; fp.slow_count = c->d_counters + 1;
-    fp.match_stride = match_stride; fp.lanesPerJob = c->G; fp.fastCols = c->fastCols; fp.tmpBytes = c->tmpBytes;
+    fp.match_stride = match_stride; fp.lanesPerJob = c->G; fp.fastCols = c->fastCols; fp.tmpBytes = c->tmpBytes; fp.tableLen = c->tableLen;
     fp.maxRows = c->cfg.maxRows; fp.maxColumns = c->cfg.maxColumns;
     fp.bandwidth = c->cfg.bandwidth; fp.bandwidthRatio = c->cfg.bandwidthRatio;
 
