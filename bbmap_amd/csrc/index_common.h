@@ -54,6 +54,7 @@ struct Params {
     int maxSites;
     int onlyPending;               // per-lane kernel: process only reads whose nsites == NSITES_PENDING
     unsigned int *queue;           // [0] read queue of the per-lane kernel, [1] reads left pending by the wave kernel
+    uint8_t *rcOut;                // optional: reverse complement of every probed read, same offsets as `bases`
     unsigned long long *stats;     // [STAT_SHARDS][8]: prescan entries, walk entries, extendScore calls, ref bytes, sites written
 };
 

@@ -573,6 +573,7 @@ __global__ __launch_bounds__(64) void probe_kernel(const Params P) {
         const uint8_t *bP = P.bases + rr.bases_off;
         const int8_t *qP = P.baseScores + rr.bases_off;
         const int *koff = P.keyinfo + rr.keys_off, *kscore = koff + n;
+        if (P.rcOut) for (int i = 0; i < blen; i++) P.rcOut[rr.bases_off + i] = (uint8_t)complement_extended(bP[blen - 1 - i]);
 
         for (int i = 0; i < n; i++) {                                   // KeyRing.makeKeys
             int key = 0;
@@ -799,6 +800,12 @@ extern "C" void bbidx_destroy(bbidx_ctx *c) {
 extern "C" int bbidx_find_batch_device(bbidx_ctx *c, void *stream_, int64_t n, const bbidx_read *reads,
                                        const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo,
                                        bbidx_site *sites, int32_t max_sites, int32_t *nsites) {
+    return bbidx_find_batch_device_rc(c, stream_, n, reads, bases, baseScores, keyinfo, sites, max_sites, nsites, nullptr);
+}
+
+extern "C" int bbidx_find_batch_device_rc(bbidx_ctx *c, void *stream_, int64_t n, const bbidx_read *reads,
+                                          const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo,
+                                          bbidx_site *sites, int32_t max_sites, int32_t *nsites, uint8_t *bases_rc_out) {
     if (!c) return ifail(BBMAP_E_ARG, "bbidx_find_batch_device: null context");
     if (n < 0 || n > 0x7fffffffLL || max_sites < 1) return ifail(BBMAP_E_ARG, "bbidx_find_batch_device: bad size");
     if (n == 0) return BBMAP_OK;
@@ -812,6 +819,7 @@ extern "C" int bbidx_find_batch_device(bbidx_ctx *c, void *stream_, int64_t n, c
     P.ix = c->dev; P.reads = reads; P.bases = bases; P.baseScores = baseScores; P.keyinfo = keyinfo;
     P.sites = sites; P.nsites = nsites; P.nreads = n; P.maxSites = max_sites; P.queue = c->d_queue;
     P.onlyPending = 0;
+    P.rcOut = bases_rc_out;
     long long blocks = (n + 63) / 64;
     if (blocks > c->blocks) blocks = c->blocks;
     IHIP(hipEventRecord(c->ev[0], stream));

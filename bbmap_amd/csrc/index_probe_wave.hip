@@ -158,10 +158,12 @@ __device__ bool popSite(const U &u, WL &L, int site, int cutoff, bool perfectOnl
 }
 
 // BBIndex.findMaxQscore2 :2294-2450
-__device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, bool perfectOnly, int &outQ, int &outHits) {
+__device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, bool perfectOnly, int numKeys, int mqsAllKeys,
+                                int &outQ, int &outHits) {
     const bbidx_params &p = u.ix->p;
     const int numHits = L.n;
-    const int mqs = maxQuickScoreW(u, L.offs, L.ksc, numHits);
+    // maxQuickScore over the lists that have hits; when every key has one that is the read's own value
+    const int mqs = numHits == numKeys ? mqsAllKeys : maxQuickScoreW(u, L.offs, L.ksc, numHits);
     int topQscore = -999999999, maxHits = 0, approxHitsCutoff, indelCutoff;
     if (perfectOnly) { approxHitsCutoff = numHits; indelCutoff = 0; }
     else { approxHitsCutoff = max(prevMaxHits, min(p.minApproxHitsToKeep, numHits - 1)); indelCutoff = p.maxIndel2; }
@@ -392,11 +394,12 @@ struct SiteOut { bbidx_site *v; int n, cap; bool overflow; };
 struct PrevSite { int idx, chrom, strand, start, stop, score, perfect, semiperfect, ngaps; };
 
 // BBIndex.slowWalk3 :1219-1706
-__device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int offsK, int kscK, int baseChrom_,
+__device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int mqs, int baseChrom_,
                            SiteOut &ssl, int *bestScores, bool allBasesCovered, int maxScore, bool fullyDefined) {
     const bbidx_params &p = u.ix->p;
     const int blen = u.blen, lane = u.lane;
-    const int mqs = maxQuickScoreW(u, offsK, kscK, numKeys);
+    // maxQuickScore(offsets, keyScores) of this strand: the minus-strand arrays are the mirrored plus-strand ones, whose sum,
+    // coverage and span are the same, so the caller's value serves both strands
     const int baseChrom = u.c.baseChrom(baseChrom_);
     const int numHits = L.n;
     const bool filter_by_qscore = numKeys >= 5;
@@ -729,6 +732,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
         sumBS = wsum(sumBS);
         const bool fullyDefined = __ballot(undefinedBase) == 0;
         wsync();
+        if (P.rcOut) {                                       // AminoAcid.reverseComplementBases for the DP stage, coalesced
+            uint8_t *rc = P.rcOut + rr.bases_off;
+            for (int i = lane; i < blen; i += 64) rc[i] = S.base[1][i];
+        }
 
         // KeyRing.makeKeys; lane i owns key i
         int off = 0, ksc = 0, keyOrig = -1;
@@ -834,7 +841,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
                     if (nh < minHitsToScore) { if (lane == cycle) { prescore = -9999; precount = 0; } }
                     else {
                         int tq, th;
-                        findMaxQscore2W(u, L, baseChrom, minHitsToScore, bestqscore >= mqs && pretend, tq, th);
+                        findMaxQscore2W(u, L, baseChrom, minHitsToScore, bestqscore >= mqs && pretend, n, mqs, tq, th);
                         if (lane == cycle) { prescore = tq; precount = th; }
                         bestqscore = max(tq, bestqscore); maxHits = max(maxHits, th);
                         if (bestqscore >= mqs && pretend) { minHitsToScore = max(minHitsToScore, maxHits); earlyOut = true; }
@@ -865,8 +872,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
                 if (!prescan || rl(precount, cycle) >= hitsCutoff || rl(prescore, cycle) >= qscoreCutoff) {
                     const int nh = makeListsW(u, S, L, block, baseChrom, keyHits(block, strand), strand ? offM : off, strand ? kscM : ksc, n, p.minApproxHitsToKeep);
                     if (nh >= p.minApproxHitsToKeep)
-                        slowWalk3W(u, S, L, strand, n, strand ? offM : off, strand ? kscM : ksc, chrom, ssl, bestScores,
-                                   allBasesCovered, maxScore, fullyDefined);
+                        slowWalk3W(u, S, L, strand, n, mqs, chrom, ssl, bestScores, allBasesCovered, maxScore, fullyDefined);
                 }
                 if (p.quitAfterTwoPerfects && bestScores[5] >= 2) quit = true;
             }

@@ -338,6 +338,9 @@ class DeviceIndex:
         L.bbidx_find_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.bbidx_find_batch_device.restype = C.c_int
+        L.bbidx_find_batch_device_rc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.bbidx_find_batch_device_rc.restype = C.c_int
         L.bbidx_set_kernel.argtypes = [C.c_void_p, C.c_int32]
         L.bbidx_set_kernel.restype = C.c_int
         L.bbidx_get_params.argtypes = [C.c_void_p, C.POINTER(bbidx_params)]

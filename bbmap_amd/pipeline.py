@@ -88,11 +88,11 @@ class MapPipeline:
         L, n = self.L, self.n
         stream = torch.cuda.current_stream().cuda_stream
         plus = self.bases.data_ptr()
-        _lib.check(L.bbpipe_revcomp_device(C.c_void_p(stream), n, self.reads.data_ptr(), plus, plus + self.total_bytes),
-                   "bbpipe_revcomp_device")
-        _lib.check(L.bbidx_find_batch_device(self.di.h, C.c_void_p(stream), n, self.reads.data_ptr(), plus,
-                                             self.base_scores.data_ptr(), self.keyinfo.data_ptr(), self.sites.data_ptr(),
-                                             self.max_sites, self.nsites.data_ptr()), "bbidx_find_batch_device")
+        # the probe writes every read's reverse complement (the DP jobs of minus-strand sites read it) while it has it in LDS
+        _lib.check(L.bbidx_find_batch_device_rc(self.di.h, C.c_void_p(stream), n, self.reads.data_ptr(), plus,
+                                                self.base_scores.data_ptr(), self.keyinfo.data_ptr(), self.sites.data_ptr(),
+                                                self.max_sites, self.nsites.data_ptr(), plus + self.total_bytes),
+                   "bbidx_find_batch_device_rc")
         _lib.check(L.bbpipe_select_jobs_device(C.c_void_p(stream), n, self.reads.data_ptr(), plus, self.total_bytes,
                                                self.nsites.data_ptr(), self.sites.data_ptr(), self.max_sites,
                                                self.chrom_off.data_ptr(), self.chrom_len.data_ptr(), self.refs.data_ptr(),

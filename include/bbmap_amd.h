@@ -268,6 +268,13 @@ void bbidx_destroy(bbidx_ctx *ctx);
 int bbidx_find_batch_device(bbidx_ctx *ctx, void *stream, int64_t n_reads, const bbidx_read *reads,
                             const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo,
                             bbidx_site *sites, int32_t max_sites, int32_t *nsites);
+/* The same, and every probed read's reverse complement (AminoAcid.reverseComplementBases, which the mapper computes once
+ * per read as basesM, current/align2/AbstractMapThread.java:643-655) is written to bases_rc_out at the read's offset: the
+ * kernel has it in LDS anyway, which saves the separate bbpipe_revcomp_device pass.  Reads without a usable key (nsites 0
+ * because len < k or no keys, or -2) are not written. */
+int bbidx_find_batch_device_rc(bbidx_ctx *ctx, void *stream, int64_t n_reads, const bbidx_read *reads,
+                               const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo,
+                               bbidx_site *sites, int32_t max_sites, int32_t *nsites, uint8_t *bases_rc_out);
 int bbidx_find_batch(bbidx_ctx *ctx, int64_t n_reads, const bbidx_read *reads,
                      const uint8_t *bases, const int8_t *baseScores, int64_t bases_bytes,
                      const int32_t *keyinfo, int64_t keyinfo_ints,

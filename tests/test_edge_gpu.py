@@ -67,3 +67,22 @@ def test_rescue_edges():
     got = quick_rescue_batch(probs, [ref])
     assert got == [None, None, None, None]
     assert quick_rescue_batch([(ref[1000:1100], 1, 1000, 0, True, 1000, 2)], [ref])[0]["start"] == 1000
+
+
+def test_revcomp_kernel():
+    import torch
+    from bbmap_amd.index import READ_DTYPE
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    lens = [150, 1, 77, 600, 64, 65]
+    reads = np.concatenate([rng.choice(list(b"ACGTNacgtnRYKM-"), n).astype(np.uint8) for n in lens])
+    recs = np.zeros(len(lens), READ_DTYPE)
+    recs["bases_off"] = np.cumsum([0] + lens[:-1]); recs["len"] = lens
+    dev = torch.device("cuda", 0)
+    t_in = torch.from_numpy(reads).to(dev); t_out = torch.zeros_like(t_in)
+    t_recs = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()).to(dev)
+    _lib.check(L.bbpipe_revcomp_device(None, len(lens), t_recs.data_ptr(), t_in.data_ptr(), t_out.data_ptr()), "bbpipe_revcomp_device")
+    comp = {ord(a): ord(b) for a, b in zip("ACGTNacgtnRYKM-", "TGCANtgcanYRMK-")}
+    out = t_out.cpu().numpy()
+    for off, n in zip(recs["bases_off"], lens):
+        assert out[off:off + n].tolist() == [comp[b] for b in reads[off:off + n][::-1]]
