@@ -13,7 +13,8 @@ SO_PATH = os.path.join(HERE, "libbbmap_amd.so")
 EXPORTS = [
     "bbmap_last_error", "bbmap_abi_version",
     "bbmsa_create", "bbmsa_destroy", "bbmsa_align_batch_device", "bbmsa_align_batch",
-    "bbmsa_fill_packed", "bbmsa_last_kernel_ms", "bbmsa_last_kernel_ms3", "bbmsa_last_counts", "bbmsa_align_gapped_batch_device", "bbmsa_align_gapped_batch",
+    "bbmsa_fill_packed", "bbmsa_last_kernel_ms", "bbmsa_last_kernel_ms3", "bbmsa_last_counts", "bbmsa_align_gapped_batch_device", "bbmsa_align_gapped_batch", "bbmsa_align_batch_device_indirect",
+    "bbmsa_align_gapped_batch_device_indirect",
     "bbband_create", "bbband_destroy", "bbband_align_batch_device", "bbband_align_batch",
     "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch", "bbidx_find_batch_device_rc", "bbidx_last_stats", "bbidx_set_kernel", "bbidx_build", "bbidx_get_params", "bbidx_export_block",
     "bbpipe_revcomp_device", "bbpipe_select_jobs_device", "bbpipe_quick_rescue_device",
@@ -87,6 +88,12 @@ def load():
     L.bbmsa_align_gapped_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     L.bbmsa_align_gapped_batch_device.restype = C.c_int
+    L.bbmsa_align_batch_device_indirect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    L.bbmsa_align_batch_device_indirect.restype = C.c_int
+    L.bbmsa_align_gapped_batch_device_indirect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    L.bbmsa_align_gapped_batch_device_indirect.restype = C.c_int
     L.bbmsa_align_gapped_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
     L.bbmsa_align_gapped_batch.restype = C.c_int
@@ -111,7 +118,7 @@ def load():
     L.bbpipe_revcomp_device.restype = C.c_int
     L.bbpipe_select_jobs_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
-                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     L.bbpipe_select_jobs_device.restype = C.c_int
     L.bbpipe_quick_rescue_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]

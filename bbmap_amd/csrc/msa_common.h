@@ -56,6 +56,13 @@ __host__ __device__ inline bool fully_defined(int b) {
     return b < 128 && (u == 'A' || u == 'C' || u == 'G' || u == 'T' || u == 'U');
 }
 
+// number of jobs of a launch: a host value, or a counter a previous kernel of the same stream left on the device
+__device__ inline long long job_count(long long njobs, const unsigned int *njobs_dev) {
+    if (!njobs_dev) return njobs;
+    const long long n = (long long)__hip_atomic_load(njobs_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return n < njobs ? n : njobs;
+}
+
 struct FillParams {
     const bbmsa_job *jobs;
     const uint8_t *reads;
@@ -63,6 +70,7 @@ struct FillParams {
     bbmsa_result *results;
     uint8_t *match;
     long long njobs;
+    const unsigned int *njobs_dev; // when set, the job count is read from here on the device (njobs = capacity)
     unsigned int *queue;          // work-queue head (zeroed before launch)
     unsigned int *dirbuf;         // traceback direction nibbles, one slot per resident job
     long long dir_slot_dwords;
@@ -88,6 +96,7 @@ struct NarrowParams {
     bbmsa_result *results;
     uint8_t *match;
     long long njobs;
+    const unsigned int *njobs_dev; // see FillParams
     unsigned int *queue;          // work-queue head (zeroed before launch)
     int *fast_list;               // jobs left to the wavefront kernel
     unsigned int *fast_count;
@@ -110,6 +119,7 @@ struct GenericParams {
     const int *list;              // job indices to process (NULL = all)
     const unsigned int *list_count;
     long long njobs;
+    const unsigned int *njobs_dev; // see FillParams
     int *matrix;                  // per-thread-slot 3*(maxRows+1)*(maxColumns+1) ints
     int *limits;                  // per-thread-slot vertLimit/horizLimit
     unsigned int *queue;

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
     const long long slot = ((long long)blockIdx.x * (blockDim.x >> 6) + wave) * jobsPerWave + sub;
     unsigned *dir = p.dirbuf + slot * p.dir_slot_dwords;
 
-    const long long total = p.list ? (long long)load_coherent(p.list_count) : p.njobs;
+    const long long total = p.list ? (long long)load_coherent(p.list_count) : job_count(p.njobs, p.njobs_dev);
     for (;;) {
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(p.queue, (unsigned)jobsPerWave);

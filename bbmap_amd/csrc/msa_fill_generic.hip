@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void msa_fill_generic_kernel(const GenericParam
     int *base = p.matrix + tid * 3 * planeInts;
     int *vertLimit = p.limits + tid * (long long)(p.maxRows + p.maxColumns + 4);
     int *horizLimit = vertLimit + p.maxRows + 2;
-    const long long total = p.list ? (long long)*p.list_count : p.njobs;
+    const long long total = p.list ? (long long)*p.list_count : job_count(p.njobs, p.njobs_dev);
 
     for (;;) {
         const long long q = (long long)atomicAdd(p.queue, 1u);

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64) void msa_fill_narrow_kernel(const NarrowParams 
     unsigned long long *dirw = p.dirbuf + (long long)blockIdx.x * (long long)(p.maxRows + 1) * 64;
     const bool ctxBanded = !(p.bandwidth < 1 && p.bandwidthRatio <= 0.0f);
     unsigned nDone = 0, nLeft = 0;
+    const long long NJ = job_count(p.njobs, p.njobs_dev);
 
     for (;;) {
         // ------------------------------------------------------------------ one candidate job per lane
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(64) void msa_fill_narrow_kernel(const NarrowParams 
         bool tight = false;
         for (;;) {
             const long long q = (long long)atomicAdd(p.queue, 1u);
-            if (q >= p.njobs) break;
+            if (q >= NJ) break;
             const bbmsa_job t = p.jobs[q];
             int ta = t.refStartLoc, tb = t.refEndLoc;
             const int tmode = t.flags & BBMSA_MODE_MASK;

@@ -33,6 +33,7 @@ struct GappedParams {
     uint8_t *gref;            // n x glen bytes
     int *aux;                 // n x 4: {origin, greflimit2, status (0 ok, 2 bad shape), ngaps}
     long long njobs;
+    const unsigned int *njobs_dev;
     int glen;                 // maxColumns + 2 (the reference's grefbuffer length, MSA.java:77)
     int maxColumns;
 };
@@ -40,7 +41,7 @@ struct GappedParams {
 // MSA.fillAndScoreLimited's gapped branch (:104-105,:125-131) + makeGref (:668-757) for one job per thread
 __global__ void make_gref_kernel(const GappedParams P) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.njobs) return;
+    if (j >= job_count(P.njobs, P.njobs_dev)) return;
     bbmsa_job jb = P.jobs[j];
     int *aux = P.aux + 4 * j;
     const int ngaps = P.gaps[j].ngaps;
@@ -105,7 +106,7 @@ __global__ void make_gref_kernel(const GappedParams P) {
 // translateFromGappedCoordinate (:759-779) on score[1], score[2]
 __global__ void gref_post_kernel(const GappedParams P, bbmsa_result *results) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.njobs) return;
+    if (j >= job_count(P.njobs, P.njobs_dev)) return;
     const int *aux = P.aux + 4 * j;
     if (aux[3] <= 0 || aux[2] != 0) return;
     bbmsa_result &r = results[j];
@@ -126,9 +127,12 @@ __global__ void gref_post_kernel(const GappedParams P, bbmsa_result *results) {
 static thread_local char g_gerr[256];
 #define GHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(g_gerr, sizeof g_gerr, "%s failed: %s", #expr, hipGetErrorString(e_)); bbmap_set_error(g_gerr); return BBMAP_E_HIP; } } while (0)
 
-extern "C" int bbmsa_align_gapped_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const bbmsa_job *jobs,
-                                               const bbmsa_gaps *gaps, const uint8_t *reads, const uint8_t *refs,
-                                               bbmsa_result *results, uint8_t *match, int32_t match_stride) {
+int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t *n_jobs_dev, const bbmsa_job *jobs,
+                     const uint8_t *reads, const uint8_t *refs, bbmsa_result *results, uint8_t *match, int32_t match_stride);   // msa_host.hip
+
+static int gapped_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t *n_jobs_dev, const bbmsa_job *jobs,
+                       const bbmsa_gaps *gaps, const uint8_t *reads, const uint8_t *refs,
+                       bbmsa_result *results, uint8_t *match, int32_t match_stride) {
     if (!c) { bbmap_set_error("bbmsa_align_gapped_batch_device: null context"); return BBMAP_E_ARG; }
     if (n_jobs < 0 || n_jobs > 0x7fffffffLL) { bbmap_set_error("bbmsa_align_gapped_batch_device: n_jobs out of range"); return BBMAP_E_ARG; }
     if (n_jobs == 0) return BBMAP_OK;
@@ -149,15 +153,28 @@ extern "C" int bbmsa_align_gapped_batch_device(bbmsa_ctx *c, void *stream_, int6
     }
     bbmsa::GappedParams P;
     P.jobs = jobs; P.gaps = gaps; P.refs = refs; P.out_jobs = c->d_gjobs; P.gref = c->d_gref; P.aux = c->d_gaux;
-    P.njobs = n_jobs; P.glen = glen; P.maxColumns = c->cfg.maxColumns;
+    P.njobs = n_jobs; P.njobs_dev = n_jobs_dev; P.glen = glen; P.maxColumns = c->cfg.maxColumns;
     const unsigned blocks = (unsigned)((n_jobs + 63) / 64);
     hipLaunchKernelGGL(bbmsa::make_gref_kernel, dim3(blocks), dim3(64), 0, stream, P);
     GHIP(hipGetLastError());
-    const int rc = bbmsa_align_batch_device(c, stream_, n_jobs, c->d_gjobs, reads, refs, results, match, match_stride);
+    const int rc = bbmsa_align_impl(c, stream_, n_jobs, n_jobs_dev, c->d_gjobs, reads, refs, results, match, match_stride);
     if (rc != BBMAP_OK) return rc;
     hipLaunchKernelGGL(bbmsa::gref_post_kernel, dim3(blocks), dim3(64), 0, stream, P, results);
     GHIP(hipGetLastError());
     return BBMAP_OK;
+}
+
+extern "C" int bbmsa_align_gapped_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const bbmsa_job *jobs,
+                                               const bbmsa_gaps *gaps, const uint8_t *reads, const uint8_t *refs,
+                                               bbmsa_result *results, uint8_t *match, int32_t match_stride) {
+    return gapped_impl(c, stream_, n_jobs, nullptr, jobs, gaps, reads, refs, results, match, match_stride);
+}
+
+extern "C" int bbmsa_align_gapped_batch_device_indirect(bbmsa_ctx *c, void *stream_, const uint32_t *n_jobs_dev, int64_t max_jobs,
+                                                        const bbmsa_job *jobs, const bbmsa_gaps *gaps, const uint8_t *reads,
+                                                        const uint8_t *refs, bbmsa_result *results, uint8_t *match, int32_t match_stride) {
+    if (!n_jobs_dev) { bbmap_set_error("bbmsa_align_gapped_batch_device_indirect: null counter"); return BBMAP_E_ARG; }
+    return gapped_impl(c, stream_, max_jobs, n_jobs_dev, jobs, gaps, reads, refs, results, match, match_stride);
 }
 
 extern "C" int bbmsa_align_gapped_batch(bbmsa_ctx *c, int64_t n_jobs, const bbmsa_job *jobs, const bbmsa_gaps *gaps,

@@ -10,6 +10,9 @@
 
 #include "msa_common.h"
 
+int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t *n_jobs_dev, const bbmsa_job *jobs,
+                     const uint8_t *reads, const uint8_t *refs, bbmsa_result *results, uint8_t *match, int32_t match_stride);
+
 namespace bbmsa {
 const void *fast_kernel_for(int R, bool banded);
 __global__ void msa_fill_generic_kernel(const GenericParams p);
@@ -178,6 +181,21 @@ extern "C" void bbmsa_destroy(bbmsa_ctx *c) {
 extern "C" int bbmsa_align_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_jobs,
                                         const bbmsa_job *jobs, const uint8_t *reads, const uint8_t *refs,
                                         bbmsa_result *results, uint8_t *match, int32_t match_stride) {
+    return bbmsa_align_impl(c, stream_, n_jobs, nullptr, jobs, reads, refs, results, match, match_stride);
+}
+
+extern "C" int bbmsa_align_batch_device_indirect(bbmsa_ctx *c, void *stream_, const uint32_t *n_jobs_dev, int64_t max_jobs,
+                                                 const bbmsa_job *jobs, const uint8_t *reads, const uint8_t *refs,
+                                                 bbmsa_result *results, uint8_t *match, int32_t match_stride) {
+    if (!n_jobs_dev) return fail(BBMAP_E_ARG, "bbmsa_align_batch_device_indirect: null counter");
+    return bbmsa_align_impl(c, stream_, max_jobs, n_jobs_dev, jobs, reads, refs, results, match, match_stride);
+}
+
+// n_jobs_dev == NULL: n_jobs jobs.  Otherwise n_jobs is the capacity of the buffers and the kernels read the real count
+// from *n_jobs_dev when they run.
+int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t *n_jobs_dev,
+                     const bbmsa_job *jobs, const uint8_t *reads, const uint8_t *refs,
+                     bbmsa_result *results, uint8_t *match, int32_t match_stride) {
     if (!c) return fail(BBMAP_E_ARG, "bbmsa_align_batch_device: null context");
     if (n_jobs < 0 || n_jobs > 0x7fffffffLL) return fail(BBMAP_E_ARG, "bbmsa_align_batch_device: n_jobs out of range");
     if (n_jobs == 0) return BBMAP_OK;
@@ -203,7 +221,7 @@ extern "C" int bbmsa_align_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_j
     HIP_TRY(hipEventRecord(c->ev[0], stream));
     if (c->narrowBlocks > 0) {
         bbmsa::NarrowParams np;
-        np.jobs = jobs; np.reads = reads; np.refs = refs; np.results = results; np.match = match; np.njobs = n_jobs;
+        np.jobs = jobs; np.reads = reads; np.refs = refs; np.results = results; np.match = match; np.njobs = n_jobs; np.njobs_dev = n_jobs_dev;
         np.queue = c->d_counters + 3; np.fast_list = c->d_fastList; np.fast_count = c->d_counters + 4;
         np.dirbuf = c->d_narrowDir; np.stats = c->d_counters + 5;
         np.match_stride = match_stride; np.maxRows = c->cfg.maxRows; np.maxColumns = c->cfg.maxColumns;
@@ -217,7 +235,7 @@ extern "C" int bbmsa_align_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_j
 
     bbmsa::FillParams fp;
     fp.jobs = jobs; fp.reads = reads; fp.refs = refs; fp.results = results; fp.match = match;
-    fp.njobs = n_jobs;
+    fp.njobs = n_jobs; fp.njobs_dev = n_jobs_dev;
     fp.queue = c->d_counters; fp.dirbuf = c->d_dir; fp.dir_slot_dwords = c->dirSlotDwords;
     fp.list = c->narrowBlocks > 0 ? c->d_fastList : nullptr; fp.list_count = c->d_counters + 4;
     fp.slow_list = c->d_slowList; fp.slow_count = c->d_counters + 1;
@@ -248,7 +266,7 @@ extern "C" int bbmsa_align_batch_device(bbmsa_ctx *c, void *stream_, int64_t n_j
 
     bbmsa::GenericParams gp;
     gp.jobs = jobs; gp.reads = reads; gp.refs = refs; gp.results = results; gp.match = match;
-    gp.list = genList; gp.list_count = genCount; gp.njobs = n_jobs;
+    gp.list = genList; gp.list_count = genCount; gp.njobs = n_jobs; gp.njobs_dev = n_jobs_dev;
     gp.matrix = c->d_matrix; gp.limits = c->d_limits; gp.queue = c->d_counters + 2;
     gp.match_stride = match_stride; gp.maxRows = c->cfg.maxRows; gp.maxColumns = c->cfg.maxColumns;
     gp.bandwidth = c->cfg.bandwidth; gp.bandwidthRatio = c->cfg.bandwidthRatio;
@@ -370,7 +388,7 @@ extern "C" int bbmsa_fill_packed(bbmsa_ctx *c, const uint8_t *read, int32_t read
         PK_TRY(hipMemset(c->d_counters, 0, 64));
         bbmsa::GenericParams gp;
         gp.jobs = d_job; gp.reads = d_read; gp.refs = d_ref; gp.results = d_res; gp.match = nullptr;
-        gp.list = nullptr; gp.list_count = nullptr; gp.njobs = 1;
+        gp.list = nullptr; gp.list_count = nullptr; gp.njobs = 1; gp.njobs_dev = nullptr;
         gp.matrix = c->d_matrix; gp.limits = c->d_limits; gp.queue = c->d_counters + 2;
         gp.match_stride = 0; gp.maxRows = c->cfg.maxRows; gp.maxColumns = c->cfg.maxColumns;
         gp.bandwidth = c->cfg.bandwidth; gp.bandwidthRatio = c->cfg.bandwidthRatio;

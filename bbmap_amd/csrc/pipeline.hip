@@ -111,6 +111,7 @@ struct SelectParams {
     unsigned int *counters;        // [0] jobs, [1] reads finished without DP, [2] gapped jobs (sites with gap arrays), [3] reads with no site
     int *noIndelScore;             // optional: per (read, site) ungapped score
     int extraFlags;                // OR-ed into every job's flags (e.g. BBMSA_NO_ITERATIONS)
+    int gappedCap;                 // capacity of the gapped list
     bbmsa_job *gjobs;              // optional second list: jobs for sites that carry a gap array (need makeGref)
     bbmsa_gaps *ggaps;
     int *gjobSrc;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
             const bool want = cand && gaps == 0;
             if (cand && gaps > 0) {                                   // rare: straight to the gapped list
                 const unsigned k = atomicAdd(&P.counters[2], 1u);
-                if (P.gjobs) {
+                if (P.gjobs && k < (unsigned)P.gappedCap) {
                     const bbidx_site sg = ss[s];
                     bbmsa_job j_;
                     j_.read_off = rr.bases_off + (sg.strand ? P.minus_delta : 0);
@@ -369,7 +370,8 @@ extern "C" int bbpipe_select_jobs_device(void *stream_, int64_t n_reads, const b
                                          const int64_t *chrom_off, const int32_t *chrom_len, const uint8_t *refs,
                                          int32_t pad, int32_t max_columns, float min_ratio,
                                          bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score,
-                                         bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src, int32_t extra_job_flags) {
+                                         bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src, int32_t gapped_cap,
+                                         int32_t extra_job_flags) {
     if (n_reads < 0 || max_sites < 1 || pad < 0 || max_columns < 1) { bbmap_set_error("bbpipe_select_jobs_device: bad size"); return BBMAP_E_ARG; }
     if (n_reads == 0) return BBMAP_OK;
     if (!reads || !bases || !nsites || !sites || !chrom_off || !chrom_len || !refs || !jobs || !job_src || !counters) {
@@ -387,6 +389,7 @@ extern "C" int bbpipe_select_jobs_device(void *stream_, int64_t n_reads, const b
     }
     P.gjobs = gapped_jobs; P.ggaps = gapped_gaps; P.gjobSrc = gapped_src;
     P.extraFlags = extra_job_flags & BBMSA_NO_ITERATIONS;
+    P.gappedCap = gapped_cap;
     const long long per_block = bbpipe::SEL_WAVES * bbpipe::SEL_READS_PER_WAVE;
     const long long blocks = (n_reads + per_block - 1) / per_block;
     hipLaunchKernelGGL(bbpipe::select_jobs_kernel, dim3((unsigned)blocks), dim3(64 * bbpipe::SEL_WAVES), 0, stream, P);

@@ -53,6 +53,7 @@ class MapPipeline:
         self.sites = torch.zeros(n_reads * max_sites * SITE_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
         self.nsites = torch.zeros(n_reads, dtype=torch.int32, device=self.dev)
         cap = n_reads * max_sites
+        self.job_cap = cap
         self.jobs = torch.zeros(cap * M.JOB_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
         self.job_src = torch.zeros(cap, dtype=torch.int32, device=self.dev)
         self.counters = torch.zeros(4, dtype=torch.int32, device=self.dev)
@@ -67,7 +68,8 @@ class MapPipeline:
         # per million reads) are taken by the context's wide pass
         self.gap_columns = max(3000, max_columns)
         self.gap_fast_cols = max(1024, max_columns)
-        self.msa_gapped = None
+        self.msa_gapped = M.MSAContext(maxRows=max_rows, maxColumns=self.gap_columns, device=device, fast_cols=self.gap_fast_cols,
+                                       lanes_per_job=64)
         self.gjobs = torch.zeros(self.gap_cap * M.JOB_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
         self.ggaps = torch.zeros(self.gap_cap * M.GAPS_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
         self.gjob_src = torch.zeros(self.gap_cap, dtype=torch.int32, device=self.dev)
@@ -75,7 +77,6 @@ class MapPipeline:
         self.gresults = torch.zeros(self.gap_cap * M.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
         self.gmatch = torch.zeros(self.gap_cap * self.gmatch_stride, dtype=torch.uint8, device=self.dev)
         self.max_rows = max_rows
-        self.side_stream = torch.cuda.Stream(device=self.dev) if __import__("os").environ.get("BBPIPE_SIDE_STREAM", "0") != "0" else None
         self.last_counters = None
         self.last_ms = {}
 
@@ -83,8 +84,11 @@ class MapPipeline:
         assert reads_u8.size == self.total_bytes
         self.bases[: self.total_bytes].copy_(torch.from_numpy(np.ascontiguousarray(reads_u8)))
 
-    def step(self):
-        """One pass of the hot path over the resident batch.  Returns the number of DP jobs."""
+    def step(self, sync=True):
+        """One pass of the hot path over the resident batch: probe -> site filter -> DP (+ gapped-reference DP), all enqueued on
+        the current stream with NO host round trip in between (the DP kernels read their job counts from the counters the
+        site filter leaves on the device).  sync=True then waits and returns the number of DP jobs; sync=False returns None
+        (call counts() later)."""
         L, n = self.L, self.n
         stream = torch.cuda.current_stream().cuda_stream
         plus = self.bases.data_ptr()
@@ -98,39 +102,31 @@ class MapPipeline:
                                                self.chrom_off.data_ptr(), self.chrom_len.data_ptr(), self.refs.data_ptr(),
                                                self.pad, self.max_columns, self.min_ratio, self.jobs.data_ptr(),
                                                self.job_src.data_ptr(), self.counters.data_ptr(), self.no_indel.data_ptr(),
-                                               self.gjobs.data_ptr(), self.ggaps.data_ptr(), self.gjob_src.data_ptr(),
+                                               self.gjobs.data_ptr(), self.ggaps.data_ptr(), self.gjob_src.data_ptr(), self.gap_cap,
                                                M.NO_ITERATIONS if self.no_iterations else 0),
                    "bbpipe_select_jobs_device")
-        cnt = self.counters.cpu().numpy()                     # the one host round trip: how many DP jobs
-        njobs = int(cnt[0])
-        ngap = int(cnt[2])
-        if ngap > self.gap_cap:
-            raise RuntimeError("more gapped sites (%d) than the pipeline's gapped-job capacity (%d)" % (ngap, self.gap_cap))
-        # The gapped-reference jobs (a few thousand wide unlimited fills, plus a handful for the context's wide pass, whose
-        # single-job latency is ~1.5 ms) are submitted FIRST, on a side stream: their kernels take the chip for a moment,
-        # and their long, thin tail then runs underneath the main DP launch instead of behind it.
-        main_stream = stream
-        side = None
-        if ngap:
-            if njobs and self.side_stream is not None:
-                side = self.side_stream
-                side.wait_stream(torch.cuda.current_stream())
-                stream = side.cuda_stream
-            if self.msa_gapped is None:
-                self.msa_gapped = M.MSAContext(maxRows=self.max_rows, maxColumns=self.gap_columns, device=self.dev.index or 0,
-                                               fast_cols=self.gap_fast_cols,
-                                               lanes_per_job=int(__import__('os').environ.get('BBPIPE_GAPPED_LANES', '64')))
-            rc = L.bbmsa_align_gapped_batch_device(self.msa_gapped.h, C.c_void_p(stream), ngap, self.gjobs.data_ptr(),
-                                                   self.ggaps.data_ptr(), plus, self.refs.data_ptr(), self.gresults.data_ptr(),
-                                                   self.gmatch.data_ptr(), self.gmatch_stride)
-            _lib.check(rc, "bbmsa_align_gapped_batch_device")
-        if njobs:
-            self.msa.align_batch_device(njobs, self.jobs.data_ptr(), plus, self.refs.data_ptr(), self.results.data_ptr(),
-                                        self.match.data_ptr(), self.match_stride, main_stream)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+        cptr = self.counters.data_ptr()
+        _lib.check(L.bbmsa_align_batch_device_indirect(self.msa.h, C.c_void_p(stream), C.c_void_p(cptr), self.job_cap,
+                                                       self.jobs.data_ptr(), plus, self.refs.data_ptr(), self.results.data_ptr(),
+                                                       self.match.data_ptr(), self.match_stride),
+                   "bbmsa_align_batch_device_indirect")
+        _lib.check(L.bbmsa_align_gapped_batch_device_indirect(self.msa_gapped.h, C.c_void_p(stream), C.c_void_p(cptr + 8),
+                                                              self.gap_cap, self.gjobs.data_ptr(), self.ggaps.data_ptr(), plus,
+                                                              self.refs.data_ptr(), self.gresults.data_ptr(), self.gmatch.data_ptr(),
+                                                              self.gmatch_stride), "bbmsa_align_gapped_batch_device_indirect")
+        if not sync:
+            self.last_counters = None
+            return None
+        return self.counts()[0]
+
+    def counts(self):
+        """Waits for the stream and returns the site filter's counters of the last step: [DP jobs, reads finished without DP,
+        gapped-reference jobs, reads without a site]."""
+        cnt = self.counters.cpu().numpy()
+        if int(cnt[2]) > self.gap_cap:
+            raise RuntimeError("more gapped sites (%d) than the pipeline's gapped-job capacity (%d)" % (int(cnt[2]), self.gap_cap))
         self.last_counters = cnt
-        return njobs
+        return int(cnt[0]), int(cnt[1]), int(cnt[2]), int(cnt[3])
 
     def probe_stats(self):
         st = (C.c_int64 * 5)()

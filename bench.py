@@ -217,19 +217,9 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    dp_ms, probe_ms, njobs_hist, probe_stats = [], [], [], None
-    narrow_ms, wave_ms, gapped_ms = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        nj = pipe.step()
-        njobs_hist.append(nj)
-        st, pms = pipe.probe_stats()            # HIP events on the launch stream around the probe kernel
-        probe_ms.append(pms)
-        probe_stats = st
-        k3 = pipe.msa.last_kernel_ms3() if nj else (0.0, 0.0, 0.0)
-        narrow_ms.append(k3[0]); wave_ms.append(k3[1])
-        dp_ms.append(k3[0] + k3[1] + k3[2])
-        gapped_ms.append(sum(pipe.msa_gapped.last_kernel_ms3()) if (pipe.msa_gapped is not None and pipe.last_counters[2]) else 0.0)
+        pipe.step(sync=False)                   # everything of a step is enqueued on the stream: no host round trip inside
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -238,8 +228,15 @@ def main():
     if dist is not None:
         elapsed = D.max_over_ranks(elapsed, dist, pipe.dev)
 
+    # per-kernel durations of the last timed step (HIP events the library recorded on the launch stream) and its counters
+    njobs = pipe.counts()[0]
+    probe_stats, pms = pipe.probe_stats()
+    probe_ms = [pms]
+    k3 = pipe.msa.last_kernel_ms3()
+    narrow_ms, wave_ms, dp_ms = [k3[0]], [k3[1]], [k3[0] + k3[1] + k3[2]]
+    gapped_ms = [sum(pipe.msa_gapped.last_kernel_ms3()) if pipe.last_counters[2] else 0.0]
+
     # ---- outside the timed region: checks and bookkeeping
-    njobs = njobs_hist[-1]
     out = pipe.fetch(njobs)
     cnt = pipe.last_counters
     res = out["results"]

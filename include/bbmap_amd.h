@@ -112,6 +112,13 @@ int bbmsa_align_batch_device(bbmsa_ctx *ctx, void *stream, int64_t n_jobs,
                              const bbmsa_job *jobs, const uint8_t *reads, const uint8_t *refs,
                              bbmsa_result *results, uint8_t *match, int32_t match_stride);
 
+/* The same with the job count left on the device: the kernels read min(*n_jobs_dev, max_jobs) when they start (max_jobs =
+ * capacity of jobs/results/match).  Lets a pipeline chain the site filter (which counts the jobs it writes) and the DP in
+ * one stream without a host round trip. */
+int bbmsa_align_batch_device_indirect(bbmsa_ctx *ctx, void *stream, const uint32_t *n_jobs_dev, int64_t max_jobs,
+                                      const bbmsa_job *jobs, const uint8_t *reads, const uint8_t *refs,
+                                      bbmsa_result *results, uint8_t *match, int32_t match_stride);
+
 /* Host-buffer batch: copies in, runs, copies out, synchronises. */
 int bbmsa_align_batch(bbmsa_ctx *ctx, int64_t n_jobs, const bbmsa_job *jobs,
                       const uint8_t *reads, int64_t reads_bytes,
@@ -142,6 +149,9 @@ typedef struct bbmsa_gaps { int32_t ngaps; int32_t gaps[BBMSA_MAX_GAPS]; } bbmsa
 int bbmsa_align_gapped_batch_device(bbmsa_ctx *ctx, void *stream, int64_t n_jobs, const bbmsa_job *jobs,
                                     const bbmsa_gaps *gaps, const uint8_t *reads, const uint8_t *refs,
                                     bbmsa_result *results, uint8_t *match, int32_t match_stride);
+int bbmsa_align_gapped_batch_device_indirect(bbmsa_ctx *ctx, void *stream, const uint32_t *n_jobs_dev, int64_t max_jobs,
+                                             const bbmsa_job *jobs, const bbmsa_gaps *gaps, const uint8_t *reads,
+                                             const uint8_t *refs, bbmsa_result *results, uint8_t *match, int32_t match_stride);
 int bbmsa_align_gapped_batch(bbmsa_ctx *ctx, int64_t n_jobs, const bbmsa_job *jobs, const bbmsa_gaps *gaps,
                              const uint8_t *reads, int64_t reads_bytes, const uint8_t *refs, int64_t refs_bytes,
                              bbmsa_result *results, uint8_t *match, int32_t match_stride);
@@ -322,13 +332,15 @@ int bbpipe_revcomp_device(void *stream, int64_t n_reads, const bbidx_read *reads
  * reverse-complemented reads at the same offsets.  no_indel_score (optional) receives the ungapped score of every
  * (read, site).  Sites with a gap array need a gapped reference: they are written to the second list
  * (gapped_jobs / gapped_gaps / gapped_src, for bbmsa_align_gapped_batch_device) when it is given, and only counted
- * when it is NULL.  extra_job_flags: BBMSA_NO_ITERATIONS or 0, OR-ed into the ordinary jobs' flags. */
+ * when it is NULL; at most gapped_cap of them are written (counters[2] keeps counting, so an overflow shows).
+ * extra_job_flags: BBMSA_NO_ITERATIONS or 0, OR-ed into the ordinary jobs' flags. */
 int bbpipe_select_jobs_device(void *stream, int64_t n_reads, const bbidx_read *reads, const uint8_t *bases,
                               int64_t minus_delta, const int32_t *nsites, bbidx_site *sites, int32_t max_sites,
                               const int64_t *chrom_off, const int32_t *chrom_len, const uint8_t *refs,
                               int32_t pad, int32_t max_columns, float min_ratio,
                               bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score,
-                              bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src, int32_t extra_job_flags);
+                              bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src, int32_t gapped_cap,
+                              int32_t extra_job_flags);
 
 /* Paired-read rescue scan: AbstractMapThread.quickRescue(bases, chrom, strand, loc, searchDist, searchRight, idealStart,
  * maxAllowedMismatches, POINTS_MATCH, POINTS_MATCH2) (current/align2/AbstractMapThread.java:2300-2391), batched.  `reads`
