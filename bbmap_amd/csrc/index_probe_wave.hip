@@ -58,6 +58,8 @@ struct U {
 // one list per lane (the reference's Quad heap entries), compacted: lanes 0..n-1
 struct WL {
     int row, stop, value, offs, ksc;
+    int nxt;                   // sites[row + 1], fetched when the cursor moved to `row`: the gather is in flight while the
+                               // wave works on other lists and has landed by the time this list is popped again
     bool live;
     int n, nlive;              // uniform
     const int *sites;          // uniform
@@ -150,7 +152,10 @@ __device__ bool popSite(const U &u, WL &L, int site, int cutoff, bool perfectOnl
         counter += (unsigned)popc(Pm);
         if (hit) {
             if (dies) L.live = false;
-            else { L.row = row; L.value = adjustSite(u, L.sites[row], L.offs, baseChrom); }
+            else {
+                L.row = row; L.value = adjustSite(u, L.nxt, L.offs, baseChrom);
+                if (row + 1 < L.stop) L.nxt = L.sites[row + 1];
+            }
         }
         if (L.nlive == 0) break;
     }
@@ -671,6 +676,8 @@ __device__ int makeListsW(const U &u, WaveLds &S, WL &L, int block, int baseChro
     L.row = __shfl(h.start, src); L.stop = L.row + __shfl(h.len, src); L.offs = __shfl(off, src); L.ksc = __shfl(ksc, src);
     const int first = __shfl(h.first, src);
     L.value = L.live ? adjustSite(u, first, L.offs, baseChrom) : 0;
+    L.nxt = 0;
+    if (L.live && L.row + 1 < L.stop) L.nxt = L.sites[L.row + 1];
     return nh;
 }
 
@@ -828,7 +835,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
         for (int chrom = p.minChrom; chrom <= p.maxChrom; chrom = ((chrom & u.c.highMask) + cpb)) ncycles += 2;
         if (ncycles > 64) { result = -2; break; }
         WL L;
-        L.row = L.stop = L.value = L.offs = L.ksc = 0; L.live = false; L.n = L.nlive = 0; L.sites = nullptr;
+        L.row = L.stop = L.value = L.offs = L.ksc = L.nxt = 0; L.live = false; L.n = L.nlive = 0; L.sites = nullptr;
         int precount = n, prescore = mqs;                 // lane c holds the prescan result of cycle c
         bool dead = false;
         if (prescan) {
