@@ -38,15 +38,16 @@ struct GappedParams {
     int maxColumns;
 };
 
-// MSA.fillAndScoreLimited's gapped branch (:104-105,:125-131) + makeGref (:668-757) for one job per thread
-__global__ void make_gref_kernel(const GappedParams P) {
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// MSA.fillAndScoreLimited's gapped branch (:104-105,:125-131) + makeGref (:668-757): one wavefront per job.  The segment
+// bookkeeping is a few scalar steps per gap; the byte copies are done by all 64 lanes, coalesced.
+__global__ __launch_bounds__(256) void make_gref_kernel(const GappedParams P) {
+    const int lane = threadIdx.x & 63;
+    const long long j = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (j >= job_count(P.njobs, P.njobs_dev)) return;
     bbmsa_job jb = P.jobs[j];
     int *aux = P.aux + 4 * j;
     const int ngaps = P.gaps[j].ngaps;
-    aux[3] = ngaps;
-    if (ngaps <= 0) { aux[0] = 0; aux[1] = 0; aux[2] = 0; P.out_jobs[j] = jb; return; }
+    if (ngaps <= 0) { if (lane == 0) { aux[0] = 0; aux[1] = 0; aux[2] = 0; aux[3] = ngaps; P.out_jobs[j] = jb; } return; }
     const uint8_t *ref = P.refs + jb.ref_off;
     const int a = max(0, jb.refStartLoc), b = min(jb.ref_len - 1, jb.refEndLoc);
     int g[BBMSA_MAX_GAPS];
@@ -62,50 +63,76 @@ __global__ void make_gref_kernel(const GappedParams P) {
         for (int i = 0; i < ngaps && !bad; i++) if (g[i] < 0 || g[i] >= jb.ref_len) bad = true;
         for (int i = 0; i + 1 < ngaps && !bad; i++) if (g[i + 1] < g[i]) bad = true;
     }
+    // copy ref[from .. from+n) to gref[gpos ..), all lanes; fails (bad) when it would run past the buffer
+    auto copy = [&](int from, int n) {
+        if (n <= 0 || bad) return;
+        if (gpos + n > P.glen) { bad = true; return; }
+        for (int i = lane; i < n; i += 64) gref[gpos + i] = ref[from + i];
+        gpos += n;
+    };
     for (int i = 0; i < ngaps && !bad; i += 2) {
         const int x = g[i], y = g[i + 1];
-        for (int r = x; r <= y && !bad; r++, gpos++) { if (gpos >= P.glen) bad = true; else gref[gpos] = ref[r]; }
+        copy(x, y - x + 1);
         if (i + 2 < ngaps && !bad) {
             const int z = g[i + 2];
             const int gap = z - y - 1;
             if (gap < K_GAPBUFFER2) { bad = true; break; }                        // the reference asserts gap >= MINGAP
             const int rem = gap % kGapLen;
-            const int lim = y + K_GAPBUFFER + rem;
             const int div = (gap - K_GAPBUFFER2) / kGapLen;
-            for (int r = y + 1; r <= lim && !bad; r++, gpos++) { if (gpos >= P.glen) bad = true; else gref[gpos] = ref[r]; }
-            for (int q = 0; q < div && !bad; q++, gpos++) { if (gpos >= P.glen) bad = true; else gref[gpos] = K_GAPC; }
-            for (int r = z - K_GAPBUFFER; r < z && !bad; r++, gpos++) { if (gpos >= P.glen) bad = true; else gref[gpos] = ref[r]; }
+            copy(y + 1, K_GAPBUFFER + rem);
+            if (!bad) {
+                if (gpos + div > P.glen) bad = true;
+                else { for (int q = lane; q < div; q += 64) gref[gpos + q] = K_GAPC; gpos += div; }
+            }
+            copy(z - K_GAPBUFFER, K_GAPBUFFER);
         }
     }
     const int greflimit = gpos;
     if (!bad) {
         const int lim = min(P.glen, greflimit + K_GREF_CUSHION);
-        for (int i = greflimit, r = b + 1; i < lim; i++, r++) { gref[i] = (r < jb.ref_len) ? ref[r] : (uint8_t)'N'; greflimit2 = i; }
+        for (int i = greflimit + lane; i < lim; i += 64) { const int r = b + 1 + (i - greflimit); gref[i] = (r < jb.ref_len) ? ref[r] : (uint8_t)'N'; }
+        if (lim > greflimit) greflimit2 = lim - 1;
         // translateToGappedCoordinate(a) must be 0 (asserted by the reference, :514): a <= origin always holds here
         // because origin = min(gaps[0], a); the fill covers columns 0..greflimit, which needs that byte to exist
         if (greflimit >= P.glen || greflimit + 1 > P.maxColumns) bad = true;
     }
-    aux[0] = origin; aux[1] = greflimit2; aux[2] = bad ? 2 : 0;
     bbmsa_job o = jb;
     if (bad) {
         // an impossible shape: the fill kernels answer BBMSA_ST_BAD_SHAPE for it
         o.read_len = 0; o.refStartLoc = 0; o.refEndLoc = -1; o.flags = BBMSA_FILL_LIMITED_RAW;
     } else {
-        // translateToGappedCoordinate(b): walk the gapped reference until the original coordinate is b (:781-801)
+        // translateToGappedCoordinate(b) (:781-801): index of the gapped reference whose original coordinate is b.  The gapped
+        // reference was just written by this wave: make the stores visible to its own loads first.
+        __threadfence_block();
         int gstop = INT_MIN;
         if (b <= origin) gstop = b - origin;
-        else for (int i = 0, q = origin; i < greflimit2; i++) { if (q == b) { gstop = i; break; } q += (gref[i] == K_GAPC) ? kGapLen : 1; }
+        else {
+            // coordinate of index i = origin + i + (kGapLen - 1) * (gap symbols before i): scan 64 indices per step
+            int carry = 0;                                   // gap symbols before the current chunk
+            for (int base = 0; base < greflimit2 && gstop == INT_MIN; base += 64) {
+                const int i = base + lane;
+                const bool in = i < greflimit2;
+                const bool isGap = in && gref[i] == K_GAPC;
+                const unsigned long long gm = __ballot(isGap);
+                const int before = carry + __builtin_popcountll(gm & ((1ull << lane) - 1ull));
+                const int q = origin + i + (kGapLen - 1) * before;
+                const unsigned long long hit = __ballot(in && q == b);
+                if (hit) gstop = base + __builtin_ctzll(hit);
+                carry += __builtin_popcountll(gm);
+            }
+        }
         o.ref_off = (int64_t)(gref - P.refs);
         o.ref_len = gstop;                                   // parked for the score2 tail (BBMSA_INTERNAL_GAPPED)
         o.refStartLoc = 0; o.refEndLoc = greflimit;
         o.flags = BBMSA_FILL_LIMITED | BBMSA_DO_SCORE | (jb.flags & BBMSA_DO_TRACEBACK) | BBMSA_INTERNAL_GAPPED;
     }
-    P.out_jobs[j] = o;
+    if (lane == 0) { aux[0] = origin; aux[1] = greflimit2; aux[2] = bad ? 2 : 0; aux[3] = ngaps; P.out_jobs[j] = o; }
 }
 
-// translateFromGappedCoordinate (:759-779) on score[1], score[2]
-__global__ void gref_post_kernel(const GappedParams P, bbmsa_result *results) {
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// translateFromGappedCoordinate (:759-779) on score[1], score[2]: one wavefront per job
+__global__ __launch_bounds__(256) void gref_post_kernel(const GappedParams P, bbmsa_result *results) {
+    const int lane = threadIdx.x & 63;
+    const long long j = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (j >= job_count(P.njobs, P.njobs_dev)) return;
     const int *aux = P.aux + 4 * j;
     if (aux[3] <= 0 || aux[2] != 0) return;
@@ -113,13 +140,20 @@ __global__ void gref_post_kernel(const GappedParams P, bbmsa_result *results) {
     if (r.score_len <= 0) return;
     const uint8_t *gref = P.gref + j * (long long)P.glen;
     const int origin = aux[0], greflimit2 = aux[1];
+    int outv[3] = {0, INT_MIN, INT_MIN};
     for (int w = 1; w <= 2; w++) {
         const int point = r.score[w];
-        int out = INT_MIN;
-        if (point <= 0) out = origin + point;
-        else for (int i = 0, q = origin; i < greflimit2; i++) { if (i == point) { out = q; break; } q += (gref[i] == K_GAPC) ? kGapLen : 1; }
-        r.score[w] = out;
+        if (point <= 0) { outv[w] = origin + point; continue; }
+        if (point >= greflimit2) continue;                   // the reference's loop ends without a match: INT_MIN
+        // coordinate of index `point` = origin + point + (kGapLen - 1) * (gap symbols before it)
+        int gaps = 0;
+        for (int base = 0; base < point; base += 64) {
+            const int i = base + lane;
+            gaps += __builtin_popcountll(__ballot(i < point && gref[i] == K_GAPC));
+        }
+        outv[w] = origin + point + (kGapLen - 1) * gaps;
     }
+    if (lane == 0) { r.score[1] = outv[1]; r.score[2] = outv[2]; }
 }
 
 }  // namespace bbmsa
@@ -154,12 +188,12 @@ static int gapped_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32
     bbmsa::GappedParams P;
     P.jobs = jobs; P.gaps = gaps; P.refs = refs; P.out_jobs = c->d_gjobs; P.gref = c->d_gref; P.aux = c->d_gaux;
     P.njobs = n_jobs; P.njobs_dev = n_jobs_dev; P.glen = glen; P.maxColumns = c->cfg.maxColumns;
-    const unsigned blocks = (unsigned)((n_jobs + 63) / 64);
-    hipLaunchKernelGGL(bbmsa::make_gref_kernel, dim3(blocks), dim3(64), 0, stream, P);
+    const unsigned blocks = (unsigned)((n_jobs + 3) / 4);                       // one wavefront per job, 4 per block
+    hipLaunchKernelGGL(bbmsa::make_gref_kernel, dim3(blocks), dim3(256), 0, stream, P);
     GHIP(hipGetLastError());
     const int rc = bbmsa_align_impl(c, stream_, n_jobs, n_jobs_dev, c->d_gjobs, reads, refs, results, match, match_stride);
     if (rc != BBMAP_OK) return rc;
-    hipLaunchKernelGGL(bbmsa::gref_post_kernel, dim3(blocks), dim3(64), 0, stream, P, results);
+    hipLaunchKernelGGL(bbmsa::gref_post_kernel, dim3(blocks), dim3(256), 0, stream, P, results);
     GHIP(hipGetLastError());
     return BBMAP_OK;
 }
