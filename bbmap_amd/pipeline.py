@@ -67,7 +67,7 @@ class MapPipeline:
         # BBMap's own maxColumns (BBMapThread.java:27-28); windows beyond the first pass's 1024-column LDS buffer (a handful
         # per million reads) are taken by the context's wide pass
         self.gap_columns = max(3000, max_columns)
-        self.gap_fast_cols = max(1024, max_columns)
+        self.gap_fast_cols = max(int(__import__('os').environ.get('BBPIPE_GAP_FAST_COLS', '640')), max_columns)
         self.msa_gapped = M.MSAContext(maxRows=max_rows, maxColumns=self.gap_columns, device=device, fast_cols=self.gap_fast_cols,
                                        lanes_per_job=64)
         self.gjobs = torch.zeros(self.gap_cap * M.JOB_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
