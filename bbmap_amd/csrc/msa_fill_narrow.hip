@@ -28,6 +28,7 @@ namespace bbmsa {
 namespace {
 
 constexpr int NB = 16;      // band width in diagonals
+static_assert(NB == 16, "the sliding reference-byte window (w0/w1/w2) and the 64-bit direction word are laid out for 16 diagonals");
 
 __device__ inline int ctime_n(int t) { return t > kMaxTime ? kMaxTime - 3 : t; }
 __device__ inline int del_step_n(int streak) {
