@@ -17,7 +17,7 @@ EXPORTS = [
     "bbmsa_align_gapped_batch_device_indirect",
     "bbband_create", "bbband_destroy", "bbband_align_batch_device", "bbband_align_batch",
     "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch", "bbidx_find_batch_device_rc", "bbidx_last_stats", "bbidx_set_kernel", "bbidx_build", "bbidx_get_params", "bbidx_export_block",
-    "bbpipe_revcomp_device", "bbpipe_select_jobs_device", "bbpipe_quick_rescue_device",
+    "bbpipe_revcomp_device", "bbpipe_select_jobs_device", "bbpipe_quick_rescue_device", "bbpipe_match_no_indels_device",
 ]
 
 
@@ -118,8 +118,11 @@ def load():
     L.bbpipe_revcomp_device.restype = C.c_int
     L.bbpipe_select_jobs_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
-                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.bbpipe_select_jobs_device.restype = C.c_int
+    L.bbpipe_match_no_indels_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.bbpipe_match_no_indels_device.restype = C.c_int
     L.bbpipe_quick_rescue_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.bbpipe_quick_rescue_device.restype = C.c_int

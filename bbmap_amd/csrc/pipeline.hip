@@ -112,6 +112,7 @@ struct SelectParams {
     int *noIndelScore;             // optional: per (read, site) ungapped score
     int extraFlags;                // OR-ed into every job's flags (e.g. BBMSA_NO_ITERATIONS)
     int gappedCap;                 // capacity of the gapped list
+    int *readState;                // optional, per read: -1 no site, (s << 2) | 1 finished without DP with best site s, 2 sent to DP
     bbmsa_job *gjobs;              // optional second list: jobs for sites that carry a gap array (need makeGref)
     bbmsa_gaps *ggaps;
     int *gjobSrc;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
         const long long r = r0 + q;
         if (r >= P.nreads) break;
         const int ns = P.nsites[r];
-        if (ns <= 0) { if (ns == 0) cNoSite++; continue; }
+        if (ns <= 0) { if (ns == 0) cNoSite++; if (P.readState && lane == 0) P.readState[r] = -1; continue; }
         const bbidx_read rr = P.reads[r];
         const int len = rr.len;
         const int maxSw = 70 + (len - 1) * 100;                        // msa.maxQuality(len)
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
         int near = 0; bool forceSlow = false;
         // lane s keeps what the second pass needs of site s (s < 64; further sites are re-read)
         int mySw = 0, mySemi = 0, myGaps = 0;
+        int bestSw = INT_MIN, bestSite = 0;                            // first site with the highest ungapped score
         for (int s = 0; s < ns; s++) {
             const int strand = ss[s].strand, chrom = ss[s].chrom, start = ss[s].start, oldScore = ss[s].score;
             int perfect = ss[s].perfect, semi = ss[s].semiperfect, ngaps = ss[s].ngaps, stop = ss[s].stop;
@@ -189,10 +191,12 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
                 if (P.noIndelScore) P.noIndelScore[r * (long long)P.maxSites + s] = sw;
             }
             if (lane == (s & 63)) { mySw = sw; mySemi = semi; myGaps = ngaps; }
+            if (sw > bestSw) { bestSw = sw; bestSite = s; }
         }
         __threadfence_block();                                        // lane 0's site updates before any lane re-reads them
         const int numNear = forceSlow ? -near : near;
-        if (numNear >= 1) { cDone++; continue; }
+        if (numNear >= 1) { cDone++; if (P.readState && lane == 0) P.readState[r] = (bestSite << 2) | 1; continue; }
+        if (P.readState && lane == 0) P.readState[r] = 2;
         const int minMsaLimit = -258 + (int)__fmul_rn(P.minRatio, (float)maxSw);     // -CLEARZONE1e + (int)(ratio*maxSwScore)
         for (int s0 = 0; s0 < ns; s0 += 64) {
             const int s = s0 + lane;
@@ -244,6 +248,45 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
         write_jobs(base);
     }
     if (threadIdx.x < 2 && blockCnt[threadIdx.x]) atomicAdd(&P.counters[threadIdx.x == 0 ? 1 : 3], blockCnt[threadIdx.x]);
+}
+
+// MSA.scoreNoIndelsAndMakeMatchString(read, ref, refStart, matchReturn) (MultiStateAligner11tsJNI.java:1244-1318) for the
+// reads the site filter finished without DP: their best site needs no alignment, its match string is one symbol per base
+// ('m' equal and called, 'N' when the read or the reference base is undefined, 'S' otherwise).  One wavefront per read.
+struct MatchParams {
+    const bbidx_read *reads;
+    const uint8_t *bases;
+    long long minus_delta;
+    const bbidx_site *sites;
+    int maxSites;
+    const int *readState;
+    const long long *chromOff;
+    const int *chromLen;
+    const uint8_t *refs;
+    long long nreads;
+    uint8_t *match;
+    int stride;
+    int *matchLen;
+};
+
+__global__ __launch_bounds__(256) void match_no_indels_kernel(const MatchParams P) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= P.nreads) return;
+    const int st = P.readState[r];
+    if ((st & 3) != 1 || st < 0) { if (lane == 0) P.matchLen[r] = 0; return; }
+    const bbidx_read rr = P.reads[r];
+    const bbidx_site ss = P.sites[r * (long long)P.maxSites + (st >> 2)];
+    const int len = rr.len, reflen = P.chromLen[ss.chrom];
+    if (ss.start < 0 || ss.start + len > reflen || len > P.stride) { if (lane == 0) P.matchLen[r] = -1; return; }   // the reference returns -99999
+    const uint8_t *bases = P.bases + rr.bases_off + (ss.strand ? P.minus_delta : 0);
+    const uint8_t *ref = P.refs + P.chromOff[ss.chrom] + ss.start;
+    uint8_t *out = P.match + r * (long long)P.stride;
+    for (int i = lane; i < len; i += 64) {
+        const int c = bases[i], q = ref[i];
+        out[i] = (c == q && c != 'N') ? 'm' : ((c >= 128 || c == 'N' || q >= 128 || q == 'N') ? 'N' : 'S');
+    }
+    if (lane == 0) P.matchLen[r] = len;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -371,7 +414,7 @@ extern "C" int bbpipe_select_jobs_device(void *stream_, int64_t n_reads, const b
                                          int32_t pad, int32_t max_columns, float min_ratio,
                                          bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score,
                                          bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src, int32_t gapped_cap,
-                                         int32_t extra_job_flags) {
+                                         int32_t extra_job_flags, int32_t *read_state) {
     if (n_reads < 0 || max_sites < 1 || pad < 0 || max_columns < 1) { bbmap_set_error("bbpipe_select_jobs_device: bad size"); return BBMAP_E_ARG; }
     if (n_reads == 0) return BBMAP_OK;
     if (!reads || !bases || !nsites || !sites || !chrom_off || !chrom_len || !refs || !jobs || !job_src || !counters) {
@@ -390,6 +433,7 @@ extern "C" int bbpipe_select_jobs_device(void *stream_, int64_t n_reads, const b
     P.gjobs = gapped_jobs; P.ggaps = gapped_gaps; P.gjobSrc = gapped_src;
     P.extraFlags = extra_job_flags & BBMSA_NO_ITERATIONS;
     P.gappedCap = gapped_cap;
+    P.readState = read_state;
     const long long per_block = bbpipe::SEL_WAVES * bbpipe::SEL_READS_PER_WAVE;
     const long long blocks = (n_reads + per_block - 1) / per_block;
     hipLaunchKernelGGL(bbpipe::select_jobs_kernel, dim3((unsigned)blocks), dim3(64 * bbpipe::SEL_WAVES), 0, stream, P);
@@ -412,6 +456,24 @@ extern "C" int bbpipe_quick_rescue_device(void *stream_, int64_t n_jobs, const b
     P.pointsMatch = points_match; P.pointsMatch2 = points_match2; P.useAffine = use_affine; P.baseHitScore = base_hit_score;
     const long long blocks = (n_jobs + bbpipe::RESC_WAVES - 1) / bbpipe::RESC_WAVES;
     hipLaunchKernelGGL(bbpipe::quick_rescue_kernel, dim3((unsigned)blocks), dim3(64 * bbpipe::RESC_WAVES), 0, (hipStream_t)stream_, P);
+    PHIP(hipGetLastError());
+    return BBMAP_OK;
+}
+
+extern "C" int bbpipe_match_no_indels_device(void *stream_, int64_t n_reads, const bbidx_read *reads, const uint8_t *bases,
+                                             int64_t minus_delta, const bbidx_site *sites, int32_t max_sites, const int32_t *read_state,
+                                             const int64_t *chrom_off, const int32_t *chrom_len, const uint8_t *refs,
+                                             uint8_t *match, int32_t match_stride, int32_t *match_len) {
+    if (n_reads < 0 || max_sites < 1 || match_stride < 1) { bbmap_set_error("bbpipe_match_no_indels_device: bad size"); return BBMAP_E_ARG; }
+    if (n_reads == 0) return BBMAP_OK;
+    if (!reads || !bases || !sites || !read_state || !chrom_off || !chrom_len || !refs || !match || !match_len) {
+        bbmap_set_error("bbpipe_match_no_indels_device: null buffer"); return BBMAP_E_ARG;
+    }
+    bbpipe::MatchParams P;
+    P.reads = reads; P.bases = bases; P.minus_delta = minus_delta; P.sites = sites; P.maxSites = max_sites; P.readState = read_state;
+    P.chromOff = (const long long *)chrom_off; P.chromLen = chrom_len; P.refs = refs; P.nreads = n_reads;
+    P.match = match; P.stride = match_stride; P.matchLen = match_len;
+    hipLaunchKernelGGL(bbpipe::match_no_indels_kernel, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, P);
     PHIP(hipGetLastError());
     return BBMAP_OK;
 }

@@ -57,6 +57,9 @@ class MapPipeline:
         self.jobs = torch.zeros(cap * M.JOB_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
         self.job_src = torch.zeros(cap, dtype=torch.int32, device=self.dev)
         self.counters = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self.read_state = torch.zeros(n_reads, dtype=torch.int32, device=self.dev)
+        self.ungapped_match = torch.zeros(n_reads * read_len, dtype=torch.uint8, device=self.dev)
+        self.ungapped_len = torch.zeros(n_reads, dtype=torch.int32, device=self.dev)
         self.no_indel = torch.zeros(cap, dtype=torch.int32, device=self.dev)
         self.match_stride = ((max_rows + max_columns + 15) // 16) * 16
         self.results = torch.zeros(cap * M.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
@@ -103,8 +106,14 @@ class MapPipeline:
                                                self.pad, self.max_columns, self.min_ratio, self.jobs.data_ptr(),
                                                self.job_src.data_ptr(), self.counters.data_ptr(), self.no_indel.data_ptr(),
                                                self.gjobs.data_ptr(), self.ggaps.data_ptr(), self.gjob_src.data_ptr(), self.gap_cap,
-                                               M.NO_ITERATIONS if self.no_iterations else 0),
+                                               M.NO_ITERATIONS if self.no_iterations else 0, self.read_state.data_ptr()),
                    "bbpipe_select_jobs_device")
+        # reads that need no DP still need their match string (one symbol per base at the best site)
+        _lib.check(L.bbpipe_match_no_indels_device(C.c_void_p(stream), n, self.reads.data_ptr(), plus, self.total_bytes,
+                                                   self.sites.data_ptr(), self.max_sites, self.read_state.data_ptr(),
+                                                   self.chrom_off.data_ptr(), self.chrom_len.data_ptr(), self.refs.data_ptr(),
+                                                   self.ungapped_match.data_ptr(), self.read_len, self.ungapped_len.data_ptr()),
+                   "bbpipe_match_no_indels_device")
         cptr = self.counters.data_ptr()
         _lib.check(L.bbmsa_align_batch_device_indirect(self.msa.h, C.c_void_p(stream), C.c_void_p(cptr), self.job_cap,
                                                        self.jobs.data_ptr(), plus, self.refs.data_ptr(), self.results.data_ptr(),
@@ -151,4 +160,6 @@ class MapPipeline:
         gres = self.gresults[: ngap * M.RESULT_DTYPE.itemsize].cpu().numpy().view(M.RESULT_DTYPE)
         gmatch = self.gmatch[: ngap * self.gmatch_stride].cpu().numpy().reshape(ngap, self.gmatch_stride)
         return dict(sites=sites, nsites=nsites, jobs=jobs, src=src, results=res, match=match, no_indel=no_indel,
+                    read_state=self.read_state.cpu().numpy(), ungapped_len=self.ungapped_len.cpu().numpy(),
+                    ungapped_match=self.ungapped_match.cpu().numpy().reshape(self.n, self.read_len),
                     gjobs=gjobs, ggaps=ggaps, gsrc=gsrc, gresults=gres, gmatch=gmatch)

@@ -88,7 +88,7 @@ def _emulate_read(oi, om, refb, bp, bm, offsets, key_scores, max_sites, L):
 
 def parity_sample(pipe, out, reads, ref, hi, offsets, key_scores, count, max_sites, max_cols):
     """Checks the first `count` reads of the last step end to end against the oracle."""
-    from oracle.oracle import OracleIndex, OracleMSA
+    from oracle.oracle import OracleIndex, OracleMSA, score_no_indels_match
     L = pipe.read_len
     oi = OracleIndex([ref], k=hi.k, chromBits=hi.chromBits)
     om = OracleMSA(160, max_cols)
@@ -110,6 +110,12 @@ def parity_sample(pipe, out, reads, ref, hi, offsets, key_scores, count, max_sit
             g = out["sites"][r, s]
             ok &= (int(g["chrom"]), int(g["strand"]), int(g["start"]), int(g["hits"])) == (e["chrom"], e["strand"], e["start"], e["hits"])
             ok &= int(out["no_indel"][r, s]) == sws[s]
+        # reads finished without DP carry the ungapped match string of their best site
+        st = int(out["read_state"][r])
+        if sites and not dp and (st & 3) == 1:
+            e = sites[st >> 2]
+            sc, ms = score_no_indels_match(bm if e["strand"] else bp, refb, e["start"])
+            ok &= (int(out["ungapped_len"][r]) == -1) if sc == -99999 else (out["ungapped_match"][r].tobytes() == ms)
         want = {s for s, _, _ in dp}
         have = {src % max_sites for src in by_src if src // max_sites == r}
         ok &= want == have

@@ -7,7 +7,7 @@ from bbmap_amd import msa as M
 from bbmap_amd.index import HostIndex
 from bbmap_amd.pipeline import MapPipeline
 from bbmap_amd import workload as W
-from oracle.oracle import OracleIndex, OracleMSA, make_offsets, score_no_indels
+from oracle.oracle import OracleIndex, OracleMSA, make_offsets, score_no_indels, score_no_indels_match
 from tests.index_problems import revcomp
 
 pytestmark = pytest.mark.gpu
@@ -39,7 +39,7 @@ def test_pipeline_matches_emulation():
     by_gsrc = {int(s): i for i, s in enumerate(out["gsrc"])}
     assert len(by_gsrc) == cnt[2]
     omg = OracleMSA(160, 3000)
-    checked_jobs = checked_gapped = 0
+    checked_jobs = checked_gapped = checked_ungapped = 0
     for r in range(600):
         bp = reads[r * L:(r + 1) * L].tobytes()
         bm = revcomp(bp)
@@ -63,6 +63,22 @@ def test_pipeline_matches_emulation():
             sws.append(sw)
             assert int(out["no_indel"][r, s]) == sw
         num_near = -near if force else near
+        # reads finished without DP: state = (best site << 2) | 1 and the ungapped match string of that site
+        state = int(out["read_state"][r])
+        if not exp_sites:
+            assert state == -1
+        elif num_near >= 1:
+            best = max(range(len(sws)), key=lambda q: (sws[q], -q))
+            assert state == (best << 2) | 1, (r, state, sws)
+            e = exp_sites[best]
+            sc, ms = score_no_indels_match(bm if e["strand"] else bp, refb, e["start"])
+            if sc == -99999:
+                assert int(out["ungapped_len"][r]) == -1
+            else:
+                assert int(out["ungapped_len"][r]) == L and out["ungapped_match"][r].tobytes() == ms
+            checked_ungapped += 1
+        else:
+            assert state == 2 and int(out["ungapped_len"][r]) == 0
         for s, e in enumerate(exp_sites):
             src = r * 8 + s
             semip = bool(out["sites"][r, s]["semiperfect"])
@@ -103,5 +119,5 @@ def test_pipeline_matches_emulation():
                     tb = om.traceback(bases, refb, max(0, int(j["refStartLoc"])), int(j["refEndLoc"]), mx[0], mx[1], mx[2])
                     assert out["match"][i, : res["match_len"]].tobytes() == tb
                 checked_jobs += 1
-    assert checked_jobs > 20
+    assert checked_jobs > 20 and checked_ungapped > 200
     assert cnt[2] > 0 and checked_gapped > 0
