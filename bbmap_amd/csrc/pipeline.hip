@@ -10,8 +10,8 @@
 //      perfect scored lower without indels (forceSlow, AbstractMapThread.java:836-838);
 //   3. otherwise every site with ungapped score < maxImperfectScore and not semiperfect becomes one DP job:
 //      window = site +- SLOW_ALIGN_PADDING, minScore = max(ungapped score, minMsaLimit) (BBMapThread.java:289-309).
-// Not carried over (host-side policies of the mapper, out of scope here): trimList, findTipDeletions, the
-// stop-anchored retry of scoreNoIndels (:808-815), the second wider fill after pad hints (scoreSlow :312-335).
+// Not carried over (host-side policies of the mapper, out of scope here): trimList, findTipDeletions, the second wider
+// fill after pad hints (scoreSlow :312-335).
 // Sites that carry a gap array go to a second job list (bbmsa_align_gapped_batch_device builds their gapped reference).
 #include <hip/hip_runtime.h>
 
@@ -91,6 +91,40 @@ __device__ int score_no_indels_wave(const uint8_t *read, int len, const uint8_t 
         }
     }
     return score;
+}
+
+// SiteScore.setPerfect (current/stream/SiteScore.java:239-292) by one wavefront, order-independent form (see
+// index_probe_wave.hip): perfect = every base equal and called; semiperfect tolerates reference N for up to len/2 bases.
+__device__ void set_perfect_wave(const uint8_t *read, int len, const uint8_t *ref, int reflen, int start, int stop, int lane,
+                                 int &perfectOut, int &semiOut) {
+    perfectOut = 0; semiOut = 0;
+    if (len != stop - start + 1) return;
+    bool perfect = true;
+    int refloc = start, readloc = 0, N = 0;
+    const int mx = min(stop, reflen - 1), nlimit = len / 2;
+    if (start < 0) { N -= start; readloc -= start; refloc -= start; perfect = false; }
+    if (stop >= reflen) { N += (stop - reflen + 1); perfect = false; }
+    if (N > nlimit) return;
+    bool anyHard = false, anyCN = false, anyBad = false;
+    for (int j0 = 0; refloc + j0 <= mx; j0 += 64) {
+        const int j = j0 + lane;
+        bool bad = false, hard = false, cn = false;
+        if (refloc + j <= mx) {
+            const int c = read[readloc + j], r = ref[refloc + j];
+            bad = (c != r || c == 'N'); hard = bad && r != 'N'; cn = bad && c == 'N';
+        }
+        const u64 badM = __ballot(bad);
+        if (badM) {
+            anyBad = true;
+            if (__ballot(hard)) { anyHard = true; break; }
+            if (__ballot(cn)) anyCN = true;
+            N += popc(badM);
+            if (N > nlimit) break;
+        }
+    }
+    if (anyHard || N > nlimit) return;
+    semiOut = anyCN ? 0 : 1;
+    perfectOut = (perfect && !anyBad && !anyCN && N == 0) ? 1 : 0;
 }
 
 struct SelectParams {
@@ -173,21 +207,34 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
         int mySw = 0, mySemi = 0, myGaps = 0;
         int bestSw = INT_MIN, bestSite = 0;                            // first site with the highest ungapped score
         for (int s = 0; s < ns; s++) {
-            const int strand = ss[s].strand, chrom = ss[s].chrom, start = ss[s].start, oldScore = ss[s].score;
-            int perfect = ss[s].perfect, semi = ss[s].semiperfect, ngaps = ss[s].ngaps, stop = ss[s].stop;
+            const int strand = ss[s].strand, chrom = ss[s].chrom, oldScore = ss[s].score;
+            int perfect = ss[s].perfect, semi = ss[s].semiperfect, ngaps = ss[s].ngaps, start = ss[s].start, stop = ss[s].stop;
+            bool newStart = false;
             int sw;
             if (perfect) { near++; sw = maxSw; ngaps = 0; }
             else {
                 const uint8_t *bases = P.bases + rr.bases_off + (strand ? P.minus_delta : 0);
-                sw = score_no_indels_wave(bases, len, P.refs + P.chromOff[chrom], P.chromLen[chrom], start, lane);
+                const uint8_t *cref = P.refs + P.chromOff[chrom];
+                const int clen = P.chromLen[chrom];
+                sw = score_no_indels_wave(bases, len, cref, clen, start, lane);
+                // the read may belong at the site's stop rather than its start (AbstractMapThread.java:808-815)
+                if (sw < oldScore && oldScore >= maxImperfect && stop - start + 1 != len) {
+                    const int sw2 = score_no_indels_wave(bases, len, cref, clen, stop - len + 1, lane);
+                    if (sw2 >= maxImperfect) {
+                        sw = sw2; start = stop - len + 1; newStart = true;
+                        set_perfect_wave(bases, len, cref, clen, start, stop, lane, perfect, semi);
+                    }
+                }
                 if (sw >= maxImperfect) {
                     near++;
                     stop = start + len - 1; ngaps = 0;
                     if (sw >= maxSw) perfect = semi = 1;
+                    else set_perfect_wave(bases, len, cref, clen, start, stop, lane, perfect, semi);      // :833-837
                 } else if (oldScore >= maxImperfect) forceSlow = true;
             }
             if (lane == 0) {
                 ss[s].score = sw; ss[s].stop = stop; ss[s].ngaps = ngaps; ss[s].perfect = perfect; ss[s].semiperfect = semi;
+                if (newStart) ss[s].start = start;
                 if (P.noIndelScore) P.noIndelScore[r * (long long)P.maxSites + s] = sw;
             }
             if (lane == (s & 63)) { mySw = sw; mySemi = semi; myGaps = ngaps; }

@@ -49,7 +49,7 @@ def usable_cores():
 
 def _emulate_read(oi, om, refb, bp, bm, offsets, key_scores, max_sites, L):
     """The reference's control flow for one read, from the oracle's pieces (probe -> scoreNoIndels -> scoreSlow)."""
-    from oracle.oracle import score_no_indels
+    from oracle.oracle import score_no_indels, set_perfect
     maxSw = 70 + (L - 1) * 100
     maxImp = maxSw - 495
     minMsaLimit = -258 + int(np.float32(0.56) * np.float32(maxSw))
@@ -58,24 +58,36 @@ def _emulate_read(oi, om, refb, bp, bm, offsets, key_scores, max_sites, L):
     except RuntimeError:                      # more than max_sites sites: the probe must report the overflow (nsites = -1)
         return None, None, None
     near, force, sws = 0, False, []
-    for e in sites:
+    for e in sites:                                   # AbstractMapThread.scoreNoIndels, current/align2/AbstractMapThread.java:762-856
+        bases = bm if e["strand"] else bp
         if e["perfect"]:
             sw = maxSw
             near += 1
+            e["gaps"] = []
         else:
-            sw = score_no_indels(bm if e["strand"] else bp, refb, e["start"])
+            old = e["score"]
+            sw = score_no_indels(bases, refb, e["start"])
+            if sw < old and old >= maxImp and e["stop"] - e["start"] + 1 != L:
+                sw2 = score_no_indels(bases, refb, e["stop"] - L + 1)
+                if sw2 >= maxImp:
+                    sw = sw2
+                    e["start"] = e["stop"] - L + 1
+                    e["perfect"], e["semiperfect"] = set_perfect(bases, refb, e["start"], e["stop"])
             if sw >= maxImp:
                 near += 1
                 e["stop"] = e["start"] + L - 1
                 e["gaps"] = []
-            elif e["score"] >= maxImp:
+                if sw >= maxSw:
+                    e["perfect"] = e["semiperfect"] = 1
+                else:
+                    e["perfect"], e["semiperfect"] = set_perfect(bases, refb, e["start"], e["stop"])
+            elif old >= maxImp:
                 force = True
         sws.append(sw)
     dp = []
     if (-near if force else near) < 1:
         for s, e in enumerate(sites):
-            semip = e["semiperfect"] or sws[s] >= maxSw
-            if sws[s] < maxImp and not semip and not e["gaps"]:
+            if sws[s] < maxImp and not e["semiperfect"] and not e["gaps"]:
                 bases = bm if e["strand"] else bp
                 ms = max(sws[s], minMsaLimit)
                 sv, mx = om.fillAndScoreLimited(bases, refb, e["start"] - 4, e["stop"] + 4, ms)

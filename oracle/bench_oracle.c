@@ -101,6 +101,8 @@ typedef struct {
     int64_t mapped, dpJobs, cells;
 } map_arg;
 
+void orc_set_perfect(const uint8_t *bases, int blen, const uint8_t *ref, int reflen, int start, int stop, int32_t *out2);   /* rescue_oracle.c */
+
 static uint8_t comp_base(uint8_t b) {
     switch (b) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'N': return 'N'; default: return 0xFF; }
 }
@@ -133,9 +135,22 @@ static void *map_worker(void *p) {
                 if (sites[s].perfect) { sw[s] = maxSw; near++; }
                 else {
                     const uint8_t *c = w->ix->chromArr[sites[s].chrom];
-                    sw[s] = orc_score_no_indels(sites[s].strand ? bm : bp, L, c, w->ix->chromArrLen[sites[s].chrom], NULL, sites[s].start);
-                    if (sw[s] >= maxImp) { near++; sites[s].stop = sites[s].start + L - 1; sites[s].ngaps = 0; if (sw[s] >= maxSw) sites[s].semiperfect = 1; }
-                    else if (sites[s].score >= maxImp) force = 1;
+                    const uint8_t *bb = sites[s].strand ? bm : bp;
+                    const int cl = w->ix->chromArrLen[sites[s].chrom], old = sites[s].score;
+                    int32_t ps[2];
+                    sw[s] = orc_score_no_indels(bb, L, c, cl, NULL, sites[s].start);
+                    if (sw[s] < old && old >= maxImp && sites[s].stop - sites[s].start + 1 != L) {      /* AbstractMapThread.java:808-815 */
+                        const int sw2 = orc_score_no_indels(bb, L, c, cl, NULL, sites[s].stop - L + 1);
+                        if (sw2 >= maxImp) {
+                            sw[s] = sw2; sites[s].start = sites[s].stop - L + 1;
+                            orc_set_perfect(bb, L, c, cl, sites[s].start, sites[s].stop, ps); sites[s].perfect = ps[0]; sites[s].semiperfect = ps[1];
+                        }
+                    }
+                    if (sw[s] >= maxImp) {
+                        near++; sites[s].stop = sites[s].start + L - 1; sites[s].ngaps = 0;
+                        if (sw[s] >= maxSw) sites[s].perfect = sites[s].semiperfect = 1;
+                        else { orc_set_perfect(bb, L, c, cl, sites[s].start, sites[s].stop, ps); sites[s].perfect = ps[0]; sites[s].semiperfect = ps[1]; }
+                    } else if (old >= maxImp) force = 1;
                 }
             }
             int ok = near > 0;

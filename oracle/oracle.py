@@ -328,3 +328,11 @@ def quick_rescue(bases, ref, minIndex, loc, searchDist, searchRight, idealStart,
         return None
     return dict(start=int(out[1]), stop=int(out[2]), score=int(out[3]), mismatches=int(out[4]), perfect=int(out[5]),
                 semiperfect=int(out[6]), contig=int(out[7]))
+
+
+def set_perfect(bases, ref, start, stop):
+    """SiteScore.setPerfect(bases) for a site [start, stop] of `ref`; returns (perfect, semiperfect)."""
+    b, f = _u8(bases), _u8(ref)
+    out = np.zeros(2, np.int32)
+    lib().orc_set_perfect(_p(b, c_u8p), len(bases), _p(f, c_u8p), len(ref), start, stop, _p(out, c_i32p))
+    return int(out[0]), int(out[1])

@@ -34,6 +34,13 @@ static void set_perfect(const uint8_t *bases, int blen, const uint8_t *ref, int 
     *perfectOut = perfect; *semiOut = semiperfect;
 }
 
+/* SiteScore.setPerfect for callers outside this file (the pipeline emulations): out2 = {perfect, semiperfect} */
+void orc_set_perfect(const uint8_t *bases, int blen, const uint8_t *ref, int reflen, int start, int stop, int32_t *out2) {
+    int p = 0, sp = 0;
+    set_perfect(bases, blen, ref, reflen, start, stop, &p, &sp);
+    out2[0] = p; out2[1] = sp;
+}
+
 /* out8 = {found, start, stop, score, mismatches (ss.slowScore), perfect, semiperfect, maxContigMatches} */
 void orc_quick_rescue(const uint8_t *bases, int blen, const uint8_t *ref, int reflen, int minIndex,
                       int loc, int searchDist, int searchRight, int idealStart, int maxAllowedMismatches,
