@@ -11,7 +11,12 @@
 //   3. otherwise every site with ungapped score < maxImperfectScore and not semiperfect becomes one DP job:
 //      window = site +- SLOW_ALIGN_PADDING, minScore = max(ungapped score, minMsaLimit) (BBMapThread.java:289-309).
 // Not carried over (host-side policies of the mapper, out of scope here): trimList, findTipDeletions, the second wider
-// fill after pad hints (scoreSlow :312-335).
+// fill after pad hints (scoreSlow :312-335), the expected-length cap (:296-303), fixXY / clipTipIndels on the result, and
+// the coupling BETWEEN the sites of one read: scoreSlow raises minMsaLimit to (slowScore - CLEARZONE3) after every site
+// (:375), so a read's later sites can get a higher minScore than its first.  Here every site of a read gets the initial
+// minMsaLimit: identical for reads with one DP candidate (99.99 % of the bench workload), a looser bound -- never a lost
+// alignment -- for the second and later candidates of a read.  A host that needs the exact per-read sequence submits the
+// candidates of a read in rounds through bbmsa_align_batch_device.
 // Sites that carry a gap array go to a second job list (bbmsa_align_gapped_batch_device builds their gapped reference).
 #include <hip/hip_runtime.h>
 
