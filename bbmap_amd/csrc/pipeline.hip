@@ -151,6 +151,9 @@ struct SelectParams {
     int *noIndelScore;             // optional: per (read, site) ungapped score
     int extraFlags;                // OR-ed into every job's flags (e.g. BBMSA_NO_ITERATIONS)
     int gappedCap;                 // capacity of the gapped list
+    uint8_t *ungMatch;             // optional: match strings of the reads finished without DP (see match_no_indels_kernel)
+    int ungStride;
+    int *ungLen;
     int *readState;                // optional, per read: -1 no site, (s << 2) | 1 finished without DP with best site s, 2 sent to DP
     bbmsa_job *gjobs;              // optional second list: jobs for sites that carry a gap array (need makeGref)
     bbmsa_gaps *ggaps;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
         const long long r = r0 + q;
         if (r >= P.nreads) break;
         const int ns = P.nsites[r];
-        if (ns <= 0) { if (ns == 0) cNoSite++; if (P.readState && lane == 0) P.readState[r] = -1; continue; }
+        if (ns <= 0) { if (ns == 0) cNoSite++; if (lane == 0) { if (P.readState) P.readState[r] = -1; if (P.ungLen) P.ungLen[r] = 0; } continue; }
         const bbidx_read rr = P.reads[r];
         const int len = rr.len;
         const int maxSw = 70 + (len - 1) * 100;                        // msa.maxQuality(len)
@@ -247,8 +250,31 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const Selec
         }
         __threadfence_block();                                        // lane 0's site updates before any lane re-reads them
         const int numNear = forceSlow ? -near : near;
-        if (numNear >= 1) { cDone++; if (P.readState && lane == 0) P.readState[r] = (bestSite << 2) | 1; continue; }
-        if (P.readState && lane == 0) P.readState[r] = 2;
+        if (numNear >= 1) {
+            cDone++;
+            if (P.readState && lane == 0) P.readState[r] = (bestSite << 2) | 1;
+            if (P.ungMatch) {
+                // MSA.scoreNoIndelsAndMakeMatchString at the best site (MultiStateAligner11tsJNI.java:1244-1318): the read
+                // and the reference bytes were just scored, so they come from cache
+                __threadfence_block();
+                const bbidx_site sb = ss[bestSite];
+                const int reflen = P.chromLen[sb.chrom];
+                int mlen = len;
+                if (sb.start < 0 || sb.start + len > reflen || len > P.ungStride) mlen = -1;      // the reference returns -99999
+                else {
+                    const uint8_t *bases = P.bases + rr.bases_off + (sb.strand ? P.minus_delta : 0);
+                    const uint8_t *cref = P.refs + P.chromOff[sb.chrom] + sb.start;
+                    uint8_t *outm = P.ungMatch + r * (long long)P.ungStride;
+                    for (int i = lane; i < len; i += 64) {
+                        const int c = bases[i], q2 = cref[i];
+                        outm[i] = (c == q2 && c != 'N') ? 'm' : ((c >= 128 || c == 'N' || q2 >= 128 || q2 == 'N') ? 'N' : 'S');
+                    }
+                }
+                if (lane == 0) P.ungLen[r] = mlen;
+            }
+            continue;
+        }
+        if (lane == 0) { if (P.readState) P.readState[r] = 2; if (P.ungLen) P.ungLen[r] = 0; }
         const int minMsaLimit = -258 + (int)__fmul_rn(P.minRatio, (float)maxSw);     // -CLEARZONE1e + (int)(ratio*maxSwScore)
         for (int s0 = 0; s0 < ns; s0 += 64) {
             const int s = s0 + lane;
@@ -466,7 +492,8 @@ extern "C" int bbpipe_select_jobs_device(void *stream_, int64_t n_reads, const b
                                          int32_t pad, int32_t max_columns, float min_ratio,
                                          bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score,
                                          bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src, int32_t gapped_cap,
-                                         int32_t extra_job_flags, int32_t *read_state) {
+                                         int32_t extra_job_flags, int32_t *read_state,
+                                         uint8_t *ungapped_match, int32_t ungapped_stride, int32_t *ungapped_len) {
     if (n_reads < 0 || max_sites < 1 || pad < 0 || max_columns < 1) { bbmap_set_error("bbpipe_select_jobs_device: bad size"); return BBMAP_E_ARG; }
     if (n_reads == 0) return BBMAP_OK;
     if (!reads || !bases || !nsites || !sites || !chrom_off || !chrom_len || !refs || !jobs || !job_src || !counters) {
@@ -486,6 +513,10 @@ extern "C" int bbpipe_select_jobs_device(void *stream_, int64_t n_reads, const b
     P.extraFlags = extra_job_flags & BBMSA_NO_ITERATIONS;
     P.gappedCap = gapped_cap;
     P.readState = read_state;
+    if ((ungapped_match != nullptr) != (ungapped_len != nullptr) || (ungapped_match && ungapped_stride < 1)) {
+        bbmap_set_error("bbpipe_select_jobs_device: ungapped_match, ungapped_stride and ungapped_len go together"); return BBMAP_E_ARG;
+    }
+    P.ungMatch = ungapped_match; P.ungStride = ungapped_stride; P.ungLen = ungapped_len;
     const long long per_block = bbpipe::SEL_WAVES * bbpipe::SEL_READS_PER_WAVE;
     const long long blocks = (n_reads + per_block - 1) / per_block;
     hipLaunchKernelGGL(bbpipe::select_jobs_kernel, dim3((unsigned)blocks), dim3(64 * bbpipe::SEL_WAVES), 0, stream, P);

@@ -106,14 +106,11 @@ class MapPipeline:
                                                self.pad, self.max_columns, self.min_ratio, self.jobs.data_ptr(),
                                                self.job_src.data_ptr(), self.counters.data_ptr(), self.no_indel.data_ptr(),
                                                self.gjobs.data_ptr(), self.ggaps.data_ptr(), self.gjob_src.data_ptr(), self.gap_cap,
-                                               M.NO_ITERATIONS if self.no_iterations else 0, self.read_state.data_ptr()),
+                                               M.NO_ITERATIONS if self.no_iterations else 0, self.read_state.data_ptr(),
+                                               # reads that need no DP still need their match string (one symbol per base at the
+                                               # best site): the filter writes it on the way
+                                               self.ungapped_match.data_ptr(), self.read_len, self.ungapped_len.data_ptr()),
                    "bbpipe_select_jobs_device")
-        # reads that need no DP still need their match string (one symbol per base at the best site)
-        _lib.check(L.bbpipe_match_no_indels_device(C.c_void_p(stream), n, self.reads.data_ptr(), plus, self.total_bytes,
-                                                   self.sites.data_ptr(), self.max_sites, self.read_state.data_ptr(),
-                                                   self.chrom_off.data_ptr(), self.chrom_len.data_ptr(), self.refs.data_ptr(),
-                                                   self.ungapped_match.data_ptr(), self.read_len, self.ungapped_len.data_ptr()),
-                   "bbpipe_match_no_indels_device")
         cptr = self.counters.data_ptr()
         _lib.check(L.bbmsa_align_batch_device_indirect(self.msa.h, C.c_void_p(stream), C.c_void_p(cptr), self.job_cap,
                                                        self.jobs.data_ptr(), plus, self.refs.data_ptr(), self.results.data_ptr(),

@@ -137,3 +137,31 @@ def test_pipeline_matches_emulation():
                 checked_jobs += 1
     assert checked_jobs > 20 and checked_ungapped > 200
     assert cnt[2] > 0 and checked_gapped > 0
+
+
+def test_match_no_indels_kernel_agrees_with_the_fused_path():
+    """bbpipe_match_no_indels_device (stand-alone) writes what the site filter writes on the way."""
+    import ctypes as C
+    import torch
+    from bbmap_amd import _lib
+    k, L, n = 12, 150, 2000
+    ref = W.make_reference(200000, seed=6, pad=2000)
+    reads, _, _ = W.make_reads_and_jobs(ref, n, read_len=L, seed=10, pad=2000)
+    hi = HostIndex([ref], k=k)
+    offs = make_offsets(L, k, 1.9)
+    pipe = MapPipeline(hi, n, L, offs, [100 * k] * len(offs), max_sites=8, max_columns=256)
+    pipe.load_reads(reads)
+    nj = pipe.step()
+    fused = pipe.fetch(nj)
+    m2 = torch.zeros_like(pipe.ungapped_match)
+    l2 = torch.full_like(pipe.ungapped_len, 77)
+    lib = _lib.load()
+    _lib.check(lib.bbpipe_match_no_indels_device(None, n, pipe.reads.data_ptr(), pipe.bases.data_ptr(), pipe.total_bytes,
+                                                 pipe.sites.data_ptr(), pipe.max_sites, pipe.read_state.data_ptr(),
+                                                 pipe.chrom_off.data_ptr(), pipe.chrom_len.data_ptr(), pipe.refs.data_ptr(),
+                                                 m2.data_ptr(), L, l2.data_ptr()), "bbpipe_match_no_indels_device")
+    torch.cuda.synchronize()
+    l2 = l2.cpu().numpy(); m2 = m2.cpu().numpy().reshape(n, L)
+    assert (l2 == fused["ungapped_len"]).all() and (l2 == L).sum() > 500
+    rows = np.nonzero(l2 == L)[0]
+    assert (m2[rows] == fused["ungapped_match"][rows]).all()
