@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--ref-len", type=int, default=0, help="reference length (default: E. coli K-12)")
     ap.add_argument("--k", type=int, default=13)
     ap.add_argument("--max-sites", type=int, default=8)
+    ap.add_argument("--scaffolds", type=int, default=1,
+                    help="split the reference into this many chromosomes (large genomes: a chromosome must stay below 2^29 bases); "
+                         "the CPU baseline and the parity sample are skipped when > 1")
     ap.add_argument("--repeat-frac", type=float, default=0.0, help="share of the reference drawn from repeat families (SURVEY 8d repeat model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=300)
@@ -197,12 +200,30 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    from bbmap_amd import dist as D0
+    rank0 = rank
     read_len, k = 150, args.k
     ref_len = args.ref_len or W.ECOLI_K12_LEN
-    ref = W.make_reference(ref_len, seed=1, repeat_frac=args.repeat_frac)
+    if args.scaffolds > 1:
+        # e.g. --ref-len 3100000000 --scaffolds 24: an hg38-sized reference; reads are drawn scaffold by scaffold
+        per = ref_len // args.scaffolds
+        chroms = [W.make_reference(per, seed=1000 + i, repeat_frac=args.repeat_frac, families=max(50, 2000 // args.scaffolds))
+                  for i in range(args.scaffolds)]
+        parts = [W.make_reads_and_jobs(c, args.reads // args.scaffolds + 1, read_len=150, seed=D0.shard_seed(2 + 7 * i, rank0))[0]
+                 for i, c in enumerate(chroms)]
+        reads_multi = np.concatenate(parts)[: args.reads * 150]
+        ref = chroms[0]
+    else:
+        chroms, reads_multi = None, None
+        ref = W.make_reference(ref_len, seed=1, repeat_frac=args.repeat_frac)
     # every rank draws its own shard of reads (same generator, different stream); the index is replicated per GPU
     from bbmap_amd import dist as D
-    reads, _, truth = W.make_reads_and_jobs(ref, args.reads, read_len=read_len, seed=D.shard_seed(2, rank))
+    if reads_multi is not None:
+        reads = reads_multi
+        args.no_cpu_baseline = True
+        args.parity_sample = 0
+    else:
+        reads, _, truth = W.make_reads_and_jobs(ref, args.reads, read_len=read_len, seed=D.shard_seed(2, rank))
     offsets = W.make_offsets(read_len, k, 1.9)
     key_scores = [100 * k] * len(offsets)          # GENERATE_KEY_SCORES_FROM_QUALITY needs qualities; synthetic reads have none
     max_sites, max_cols = args.max_sites, 256
@@ -221,7 +242,7 @@ def main():
 
     n = args.reads
     t_ix = time.perf_counter()
-    di = DeviceIndex.build([ref], k=k, device=local_rank)          # IndexMaker4 + analyzeIndex on the device (bbidx_build)
+    di = DeviceIndex.build(chroms if chroms is not None else [ref], k=k, device=local_rank)          # IndexMaker4 + analyzeIndex on the device (bbidx_build)
     torch.cuda.synchronize()
     t_ix = time.perf_counter() - t_ix
     hi = di.host
