@@ -56,19 +56,26 @@ struct U {
 };
 
 // one list per lane (the reference's Quad heap entries), compacted: lanes 0..n-1
+#ifndef BBIDX_LIST_BUF
+#define BBIDX_LIST_BUF 4
+#endif
+constexpr int NB = BBIDX_LIST_BUF;
 struct WL {
     int row, stop, value, offs, ksc;
-    int nxt;                   // sites[row + 1], fetched when the cursor moved to `row`: the gather is in flight while the
-                               // wave works on other lists and has landed by the time this list is popped again
+    int nb[NB], nbuf;          // nb[j] = sites[row + 1 + j] for j < nbuf: the entries after the cursor.  A list is popped one
+                               // entry at a time by one lane, and a load issued for that lane alone costs the wave a full
+                               // memory round trip (s_waitcnt counts in order), so the buffers of ALL lists are refilled
+                               // together, 64 x NB gathers in flight, whenever a popped list finds its buffer empty
     bool live;
     int n, nlive;              // uniform
     const int *sites;          // uniform
 };
 
 __device__ inline int adjustSite(const U &u, int a, int offset, int baseChrom) {
-    if ((a & u.c.siteMask) >= offset) return a - offset;
-    const int ch = u.c.chromOf(a, baseChrom), st = u.c.siteOf(a);
-    return u.c.toNumber(max(st - offset, 0), ch);
+    // a site in the first `offset` bases of its chromosome maps to position 0 of that chromosome (branch-free: both forms
+    // are a handful of ALU ops, and a per-lane branch here would sit in the innermost loop of the probe)
+    const int below = u.c.toNumber(0, u.c.chromOf(a, baseChrom));
+    return (a & u.c.siteMask) >= offset ? a - offset : below;
 }
 
 // BBIndex.maxQuickScore :2473-2487 over lanes 0..n-1 (offsets ascending: the coverage of maxScoreZ :2948-2964 is
@@ -126,11 +133,22 @@ __device__ int quickScoreW(const U &u, int value, int ksc, int offs, int centerI
     return x + Y_MULT * (rl(offs, rightIndex) - rl(offs, centerIndex));
 }
 
+// reloads every live list's look-ahead buffer from its cursor
+__device__ inline void refillLists(WL &L) {
+    const int avail = L.live ? L.stop - L.row - 1 : 0;
+    const int last = L.live ? L.stop - 1 : 0;              // slots past the list's end re-read its last entry (never used)
+#pragma unroll
+    for (int j = 0; j < NB; j++) L.nb[j] = L.sites[min(L.row + 1 + j, last)];
+    L.nbuf = min(avail, NB);
+}
+
 // Pops every list whose head equals `site`, in (site, column) order (QuadHeap.poll/add of the reference's inner
 // loop, BBIndex.java:1637-1666 and :2420-2444).  Returns true when the caller's loop must end (a list ran out and
 // fewer than `cutoff` lists remain, or perfectOnly).
 __device__ bool popSite(const U &u, WL &L, int site, int cutoff, bool perfectOnly, int baseChrom, unsigned &counter) {
+    site = uni(site); cutoff = uni(cutoff); perfectOnly = uni(perfectOnly);
     for (;;) {
+        L.nlive = uni(L.nlive); counter = uni(counter);
         const bool hit = L.live && L.value == site;
         const u64 Pm = __ballot(hit);
         if (!Pm) break;
@@ -150,13 +168,15 @@ __device__ bool popSite(const U &u, WL &L, int site, int cutoff, bool perfectOnl
             L.nlive -= nd;
         }
         counter += (unsigned)popc(Pm);
-        if (hit) {
-            if (dies) L.live = false;
-            else {
-                L.row = row; L.value = adjustSite(u, L.nxt, L.offs, baseChrom);
-                if (row + 1 < L.stop) L.nxt = L.sites[row + 1];
-            }
-        }
+        if (__ballot(hit && !dies && L.nbuf == 0)) refillLists(L);
+        // per-lane cursor update as selects: no EXEC juggling in the innermost loop
+        const bool adv = hit && !dies;
+        const int nv = adjustSite(u, L.nb[0], L.offs, baseChrom);
+        L.live = L.live && !dies;
+        L.row = adv ? row : L.row; L.value = adv ? nv : L.value;
+#pragma unroll
+        for (int j = 0; j + 1 < NB; j++) L.nb[j] = adv ? L.nb[j + 1] : L.nb[j];
+        L.nbuf -= adv ? 1 : 0;
         if (L.nlive == 0) break;
     }
     return false;
@@ -173,6 +193,7 @@ __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, boo
     if (perfectOnly) { approxHitsCutoff = numHits; indelCutoff = 0; }
     else { approxHitsCutoff = max(prevMaxHits, min(p.minApproxHitsToKeep, numHits - 1)); indelCutoff = p.maxIndel2; }
     while (L.nlive > 0) {
+        approxHitsCutoff = uni(approxHitsCutoff); topQscore = uni(topQscore); maxHits = uni(maxHits); L.nlive = uni(L.nlive);
         const int site = wmin(L.live ? L.value : INT_MAX);
         const int centerIndex = __builtin_ctzll(__ballot(L.live && L.value == site));
         const int minsite = site - min(p.maxIndel, indelCutoff), maxsite = site + p.maxIndel2;
@@ -324,7 +345,7 @@ __device__ int extendScoreW(U &u, WaveLds &S, int strand, int value, int offs, i
     }
     for (int i = lane; i < blen; i += 64) if (rb[i] == 'N') S.loc[i] = -2;
     wsync();
-    return calcAffineScoreW(u, S, strand, p.kfilter);
+    return uni(calcAffineScoreW(u, S, strand, p.kfilter));
 }
 
 // BBIndex.makeGapArray :2837-2878 -- rare (a site spanning more than MINGAP + read length); one lane walks LDS
@@ -372,13 +393,12 @@ __device__ void setPerfectW(const U &u, const WaveLds &S, int chrom, int strand,
     if (stop >= reflen) { N += (stop - reflen + 1); perfect = false; }
     if (N > nlimit) return;
     bool anyHard = false, anyCN = false, anyBad = false;
-    for (int j0 = 0; refloc + j0 <= mx; j0 += 64) {
-        const int j = j0 + u.lane;
-        bool bad = false, hard = false, cn = false;
-        if (refloc + j <= mx) {
-            const int c = rb[readloc + j], r = ref[refloc + j];
-            bad = (c != r || c == 'N'); hard = bad && r != 'N'; cn = bad && c == 'N';
-        }
+    const int total = uni(mx - refloc + 1);                 // bases compared; lanes past the end re-read the last one
+    for (int j0 = 0; j0 < total; j0 += 64) {
+        const bool in = j0 + u.lane < total;
+        const int j = in ? j0 + u.lane : total - 1;
+        const int c = rb[readloc + j], r = ref[refloc + j];
+        const bool bad = in && (c != r || c == 'N'), hard = bad && r != 'N', cn = bad && c == 'N';
         const u64 badM = __ballot(bad);
         if (badM) {
             anyBad = true;
@@ -422,6 +442,12 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
     PrevSite pv; pv.idx = -1; pv.chrom = pv.strand = pv.start = pv.stop = pv.score = pv.perfect = pv.semiperfect = pv.ngaps = 0;
     bool finished = false;
     while (L.nlive > 0 && !finished) {
+        // loop-carried uniform state, re-declared uniform at the top of every round (see wavep::uni)
+        approxHitsCutoff = uni(approxHitsCutoff); cutoff = uni(cutoff); qcutoff = uni(qcutoff); currentTopScore = uni(currentTopScore);
+        maxHits = uni(maxHits); perfectsFound = uni(perfectsFound); bestqscore = uni(bestqscore); L.nlive = uni(L.nlive);
+        pv.idx = uni(pv.idx); pv.chrom = uni(pv.chrom); pv.strand = uni(pv.strand); pv.start = uni(pv.start); pv.stop = uni(pv.stop);
+        pv.score = uni(pv.score); pv.perfect = uni(pv.perfect); pv.semiperfect = uni(pv.semiperfect); pv.ngaps = uni(pv.ngaps);
+        ssl.n = uni(ssl.n); ssl.overflow = uni(ssl.overflow); finished = uni(finished); u.cWalk = uni(u.cWalk); u.cExtend = uni(u.cExtend); u.cRefBytes = uni(u.cRefBytes);
         const int site = wmin(L.live ? L.value : INT_MAX);
         const int centerIndex = __builtin_ctzll(__ballot(L.live && L.value == site));
         const int minsite = site - p.maxIndel, maxsite = site + p.maxIndel2;
@@ -474,10 +500,12 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
                         wsync();
                     }
                 }
+                ngaps = uni(ngaps);
                 const bool perfect1 = (score == maxScore && fullyDefined);
                 const bool inbounds = (site2 >= 0 && site3 < u.ix->chromLengths[chrom]);
                 const bool havePrev = pv.idx >= 0;
                 bool makeNew = false, withGaps = false;
+                int wb = 0;
                 if (inbounds && ngaps == 0 && havePrev && pv.chrom == chrom && pv.strand == strand && overlap(pv.start, pv.stop, site2, site3)) {
                     const int betterScore = max(score, pv.score);
                     const int minStart = min(pv.start, site2), maxStop = max(pv.stop, site3);
@@ -488,7 +516,7 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
                         pv.score = betterScore;
                         pv.perfect = (pv.perfect || perfect1 || perfect2) ? 1 : 0;
                         if (pv.perfect) pv.semiperfect = 1;
-                        if (lane == 0) { pd->score = pv.score; pd->perfect = pv.perfect; pd->semiperfect = pv.semiperfect; }
+                        wb = 1;
                     } else if (shortEnough && pv.start == site2 && !pv.semiperfect) {
                         if (perfect2) { }
                         else if (perfect1) {
@@ -500,10 +528,7 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
                             setPerfectW(u, S, pv.chrom, pv.strand, pv.start, pv.stop, pv.perfect, pv.semiperfect);
                         }
                         pv.score = betterScore;
-                        if (lane == 0) {
-                            pd->stop = pv.stop; if (pv.ngaps) pd->gaps[pv.ngaps - 1] = pv.stop;
-                            pd->perfect = pv.perfect; pd->semiperfect = pv.semiperfect; pd->score = pv.score;
-                        }
+                        wb = 2;
                     } else if (shortEnough && pv.stop == site3 && !pv.semiperfect) {
                         if (perfect2) { }
                         else if (perfect1) {
@@ -515,15 +540,23 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
                             setPerfectW(u, S, pv.chrom, pv.strand, pv.start, pv.stop, pv.perfect, pv.semiperfect);
                         }
                         pv.score = betterScore;
-                        if (lane == 0) {
-                            pd->start = pv.start; if (pv.ngaps) pd->gaps[0] = pv.start;
-                            pd->perfect = pv.perfect; pd->semiperfect = pv.semiperfect; pd->score = pv.score;
-                        }
+                        wb = 3;
                     } else makeNew = true;
+                    // the merged site goes back to the list after the if-chain: a lane-0 store inside an arm would share its
+                    // join block with the chain, and every value merged there would count as divergent
+                    wb = uni(wb);
+                    if (wb && lane == 0) {
+                        if (wb == 2) { pd->stop = pv.stop; if (pv.ngaps) pd->gaps[pv.ngaps - 1] = pv.stop; }
+                        if (wb == 3) { pd->start = pv.start; if (pv.ngaps) pd->gaps[0] = pv.start; }
+                        pd->perfect = pv.perfect; pd->semiperfect = pv.semiperfect; pd->score = pv.score;
+                    }
                 } else if (inbounds) { makeNew = true; withGaps = true; }
-                if (makeNew) {
+                pv.chrom = uni(pv.chrom); pv.strand = uni(pv.strand); pv.start = uni(pv.start); pv.stop = uni(pv.stop);
+                pv.score = uni(pv.score); pv.perfect = uni(pv.perfect); pv.semiperfect = uni(pv.semiperfect); perfectsFound = uni(perfectsFound);
+                if (uni(makeNew)) {
                     int sp = perfect1 ? 1 : 0, ssemi = sp;
                     if (!perfect1) setPerfectW(u, S, chrom, strand, site2, site3, sp, ssemi);
+                    sp = uni(sp); ssemi = uni(ssemi);
                     const int sg = withGaps ? ngaps : 0;
                     if (ssl.n >= ssl.cap) { ssl.overflow = true; finished = true; }
                     else {
@@ -545,12 +578,12 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
                         }
                         pv.idx = idx; pv.chrom = chrom; pv.strand = strand; pv.start = site2; pv.stop = site3; pv.score = score;
                         pv.perfect = sp; pv.semiperfect = ssemi; pv.ngaps = sg;
-                        if (stopNow) break;
+                        if (stopNow) finished = true;
                     }
                 }
             }
         }
-        if (finished) break;
+        if (uni(finished)) break;
         if (popSite(u, L, site, approxHitsCutoff, false, baseChrom, u.cWalk)) break;
     }
     bestScores[0] = max(bestScores[0], currentTopScore);
@@ -625,7 +658,8 @@ __device__ int trimByGreedyW(const U &u, WaveLds &S, int off, int ksc, int n, in
         const bool upd = lane < hitsCount && v < ex;
         const u64 earlyM = __ballot(upd && lane != 0 && ex < EARLY);
         const int worstIndex = earlyM ? __builtin_ctzll(earlyM) : hibit(__ballot(upd));
-        const long long worstValue64 = __shfl(v, worstIndex);
+        // readlane, not ds_bpermute: the value steers uniform control flow, and only a readlane tells the compiler so
+        const long long worstValue64 = (long long)(((u64)(unsigned)rl((int)(v >> 32), worstIndex) << 32) | (unsigned)rl((int)v, worstIndex));
         const int worstValue = worstValue64 < INT_MIN ? INT_MIN : (worstValue64 > INT_MAX ? INT_MAX : (int)worstValue64);
         const int worst = listsL[worstIndex];
         const int lenWorst = rl(x, worst);
@@ -676,8 +710,9 @@ __device__ int makeListsW(const U &u, WaveLds &S, WL &L, int block, int baseChro
     L.row = __shfl(h.start, src); L.stop = L.row + __shfl(h.len, src); L.offs = __shfl(off, src); L.ksc = __shfl(ksc, src);
     const int first = __shfl(h.first, src);
     L.value = L.live ? adjustSite(u, first, L.offs, baseChrom) : 0;
-    L.nxt = 0;
-    if (L.live && L.row + 1 < L.stop) L.nxt = L.sites[L.row + 1];
+#pragma unroll
+    for (int j = 0; j < NB; j++) L.nb[j] = 0;
+    refillLists(L);
     return nh;
 }
 
@@ -835,7 +870,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
         for (int chrom = p.minChrom; chrom <= p.maxChrom; chrom = ((chrom & u.c.highMask) + cpb)) ncycles += 2;
         if (ncycles > 64) { result = -2; break; }
         WL L;
-        L.row = L.stop = L.value = L.offs = L.ksc = L.nxt = 0; L.live = false; L.n = L.nlive = 0; L.sites = nullptr;
+        L.row = L.stop = L.value = L.offs = L.ksc = L.nbuf = 0; for (int j = 0; j < NB; j++) L.nb[j] = 0; L.live = false; L.n = L.nlive = 0; L.sites = nullptr;
         int precount = n, prescore = mqs;                 // lane c holds the prescan result of cycle c
         bool dead = false;
         if (prescan) {
@@ -867,7 +902,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
                 qscoreCutoff = max(qscoreCutoff, (int)(bestScores[3] * PRESCAN_QSCORE_THRESH));
             }
         }
-        if (dead) { result = 0; break; }
+        if (uni(dead)) { result = 0; break; }
+        hitsCutoff = uni(hitsCutoff); qscoreCutoff = uni(qscoreCutoff); n = uni(n);
 
         const int maxScore = 70 + (blen - 1) * 100 + sumBS;               // msa.maxQuality(baseScores)
         SiteOut ssl; ssl.v = P.sites + r * (long long)P.maxSites; ssl.n = 0; ssl.cap = P.maxSites; ssl.overflow = false;
@@ -876,6 +912,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
             const int baseChrom = u.c.baseChrom(chrom);
             const int block = baseChrom >> p.chromBits;
             for (int strand = 0; strand < 2 && !quit; strand++, cycle++) {
+                for (int j = 0; j < 6; j++) bestScores[j] = uni(bestScores[j]);
+                ssl.n = uni(ssl.n); ssl.overflow = uni(ssl.overflow); cycle = uni(cycle); quit = uni(quit);
                 if (!prescan || rl(precount, cycle) >= hitsCutoff || rl(prescore, cycle) >= qscoreCutoff) {
                     const int nh = makeListsW(u, S, L, block, baseChrom, keyHits(block, strand), strand ? offM : off, strand ? kscM : ksc, n, p.minApproxHitsToKeep);
                     if (nh >= p.minApproxHitsToKeep)

@@ -11,6 +11,12 @@ typedef unsigned long long u64;
 __device__ inline void wsync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 __device__ inline int rl(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+// Marks a value the algorithm keeps wave-uniform as uniform for the compiler as well.  Without it one value that passed
+// through a VGPR-only operation (ds_bpermute, a per-lane select) makes every branch that depends on it a divergent one:
+// EXEC-mask bookkeeping around each `if`, uniform state held in VGPRs, and s_waitcnt 0 in front of every load.
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
 __device__ inline u64 lt_mask(int lane) { return (1ull << lane) - 1ull; }
 __device__ inline u64 gt_mask(int lane) { return (~0ull << lane) << 1; }
 __device__ inline int hibit(u64 m) { return 63 - __builtin_clzll(m); }
