@@ -60,15 +60,18 @@ struct U {
 #define BBIDX_LIST_BUF 4
 #endif
 constexpr int NB = BBIDX_LIST_BUF;
+typedef const int __attribute__((address_space(1))) *GlobalInts;   // global_load instead of flat_load (no LDS counter traffic)
+constexpr int LANE_UNUSED = -(1 << 30);   // `value` of the lanes past the last list: outside every [minsite, maxsite] window
 struct WL {
     int row, stop, value, offs, ksc;
+    int hv;                    // the list's head for the "smallest head" search: value while the list lives, INT_MAX once it ran
+                               // out (the reference keeps counting an exhausted list's last value as a nearby hit)
     int nb[NB], nbuf;          // nb[j] = sites[row + 1 + j] for j < nbuf: the entries after the cursor.  A list is popped one
                                // entry at a time by one lane, and a load issued for that lane alone costs the wave a full
                                // memory round trip (s_waitcnt counts in order), so the buffers of ALL lists are refilled
                                // together, 64 x NB gathers in flight, whenever a popped list finds its buffer empty
-    bool live;
     int n, nlive;              // uniform
-    const int *sites;          // uniform
+    GlobalInts sites;          // uniform
 };
 
 __device__ inline int adjustSite(const U &u, int a, int offset, int baseChrom) {
@@ -135,26 +138,26 @@ __device__ int quickScoreW(const U &u, int value, int ksc, int offs, int centerI
 
 // reloads every live list's look-ahead buffer from its cursor
 __device__ inline void refillLists(WL &L) {
-    const int avail = L.live ? L.stop - L.row - 1 : 0;
-    const int last = L.live ? L.stop - 1 : 0;              // slots past the list's end re-read its last entry (never used)
+    const bool live = L.hv != INT_MAX;
+    const int avail = live ? L.stop - L.row - 1 : 0;
+    const int last = live ? L.stop - 1 : 0;                // slots past the list's end re-read its last entry (never used)
 #pragma unroll
     for (int j = 0; j < NB; j++) L.nb[j] = L.sites[min(L.row + 1 + j, last)];
     L.nbuf = min(avail, NB);
 }
 
 // Pops every list whose head equals `site`, in (site, column) order (QuadHeap.poll/add of the reference's inner
-// loop, BBIndex.java:1637-1666 and :2420-2444).  Returns true when the caller's loop must end (a list ran out and
-// fewer than `cutoff` lists remain, or perfectOnly).
-__device__ bool popSite(const U &u, WL &L, int site, int cutoff, bool perfectOnly, int baseChrom, unsigned &counter) {
+// loop, BBIndex.java:1637-1666 and :2420-2444).  When the caller's loop must end (a list ran out and fewer than
+// `cutoff` lists remain, or perfectOnly) L.nlive is set to 0.
+__device__ inline void popSite(const U &u, WL &L, int site, int cutoff, bool perfectOnly, int baseChrom, unsigned &counter) {
     site = uni(site); cutoff = uni(cutoff); perfectOnly = uni(perfectOnly);
     for (;;) {
         L.nlive = uni(L.nlive); counter = uni(counter);
-        const bool hit = L.live && L.value == site;
-        const u64 Pm = __ballot(hit);
+        const u64 Pm = mask_eq(L.hv, site);
         if (!Pm) break;
+        const bool hit = L.hv == site;
         const int row = L.row + 1;
-        const bool dies = hit && row >= L.stop;
-        const u64 D = __ballot(dies);
+        const u64 D = Pm & __builtin_amdgcn_sicmp(row, L.stop, 39);      // lists whose last entry this was
         if (D) {
             const int nd = popc(D);
             const int jexit = perfectOnly ? 1 : max(1, L.nlive - cutoff + 1);
@@ -163,23 +166,24 @@ __device__ bool popSite(const U &u, WL &L, int site, int cutoff, bool perfectOnl
                 for (int j = 1; j < jexit; j++) m &= m - 1;
                 const int d = __builtin_ctzll(m);
                 counter += (unsigned)popc(Pm & (lt_mask(d) | (1ull << d)));
-                return true;
+                L.nlive = 0;
+                return;
             }
             L.nlive -= nd;
         }
         counter += (unsigned)popc(Pm);
+        const bool dies = hit && row >= L.stop;
         if (__ballot(hit && !dies && L.nbuf == 0)) refillLists(L);
         // per-lane cursor update as selects: no EXEC juggling in the innermost loop
         const bool adv = hit && !dies;
         const int nv = adjustSite(u, L.nb[0], L.offs, baseChrom);
-        L.live = L.live && !dies;
         L.row = adv ? row : L.row; L.value = adv ? nv : L.value;
+        L.hv = hit ? (dies ? INT_MAX : nv) : L.hv;
 #pragma unroll
         for (int j = 0; j + 1 < NB; j++) L.nb[j] = adv ? L.nb[j + 1] : L.nb[j];
         L.nbuf -= adv ? 1 : 0;
         if (L.nlive == 0) break;
     }
-    return false;
 }
 
 // BBIndex.findMaxQscore2 :2294-2450
@@ -194,11 +198,11 @@ __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, boo
     else { approxHitsCutoff = max(prevMaxHits, min(p.minApproxHitsToKeep, numHits - 1)); indelCutoff = p.maxIndel2; }
     while (L.nlive > 0) {
         approxHitsCutoff = uni(approxHitsCutoff); topQscore = uni(topQscore); maxHits = uni(maxHits); L.nlive = uni(L.nlive);
-        const int site = wmin(L.live ? L.value : INT_MAX);
-        const int centerIndex = __builtin_ctzll(__ballot(L.live && L.value == site));
+        const int site = wmin(L.hv);
         const int minsite = site - min(p.maxIndel, indelCutoff), maxsite = site + p.maxIndel2;
-        const int approxHits = popc(__ballot(u.lane < numHits && L.value >= minsite && L.value <= maxsite));
+        const int approxHits = popc(mask_ule((unsigned)L.value - (unsigned)minsite, (unsigned)(maxsite - minsite)));
         if (approxHits >= approxHitsCutoff) {
+            const int centerIndex = __builtin_ctzll(mask_eq(L.hv, site));
             const int qscore = quickScoreW(u, L.value, L.ksc, L.offs, centerIndex, site, approxHits, numHits)
                              + scoreZ2W(u, L.value, L.offs, site, approxHits, numHits);
             if (qscore > topQscore) {
@@ -208,7 +212,7 @@ __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, boo
                 if (qscore >= mqs) break;
             }
         }
-        if (popSite(u, L, site, approxHitsCutoff, perfectOnly, baseChrom, u.cPrescan)) break;
+        popSite(u, L, site, approxHitsCutoff, perfectOnly, baseChrom, u.cPrescan);
     }
     outQ = topQscore; outHits = maxHits;
 }
@@ -448,12 +452,12 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
         pv.idx = uni(pv.idx); pv.chrom = uni(pv.chrom); pv.strand = uni(pv.strand); pv.start = uni(pv.start); pv.stop = uni(pv.stop);
         pv.score = uni(pv.score); pv.perfect = uni(pv.perfect); pv.semiperfect = uni(pv.semiperfect); pv.ngaps = uni(pv.ngaps);
         ssl.n = uni(ssl.n); ssl.overflow = uni(ssl.overflow); finished = uni(finished); u.cWalk = uni(u.cWalk); u.cExtend = uni(u.cExtend); u.cRefBytes = uni(u.cRefBytes);
-        const int site = wmin(L.live ? L.value : INT_MAX);
-        const int centerIndex = __builtin_ctzll(__ballot(L.live && L.value == site));
+        const int site = wmin(L.hv);
         const int minsite = site - p.maxIndel, maxsite = site + p.maxIndel2;
-        const bool inr = lane < numHits && L.value >= minsite && L.value <= maxsite;
-        const int approxHits = popc(__ballot(inr));
+        const bool inr = (unsigned)L.value - (unsigned)minsite <= (unsigned)(maxsite - minsite);
+        const int approxHits = popc(mask_ule((unsigned)L.value - (unsigned)minsite, (unsigned)(maxsite - minsite)));
         if (approxHits >= approxHitsCutoff) {
+            const int centerIndex = __builtin_ctzll(mask_eq(L.hv, site));
             const int maxNearbySite = wmax(inr ? L.value : site);
             int score;
             int qscore = filter_by_qscore ? quickScoreW(u, L.value, L.ksc, L.offs, centerIndex, site, approxHits, numHits) : qcutoff;
@@ -584,7 +588,7 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
             }
         }
         if (uni(finished)) break;
-        if (popSite(u, L, site, approxHitsCutoff, false, baseChrom, u.cWalk)) break;
+        popSite(u, L, site, approxHitsCutoff, false, baseChrom, u.cWalk);
     }
     bestScores[0] = max(bestScores[0], currentTopScore);
     bestScores[1] = max(bestScores[1], maxHits);
@@ -705,11 +709,12 @@ __device__ int makeListsW(const U &u, WaveLds &S, WL &L, int block, int baseChro
     if (nh < minHits) return nh;
     int cnt;
     const int src = compactSrc(S, u.lane, hit, cnt);
-    L.n = L.nlive = nh; L.sites = u.ix->sites[block];
-    L.live = u.lane < nh;
+    L.n = L.nlive = nh; L.sites = (GlobalInts)u.ix->sites[block];
+    const bool live = u.lane < nh;
     L.row = __shfl(h.start, src); L.stop = L.row + __shfl(h.len, src); L.offs = __shfl(off, src); L.ksc = __shfl(ksc, src);
     const int first = __shfl(h.first, src);
-    L.value = L.live ? adjustSite(u, first, L.offs, baseChrom) : 0;
+    L.value = live ? adjustSite(u, first, L.offs, baseChrom) : LANE_UNUSED;
+    L.hv = live ? L.value : INT_MAX;
 #pragma unroll
     for (int j = 0; j < NB; j++) L.nb[j] = 0;
     refillLists(L);
@@ -870,7 +875,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
         for (int chrom = p.minChrom; chrom <= p.maxChrom; chrom = ((chrom & u.c.highMask) + cpb)) ncycles += 2;
         if (ncycles > 64) { result = -2; break; }
         WL L;
-        L.row = L.stop = L.value = L.offs = L.ksc = L.nbuf = 0; for (int j = 0; j < NB; j++) L.nb[j] = 0; L.live = false; L.n = L.nlive = 0; L.sites = nullptr;
+        L.row = L.stop = L.offs = L.ksc = L.nbuf = 0; L.value = LANE_UNUSED; L.hv = INT_MAX; for (int j = 0; j < NB; j++) L.nb[j] = 0; L.n = L.nlive = 0; L.sites = nullptr;
         int precount = n, prescore = mqs;                 // lane c holds the prescan result of cycle c
         bool dead = false;
         if (prescan) {
