@@ -30,6 +30,12 @@ namespace bbidxw {
 using namespace bbidx;
 using namespace wavep;
 
+#ifdef BBIDX_PHASE_TIMERS
+#define PH_MARK(u, i) do { const unsigned long long now_ = __builtin_readcyclecounter(); (u).ph[i] += (unsigned)(now_ - (u).phT); (u).phT = now_; } while (0)
+#else
+#define PH_MARK(u, i) do { } while (0)
+#endif
+
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int WMAXLEN = 400;      // longest read this kernel takes (longer ones go to the per-lane kernel): keeps a wave's
                                   // LDS share under 160 KiB / 32 so that LDS never limits occupancy
@@ -53,6 +59,9 @@ struct U {
     int k, baseKeyHitScore, indelPenalty, indelPenaltyMult, maxPenalty, scoreZ1Key;
     int lane, blen;
     unsigned cPrescan, cWalk, cExtend, cRefBytes;
+#ifdef BBIDX_PHASE_TIMERS
+    unsigned ph[5]; unsigned long long phT;     // debug build: cycles per phase instead of the work counters
+#endif
 };
 
 // one list per lane (the reference's Quad heap entries), compacted: lanes 0..n-1
@@ -469,7 +478,9 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
                 const int chrom = u.c.chromOf(site, baseChrom);
                 if (shortCircuit && qscore == mqs) score = maxScore;
                 else {
+                    PH_MARK(u, 3);
                     score = extendScoreW(u, S, strand, L.value, L.offs, numHits, chrom, centerIndex);
+                    PH_MARK(u, 4);
                     locArrayValid = true;
                     int mn = INT_MAX, mx = INT_MIN;
                     for (int i = lane; i < blen; i += 64) { const int x = S.loc[i]; if (x > -1) { mn = min(mn, x); mx = max(mx, x); } }
@@ -748,6 +759,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
     u.scoreZ1Key = Z_MULT * p.k;
     u.lane = lane; u.blen = 0;
     u.cPrescan = u.cWalk = u.cExtend = u.cRefBytes = 0;
+#ifdef BBIDX_PHASE_TIMERS
+    for (int j = 0; j < 5; j++) u.ph[j] = 0;
+    u.phT = __builtin_readcyclecounter();
+#endif
     unsigned cSites = 0;
 
     int result = 0;                      // what goes to nsites[r]
@@ -815,6 +830,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
             if (numHits < 3 && numHits < trigger) { key = keyOrig; numHits = countHits(maxLen * 3); }
             if (numHits < 2 && numHits < trigger) { key = keyOrig; numHits = countHits(maxLen * 5); }
         }
+        PH_MARK(u, 0);
         const int nOriginal = n;
         int cnt = cntOrig;
         auto compactKeys = [&]() {
@@ -870,6 +886,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
             pretend = allBasesCovered || n >= nOriginal - 4 || (n >= 9 && (offLast - off0 + p.k) > max(40, (int)(blen * .75f)));
         }
 
+        PH_MARK(u, 1);
         const int cpb = u.c.cpb;
         int ncycles = 0;
         for (int chrom = p.minChrom; chrom <= p.maxChrom; chrom = ((chrom & u.c.highMask) + cpb)) ncycles += 2;
@@ -907,6 +924,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
                 qscoreCutoff = max(qscoreCutoff, (int)(bestScores[3] * PRESCAN_QSCORE_THRESH));
             }
         }
+        PH_MARK(u, 2);
         if (uni(dead)) { result = 0; break; }
         hitsCutoff = uni(hitsCutoff); qscoreCutoff = uni(qscoreCutoff); n = uni(n);
 
@@ -928,6 +946,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
             }
         }
         result = ssl.overflow ? -1 : ssl.n;
+        PH_MARK(u, 3);
         cSites = (unsigned)ssl.n;
     } while (0);
 
@@ -937,8 +956,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
     }
     if (P.stats) {
         if (lane == 0) {
+#ifdef BBIDX_PHASE_TIMERS
+            for (int j = 0; j < 5; j++) atomicAdd(&blockStats[j], u.ph[j] >> 4);
+#else
             atomicAdd(&blockStats[0], u.cPrescan); atomicAdd(&blockStats[1], u.cWalk); atomicAdd(&blockStats[2], u.cExtend);
             atomicAdd(&blockStats[3], u.cRefBytes); atomicAdd(&blockStats[4], cSites);
+#endif
         }
         __syncthreads();
         if (threadIdx.x < 5 && blockStats[threadIdx.x])

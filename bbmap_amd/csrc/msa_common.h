@@ -56,6 +56,60 @@ __host__ __device__ inline bool fully_defined(int b) {
     return b < 128 && (u == 'A' || u == 'C' || u == 'G' || u == 'T' || u == 'U');
 }
 
+// ---- scoring schemes.  The wavefront and narrow kernels are written for the 11ts constants above; the generic kernel is
+// a template over one of these, so that the PacBio parameter set runs through the same literal statement.
+struct Scheme11ts {      // jni/MultiStateAligner11tsJNI.c:18-98
+    static constexpr int OFF = kScoreOffset, TMASK = kTimeMask, SMASK = kScoreMask, MAXT = kMaxTime;
+    static constexpr int MATCH = P_MATCH, MATCH2 = P_MATCH2, SUB = P_SUB, SUBR = P_SUBR, SUB2 = P_SUB2, SUB3 = P_SUB3;
+    static constexpr int INS = P_INS, INS2 = P_INS2, INS3 = P_INS3, INS4 = P_INS4;
+    static constexpr int DEL = P_DEL, DEL2 = P_DEL2, DEL3 = P_DEL3, DEL4 = P_DEL4, DEL5 = P_DEL5;
+    static constexpr int DEL_REF_N = P_DEL_REF_N, GAP = P_GAP;
+    static constexpr int BAR_I1 = 2, BAR_D1 = 3;
+    static constexpr int BADOFF = kBadOff;
+    __host__ __device__ static inline int del_off(int len) { return calc_del_off(len); }
+    __host__ __device__ static inline int ins_cum_off(int len) { return calc_ins_cum_off(len); }
+    __host__ __device__ static inline int col0(int row) { return calc_ins_cum_off(row); }   // ...JNI.java:101-112
+};
+struct Scheme9PacBio {   // current/align2/MultiStateAligner9PacBio.java:2359-2439
+    static constexpr int OFF = 9, TMASK = 0x1FF, SMASK = (int)0xFFFFFE00, MAXT = 511;
+#define BBMSA_PB(x) ((x) * 512)
+    static constexpr int MATCH = BBMSA_PB(90), MATCH2 = BBMSA_PB(100);
+    static constexpr int SUB = BBMSA_PB(-137), SUBR = BBMSA_PB(-157), SUB2 = BBMSA_PB(-49), SUB3 = BBMSA_PB(-25);
+    static constexpr int INS = BBMSA_PB(-205), INS2 = BBMSA_PB(-42), INS3 = BBMSA_PB(-23), INS4 = BBMSA_PB(-8);
+    static constexpr int DEL = BBMSA_PB(-292), DEL2 = BBMSA_PB(-37), DEL3 = BBMSA_PB(-17), DEL4 = BBMSA_PB(-2), DEL5 = BBMSA_PB(-1);
+    static constexpr int DEL_REF_N = BBMSA_PB(-10), GAP = BBMSA_PB(-2);
+    static constexpr int BAR_I1 = 1, BAR_D1 = 1;
+    static constexpr int BADOFF = (-(((1 << 22) - 1) - 2000) - 1) * 512;
+#undef BBMSA_PB
+    __host__ __device__ static inline int del_off(int len) {            // calcDelScoreOffset, ...9PacBio.java:2254-2275
+        if (len <= 0) return 0;
+        int s = DEL;
+        if (len > 80) { s += ((len - 80 + 3) / 4) * DEL5; len = 80; }
+        if (len > 20) { s += (len - 20) * DEL4; len = 20; }
+        if (len > 5) { s += (len - 5) * DEL3; len = 5; }
+        if (len > 1) s += (len - 1) * DEL2;
+        return s;
+    }
+    __host__ __device__ static inline int ins_cum_off(int len) {        // calcInsScoreOffset, :2295-2310
+        if (len <= 0) return 0;
+        int s = INS;
+        if (len > 20) { s += (len - 20) * INS4; len = 20; }
+        if (len > 5) { s += (len - 5) * INS3; len = 5; }
+        if (len > 1) s += (len - 1) * INS2;
+        return s;
+    }
+    // column 0 as the constructor fills it (:91-98): its tiers switch at row 5 and row 20, one row earlier than
+    // calcInsScoreOffset's, so it is its own closed form
+    __host__ __device__ static inline int col0(int row) {
+        if (row <= 0) return 0;
+        int s = INS;
+        if (row >= 20) { s += (row - 19) * INS4; row = 19; }
+        if (row >= 5) { s += (row - 4) * INS3; row = 4; }
+        if (row >= 2) s += (row - 1) * INS2;
+        return s;
+    }
+};
+
 // number of jobs of a launch: a host value, or a counter a previous kernel of the same stream left on the device
 __device__ inline long long job_count(long long njobs, const unsigned int *njobs_dev) {
     if (!njobs_dev) return njobs;

@@ -8,6 +8,7 @@ struct bbmsa_ctx {
     bbmsa_config cfg;
     int device;
     int numCUs;
+    int scheme;                 // BBMSA_SCHEME_*
     // fast kernel geometry
     int G, R, fastCols, tmpBytes, blocks, ldsBytes, tableLen;
     long long dirSlotDwords;

@@ -20,29 +20,29 @@ struct Planes {
     int W;     // row stride (columns + 2)
 };
 
-__device__ inline int ctime(int t) { return t > kMaxTime ? kMaxTime - 3 : t; }
+template <class S> __device__ inline int ctime(int t) { return t > S::MAXT ? S::MAXT - 3 : t; }
 
-__device__ inline int del_step(int streak) {
-    if (streak == 0) return P_DEL;
-    if (streak < 5) return P_DEL2;
-    if (streak < 20) return P_DEL3;
-    if (streak < 80) return P_DEL4;
-    return (streak & 3) == 0 ? P_DEL5 : 0;
+template <class S> __device__ inline int del_step(int streak) {
+    if (streak == 0) return S::DEL;
+    if (streak < 5) return S::DEL2;
+    if (streak < 20) return S::DEL3;
+    if (streak < 80) return S::DEL4;
+    return (streak & 3) == 0 ? S::DEL5 : 0;
 }
-__device__ inline int ins_step(int streak) {   // POINTSoff_INS_ARRAY[streak+1]
-    if (streak == 0) return P_INS;
-    if (streak < 5) return P_INS2;
-    if (streak < 20) return P_INS3;
-    return P_INS4;
+template <class S> __device__ inline int ins_step(int streak) {   // POINTSoff_INS_ARRAY[streak+1] / the tiered form of 9PacBio
+    if (streak == 0) return S::INS;
+    if (streak < 5) return S::INS2;
+    if (streak < 20) return S::INS3;
+    return S::INS4;
 }
-__device__ inline int sub_step(int streak) {   // POINTSoff_SUB_ARRAY[streak+1]
-    if (streak == 0) return P_SUB;
-    if (streak < 5) return P_SUB2;
-    return P_SUB3;
+template <class S> __device__ inline int sub_step(int streak) {   // POINTSoff_SUB_ARRAY[streak+1] / the tiered form of 9PacBio
+    if (streak == 0) return S::SUB;
+    if (streak < 5) return S::SUB2;
+    return S::SUB3;
 }
 
 // one DP cell; `limited` adds the prune tests.  Returns true if any plane is "good".
-__device__ inline bool dp_cell(const Planes &pl, bool limited, int row, int col, int rows, int columns,
+template <class S> __device__ inline bool dp_cell(const Planes &pl, bool limited, int row, int col, int rows, int columns,
                                int call0, int call1, int ref0, int ref1,
                                int vlimit, int hlimit, int floorv, int subfloor) {
     const int up = (row - 1) * pl.W, cur = row * pl.W;
@@ -50,33 +50,33 @@ __device__ inline bool dp_cell(const Planes &pl, bool limited, int row, int col,
     const bool match = (call1 == ref1) && ref1 != 'N';
     const bool prevMatch = (call0 == ref0) && ref0 != 'N';
     const int limit = limited ? max(vlimit, hlimit) : kNegInf;
-    const int limit3 = limited ? max(floorv, match ? limit - P_MATCH2 : limit - P_SUB3) : kNegInf;
+    const int limit3 = limited ? max(floorv, match ? limit - S::MATCH2 : limit - S::SUB3) : kNegInf;
     const int delNeeded = max(0, row - col - 1);
     const int insNeeded = max(0, (rows - row) - (columns - col) - 1);
-    const int delPen = calc_del_off(delNeeded);
-    const int insPen = calc_ins_cum_off(insNeeded);
+    const int delPen = S::del_off(delNeeded);
+    const int insPen = S::ins_cum_off(insNeeded);
     bool anyGood = false;
 
     const int dmP = pl.M[up + col - 1];
-    const int dm = dmP & kScoreMask, dd = pl.D[up + col - 1] & kScoreMask, di = pl.I[up + col - 1] & kScoreMask;
-    const int lm = pl.M[cur + col - 1] & kScoreMask;
+    const int dm = dmP & S::SMASK, dd = pl.D[up + col - 1] & S::SMASK, di = pl.I[up + col - 1] & S::SMASK;
+    const int lm = pl.M[cur + col - 1] & S::SMASK;
     const int ldP = pl.D[cur + col - 1];
-    const int ld = ldP & kScoreMask;
-    const int um = pl.M[up + col] & kScoreMask;
+    const int ld = ldP & S::SMASK;
+    const int um = pl.M[up + col] & S::SMASK;
     const int uiP = pl.I[up + col];
-    const int ui = uiP & kScoreMask;
+    const int ui = uiP & S::SMASK;
 
     if (gap || (limited && dm <= limit3 && dd <= limit3 && di <= limit3)) {
         pl.M[cur + col] = subfloor;
     } else {
-        const int streak = dmP & kTimeMask;
+        const int streak = dmP & S::TMASK;
         int a, bonus, tA;
         if (match) {
-            a = dm + (prevMatch ? P_MATCH2 : P_MATCH); bonus = P_MATCH; tA = prevMatch ? streak + 1 : 1;
+            a = dm + (prevMatch ? S::MATCH2 : S::MATCH); bonus = S::MATCH; tA = prevMatch ? streak + 1 : 1;
         } else {
-            if (ref1 != 'N' && call1 != 'N') a = dm + (prevMatch ? (streak <= 1 ? P_SUBR : P_SUB) : sub_step(streak));
+            if (ref1 != 'N' && call1 != 'N') a = dm + (prevMatch ? (streak <= 1 ? S::SUBR : S::SUB) : sub_step<S>(streak));
             else a = dm;
-            bonus = P_SUB; tA = prevMatch ? 1 : streak + 1;
+            bonus = S::SUB; tA = prevMatch ? 1 : streak + 1;
         }
         const int bb = dd + bonus, cc = di + bonus;
         int score, time;
@@ -87,41 +87,41 @@ __device__ inline bool dp_cell(const Planes &pl, bool limited, int row, int col,
             const int limit2 = delNeeded > 0 ? limit - delPen : (insNeeded > 0 ? limit - insPen : limit);
             if (score >= limit2) anyGood = true; else score = subfloor;
         }
-        pl.M[cur + col] = score | ctime(time);
+        pl.M[cur + col] = score | ctime<S>(time);
     }
 
-    if ((limited && lm <= limit && ld <= limit) || row < 3 || row > rows - 3) {
+    if ((limited && lm <= limit && ld <= limit) || row < S::BAR_D1 || row > rows - S::BAR_D1) {
         pl.D[cur + col] = subfloor;
     } else {
-        const int streak = ldP & kTimeMask;
-        int a = lm + P_DEL, bsc = ld + del_step(streak);
-        if (ref1 == 'N') { a += P_DEL_REF_N; bsc += P_DEL_REF_N; }
-        else if (gap) { a += P_GAP; bsc += P_GAP; }
+        const int streak = ldP & S::TMASK;
+        int a = lm + S::DEL, bsc = ld + del_step<S>(streak);
+        if (ref1 == 'N') { a += S::DEL_REF_N; bsc += S::DEL_REF_N; }
+        else if (gap) { a += S::GAP; bsc += S::GAP; }
         int score, time;
         if (a >= bsc) { score = a; time = 1; } else { score = bsc; time = streak + 1; }
         if (limited) {
             int limit2 = limit;
             if (insNeeded > 0) limit2 = limit - insPen;
-            else if (delNeeded > 0) limit2 = limit - calc_del_off(time + delNeeded) + calc_del_off(time);
+            else if (delNeeded > 0) limit2 = limit - S::del_off(time + delNeeded) + S::del_off(time);
             if (score >= limit2) anyGood = true; else score = subfloor;
         }
-        pl.D[cur + col] = score | ctime(time);
+        pl.D[cur + col] = score | ctime<S>(time);
     }
 
-    if (gap || (limited && um <= limit && ui <= limit) || (row < 2 && col > 1) || (row > rows - 2 && col < columns - 1)) {
+    if (gap || (limited && um <= limit && ui <= limit) || (row < S::BAR_I1 && col > 1) || (row > rows - S::BAR_I1 && col < columns - 1)) {
         pl.I[cur + col] = subfloor;
     } else {
-        const int streak = uiP & kTimeMask;
-        const int a = um + P_INS, bsc = ui + ins_step(streak);
+        const int streak = uiP & S::TMASK;
+        const int a = um + S::INS, bsc = ui + ins_step<S>(streak);
         int score, time;
         if (a >= bsc) { score = a; time = 1; } else { score = bsc; time = streak + 1; }
         if (limited) {
             int limit2 = limit;
             if (delNeeded > 0) limit2 = limit - delPen;
-            else if (insNeeded > 0) limit2 = limit - calc_ins_cum_off(time + insNeeded) + calc_ins_cum_off(time);
+            else if (insNeeded > 0) limit2 = limit - S::ins_cum_off(time + insNeeded) + S::ins_cum_off(time);
             if (score >= limit2) anyGood = true; else score = subfloor;
         }
-        pl.I[cur + col] = score | ctime(time);
+        pl.I[cur + col] = score | ctime<S>(time);
     }
     return anyGood;
 }
@@ -131,27 +131,27 @@ __device__ inline int plane_at(const Planes &pl, int state, int row, int col) {
     return q[row * pl.W + col];
 }
 // predecessor rule shared by traceback2 and score2 (MultiStateAligner11tsJNI.java:389-443)
-__device__ inline int walk_prev(const Planes &pl, int state, int row, int col) {
-    const int time = plane_at(pl, state, row, col) & kTimeMask;
+template <class S> __device__ inline int walk_prev(const Planes &pl, int state, int row, int col) {
+    const int time = plane_at(pl, state, row, col) & S::TMASK;
     if (time > 1) return state;
     if (state == 0) {
-        const int a = plane_at(pl, 0, row - 1, col - 1) & kScoreMask;
-        const int b = plane_at(pl, 1, row - 1, col - 1) & kScoreMask;
-        const int c = plane_at(pl, 2, row - 1, col - 1) & kScoreMask;
+        const int a = plane_at(pl, 0, row - 1, col - 1) & S::SMASK;
+        const int b = plane_at(pl, 1, row - 1, col - 1) & S::SMASK;
+        const int c = plane_at(pl, 2, row - 1, col - 1) & S::SMASK;
         if (a >= b && a >= c) return 0;
         return b >= c ? 1 : 2;
     }
     if (state == 1) {
-        const int a = plane_at(pl, 0, row, col - 1) & kScoreMask, b = plane_at(pl, 1, row, col - 1) & kScoreMask;
+        const int a = plane_at(pl, 0, row, col - 1) & S::SMASK, b = plane_at(pl, 1, row, col - 1) & S::SMASK;
         return a >= b ? 0 : 1;
     }
-    const int a = plane_at(pl, 0, row - 1, col) & kScoreMask, b = plane_at(pl, 2, row - 1, col) & kScoreMask;
+    const int a = plane_at(pl, 0, row - 1, col) & S::SMASK, b = plane_at(pl, 2, row - 1, col) & S::SMASK;
     return a >= b ? 0 : 2;
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void msa_fill_generic_kernel(const GenericParams p) {
+template <class S> __global__ __launch_bounds__(64) void msa_fill_generic_kernel(const GenericParams p) {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long planeInts = (long long)(p.maxRows + 1) * (p.maxColumns + 2);
     int *base = p.matrix + tid * 3 * planeInts;
@@ -208,12 +208,12 @@ __global__ __launch_bounds__(64) void msa_fill_generic_kernel(const GenericParam
         // everything else is whatever an earlier job left behind, as in the reference.
         for (int c = 0; c <= columns + 1; c++) { pl.M[c] = 0; pl.D[c] = 0; pl.I[c] = 0; }
         for (int i = 1; i <= rows; i++) {
-            const int v = calc_ins_cum_off(i);
+            const int v = S::col0(i);
             pl.M[i * pl.W] = v; pl.D[i * pl.W] = v; pl.I[i * pl.W] = v;
         }
 
-        const int maxGain = (rows - 1) * P_MATCH2 + P_MATCH;
-        const int minScoreOff = minScore * 2048;
+        const int maxGain = (rows - 1) * S::MATCH2 + S::MATCH;
+        const int minScoreOff = minScore * (1 << S::OFF);
         long long iters = 0;
         int bestScore, bestCol, bestState;
         bool fillNull = false;
@@ -224,21 +224,21 @@ __global__ __launch_bounds__(64) void msa_fill_generic_kernel(const GenericParam
                 const int call0 = row < 2 ? '?' : rd[row - 2], call1 = rd[row - 1];
                 for (int col = 1; col <= columns; col++) {
                     const int ref0 = col < 2 ? '!' : rf[a + col - 2], ref1 = rf[a + col - 1];
-                    dp_cell(pl, false, row, col, rows, columns, call0, call1, ref0, ref1, 0, 0, kNegInf, subfloor);
+                    dp_cell<S>(pl, false, row, col, rows, columns, call0, call1, ref0, ref1, 0, 0, kNegInf, subfloor);
                 }
             }
             iters = (long long)rows * columns;
         } else {
             const int floorv = minScoreOff - maxGain;
-            const int subfloor = floorv - 5 * P_MATCH2;
+            const int subfloor = floorv - 5 * S::MATCH2;
             for (int c = 1; c <= columns; c++) {
-                pl.M[rows * pl.W + c] = kBadOff; pl.D[rows * pl.W + c] = kBadOff; pl.I[rows * pl.W + c] = kBadOff;
+                pl.M[rows * pl.W + c] = S::BADOFF; pl.D[rows * pl.W + c] = S::BADOFF; pl.I[rows * pl.W + c] = S::BADOFF;
             }
             vertLimit[rows] = minScoreOff;
             bool prevDef = false;
             for (int i = rows - 1; i >= 0; i--) {
                 const bool def = fully_defined(rd[i]);
-                vertLimit[i] = max(vertLimit[i + 1] - (def ? (prevDef ? P_MATCH2 : P_MATCH) : 0), floorv);
+                vertLimit[i] = max(vertLimit[i + 1] - (def ? (prevDef ? S::MATCH2 : S::MATCH) : 0), floorv);
                 prevDef = def;
             }
             horizLimit[columns] = minScoreOff;
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(64) void msa_fill_generic_kernel(const GenericParam
             for (int i = columns - 1; i >= 0; i--) {
                 const int cb = rf[a + i];
                 const bool def = fully_defined(cb);
-                horizLimit[i] = max(horizLimit[i + 1] - (def ? (prevDef ? P_MATCH2 : P_MATCH)
-                                                             : ((prevDef && cb == '-') ? P_DEL : 0)), floorv);
+                horizLimit[i] = max(horizLimit[i + 1] - (def ? (prevDef ? S::MATCH2 : S::MATCH)
+                                                             : ((prevDef && cb == '-') ? S::DEL : 0)), floorv);
                 prevDef = def;
             }
             int minGoodCol = 1, maxGoodCol = columns;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) void msa_fill_generic_kernel(const GenericParam
                 for (int col = colStart; col <= columns; col++) {
                     const int ref0 = col < 2 ? '!' : rf[a + col - 2], ref1 = rf[a + col - 1];
                     iters++;
-                    if (dp_cell(pl, true, row, col, rows, columns, call0, call1, ref0, ref1, vlimit, horizLimit[col], floorv, subfloor)) {
+                    if (dp_cell<S>(pl, true, row, col, rows, columns, call0, call1, ref0, ref1, vlimit, horizLimit[col], floorv, subfloor)) {
                         maxGoodCol = col; if (minGoodCol < 0) minGoodCol = col;
                     }
                     if (col >= colStop) {
@@ -277,13 +277,13 @@ __global__ __launch_bounds__(64) void msa_fill_generic_kernel(const GenericParam
         bestScore = INT_MIN; bestCol = -1; bestState = -1;
         for (int s = 0; s < 3; s++) {
             for (int c = 1; c <= columns; c++) {
-                const int x = plane_at(pl, s, rows, c) & kScoreMask;
+                const int x = plane_at(pl, s, rows, c) & S::SMASK;
                 if (x > bestScore) { bestScore = x; bestCol = c; bestState = s; }
             }
         }
         r.result[0] = rows; r.result[1] = bestCol; r.result[2] = bestState;
         if (limited && bestScore < minScoreOff) { r.result[3] = bestScore; r.result[4] = 1; fillNull = true; }
-        else { r.result[3] = bestScore >> kScoreOffset; r.result[4] = 0; }
+        else { r.result[3] = bestScore >> S::OFF; r.result[4] = 0; }
         r.iterations = iters;
         r.fill_kind = limited ? 0 : 1;
         if (fillNull && mode == BBMSA_FILL_LIMITED) r.status = BBMSA_ST_NULL;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64) void msa_fill_generic_kernel(const GenericParam
             int row = rows, col = bestCol, state = bestState, n = 0, gaps = 0, stateTime = 0;
             bool overflow = false;
             while (row > 0 && col > 0) {
-                const int prev = walk_prev(pl, state, row, col);
+                const int prev = walk_prev<S>(pl, state, row, col);
                 uint8_t sym;
                 if (state == 0) {
                     const int cb = rd[row - 1], rb = rf[a + col - 1];
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(64) void msa_fill_generic_kernel(const GenericParam
                 else if (bestRefStart == a && state == 2) padLeft = stateTime;
                 const int bW = (jb.flags & BBMSA_INTERNAL_GAPPED) ? jb.ref_len : b;      // see msa_fill_fast.hip
                 if (bestRefStop > bW) padRight = max(0, bestRefStop - bW);
-                else if (bestRefStop == bW && bestState == 2) padRight = plane_at(pl, bestState, rows, bestCol) & kTimeMask;
-                r.score[0] = bestScore >> kScoreOffset; r.score[1] = bestRefStart; r.score[2] = bestRefStop;
+                else if (bestRefStop == bW && bestState == 2) padRight = plane_at(pl, bestState, rows, bestCol) & S::TMASK;
+                r.score[0] = bestScore >> S::OFF; r.score[1] = bestRefStart; r.score[2] = bestRefStop;
                 r.score[3] = rows; r.score[4] = bestCol; r.score[5] = bestState;
                 if (padLeft > 0 || padRight > 0) { r.score[6] = padLeft; r.score[7] = padRight; r.score_len = 8; }
                 else r.score_len = 6;
@@ -349,5 +349,8 @@ __global__ __launch_bounds__(64) void msa_fill_generic_kernel(const GenericParam
         p.results[j] = r;
     }
 }
+
+template __global__ void msa_fill_generic_kernel<Scheme11ts>(const GenericParams p);
+template __global__ void msa_fill_generic_kernel<Scheme9PacBio>(const GenericParams p);
 
 }  // namespace bbmsa

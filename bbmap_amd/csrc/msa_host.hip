@@ -15,7 +15,7 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
 
 namespace bbmsa {
 const void *fast_kernel_for(int R, bool banded);
-__global__ void msa_fill_generic_kernel(const GenericParams p);
+template <class S> __global__ void msa_fill_generic_kernel(const GenericParams p);
 __global__ void msa_fill_narrow_kernel(const NarrowParams p);
 }  // namespace bbmsa
 
@@ -48,8 +48,12 @@ static int env_int(const char *name, int dflt) {
 extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     if (!cfg || !out) return fail(BBMAP_E_ARG, "bbmsa_create: null argument");
     *out = nullptr;
-    if (cfg->maxRows < 1 || cfg->maxRows > 640 || cfg->maxColumns < 1 || cfg->maxColumns > 4096)
+    const int scheme = cfg->reserved[2];
+    if (scheme != BBMSA_SCHEME_11TS && scheme != BBMSA_SCHEME_9PACBIO) return fail(BBMAP_E_ARG, "bbmsa_create: unknown scoring scheme");
+    if (scheme == BBMSA_SCHEME_11TS && (cfg->maxRows < 1 || cfg->maxRows > 640 || cfg->maxColumns < 1 || cfg->maxColumns > 4096))
         return fail(BBMAP_E_ARG, "bbmsa_create: maxRows must be 1..640 and maxColumns 1..4096");
+    if (scheme == BBMSA_SCHEME_9PACBIO && (cfg->maxRows < 1 || cfg->maxRows > 6100 || cfg->maxColumns < 1 || cfg->maxColumns > 8192))
+        return fail(BBMAP_E_ARG, "bbmsa_create: the PacBio scheme takes maxRows 1..6100 and maxColumns 1..8192");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(BBMAP_E_NODEVICE, "bbmsa_create: no HIP device (this library has no CPU path)");
@@ -67,6 +71,26 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     c->device = cfg->device;
     c->numCUs = prop.multiProcessorCount;
 
+    c->scheme = scheme;
+    if (scheme != BBMSA_SCHEME_11TS) {
+        // 9PacBio: every job runs in the generic kernel (the wavefront and narrow kernels are written for the 11ts constants
+        // and for reads of at most 640 bases)
+        HIP_TRY(hipMalloc(&c->d_counters, 64));
+        HIP_TRY(hipMemset(c->d_counters, 0, 64));
+        const long long planeInts = (long long)(cfg->maxRows + 1) * (cfg->maxColumns + 2);
+        const long long perThread = 3 * planeInts * 4;
+        long long budget = (long long)env_int("BBMSA_GENERIC_SCRATCH_MB", 8192) << 20;
+        long long threads = budget / perThread;
+        if (threads > 16384) threads = 16384;
+        threads = (threads / 64) * 64;
+        if (threads < 64) threads = 64;
+        c->genThreads = (int)threads;
+        HIP_TRY(hipMalloc(&c->d_matrix, (size_t)(threads * perThread)));
+        HIP_TRY(hipMalloc(&c->d_limits, (size_t)(threads * (cfg->maxRows + cfg->maxColumns + 4) * 4)));
+        for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+        *out = c;
+        return BBMAP_OK;
+    }
     // lanes per job / rows per lane: smallest lane group whose <=10 rows per lane cover maxRows
     int G = cfg->reserved[0];
     if (G != 16 && G != 32 && G != 64) {
@@ -203,6 +227,23 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
     if (match && match_stride < 1) return fail(BBMAP_E_ARG, "bbmsa_align_batch_device: match_stride must be positive");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->scheme != BBMSA_SCHEME_11TS) {
+        HIP_TRY(hipMemsetAsync(c->d_counters, 0, 64, stream));
+        HIP_TRY(hipEventRecord(c->ev[0], stream));
+        HIP_TRY(hipEventRecord(c->ev[3], stream));
+        HIP_TRY(hipEventRecord(c->ev[1], stream));
+        bbmsa::GenericParams gp;
+        gp.jobs = jobs; gp.reads = reads; gp.refs = refs; gp.results = results; gp.match = match;
+        gp.list = nullptr; gp.list_count = nullptr; gp.njobs = n_jobs; gp.njobs_dev = n_jobs_dev;
+        gp.matrix = c->d_matrix; gp.limits = c->d_limits; gp.queue = c->d_counters + 2;
+        gp.match_stride = match_stride; gp.maxRows = c->cfg.maxRows; gp.maxColumns = c->cfg.maxColumns;
+        gp.bandwidth = c->cfg.bandwidth; gp.bandwidthRatio = c->cfg.bandwidthRatio;
+        hipLaunchKernelGGL(bbmsa::msa_fill_generic_kernel<bbmsa::Scheme9PacBio>, dim3(c->genThreads / 64), dim3(64), 0, stream, gp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[2], stream));
+        c->timed = true;
+        return BBMAP_OK;
+    }
     if (n_jobs > c->slowCap) {
         if (c->d_slowList) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_slowList)); c->d_slowList = nullptr; }
         if (c->d_slowList2) { HIP_TRY(hipFree(c->d_slowList2)); c->d_slowList2 = nullptr; }
@@ -270,7 +311,7 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
     gp.matrix = c->d_matrix; gp.limits = c->d_limits; gp.queue = c->d_counters + 2;
     gp.match_stride = match_stride; gp.maxRows = c->cfg.maxRows; gp.maxColumns = c->cfg.maxColumns;
     gp.bandwidth = c->cfg.bandwidth; gp.bandwidthRatio = c->cfg.bandwidthRatio;
-    hipLaunchKernelGGL(bbmsa::msa_fill_generic_kernel, dim3(c->genThreads / 64), dim3(64), 0, stream, gp);
+    hipLaunchKernelGGL(bbmsa::msa_fill_generic_kernel<bbmsa::Scheme11ts>, dim3(c->genThreads / 64), dim3(64), 0, stream, gp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[2], stream));
     c->timed = true;
@@ -392,7 +433,10 @@ extern "C" int bbmsa_fill_packed(bbmsa_ctx *c, const uint8_t *read, int32_t read
         gp.matrix = c->d_matrix; gp.limits = c->d_limits; gp.queue = c->d_counters + 2;
         gp.match_stride = 0; gp.maxRows = c->cfg.maxRows; gp.maxColumns = c->cfg.maxColumns;
         gp.bandwidth = c->cfg.bandwidth; gp.bandwidthRatio = c->cfg.bandwidthRatio;
-        hipLaunchKernelGGL(bbmsa::msa_fill_generic_kernel, dim3(1), dim3(1), 0, nullptr, gp);     // thread 0 owns scratch slot 0
+        if (c->scheme == BBMSA_SCHEME_9PACBIO)
+            hipLaunchKernelGGL(bbmsa::msa_fill_generic_kernel<bbmsa::Scheme9PacBio>, dim3(1), dim3(1), 0, nullptr, gp);
+        else
+            hipLaunchKernelGGL(bbmsa::msa_fill_generic_kernel<bbmsa::Scheme11ts>, dim3(1), dim3(1), 0, nullptr, gp);  // thread 0 owns scratch slot 0
         PK_TRY(hipGetLastError());
         PK_TRY(hipStreamSynchronize(nullptr));
         PK_TRY(hipMemcpy(&res, d_res, sizeof res, hipMemcpyDeviceToHost));

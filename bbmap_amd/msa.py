@@ -32,16 +32,19 @@ assert JOB_DTYPE.itemsize == C.sizeof(bbmsa_job) and RESULT_DTYPE.itemsize == C.
 assert GAPS_DTYPE.itemsize == 68
 
 
+SCHEME_11TS, SCHEME_9PACBIO = 0, 1      # BBMSA_SCHEME_* (include/bbmap_amd.h)
+
+
 class MSAContext:
     """Owns a bbmsa_ctx (one per device and per (maxRows, maxColumns, band) setting)."""
 
     def __init__(self, maxRows=601, maxColumns=3000, bandwidth=0, bandwidthRatio=0.0, device=0,
-                 lanes_per_job=0, fast_cols=0):
+                 lanes_per_job=0, fast_cols=0, scheme=SCHEME_11TS):
         self.L = _lib.load()
         cfg = bbmsa_config()
         cfg.device, cfg.maxRows, cfg.maxColumns = device, maxRows, maxColumns
         cfg.bandwidth, cfg.bandwidthRatio = bandwidth, bandwidthRatio
-        cfg.reserved[0], cfg.reserved[1], cfg.reserved[2] = lanes_per_job, fast_cols, 0
+        cfg.reserved[0], cfg.reserved[1], cfg.reserved[2] = lanes_per_job, fast_cols, scheme
         h = C.c_void_p()
         _lib.check(self.L.bbmsa_create(C.byref(cfg), C.byref(h)), "bbmsa_create")
         self.h = h
@@ -224,3 +227,11 @@ class MultiStateAligner11ts:
                         "score": None if r["score_len"] == 0 else r["score"][:r["score_len"]].tolist(),
                         "match": match[k, :r["match_len"]].tobytes() if r["match_len"] > 0 else None})
         return out
+
+
+class MultiStateAligner9PacBio(MultiStateAligner11ts):
+    """align2.MultiStateAligner9PacBio (current/align2/MultiStateAligner9PacBio.java): the same batched interface with the
+    PacBio parameter set (9 time bits, its own point values and barriers); reads up to 6019 bases."""
+
+    def __init__(self, maxRows=6019, maxColumns=7600, bandwidth=0, bandwidthRatio=0.0, device=0, **kw):
+        super().__init__(maxRows, maxColumns, bandwidth, bandwidthRatio, device, scheme=SCHEME_9PACBIO, **kw)

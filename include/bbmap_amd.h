@@ -98,8 +98,16 @@ typedef struct bbmsa_config {
     int32_t maxColumns;      /* <= 4096                                                              */
     int32_t bandwidth;       /* MSA.bandwidth (static in the reference, MSA.java:864)                */
     float   bandwidthRatio;  /* MSA.bandwidthRatio (MSA.java:865)                                    */
-    int32_t reserved[3];
+    int32_t reserved[3];     /* [0] lanes per job (0 = auto), [1] first-pass column buffer (0 = auto),
+                              * [2] scoring scheme: BBMSA_SCHEME_11TS (0) or BBMSA_SCHEME_9PACBIO            */
 } bbmsa_config;
+
+/* Scoring schemes.  11ts: align2.MultiStateAligner11ts[JNI] (jni/MultiStateAligner11tsJNI.c:18-98), maxRows <= 640,
+ * maxColumns <= 4096.  9PacBio: align2.MultiStateAligner9PacBio (current/align2/MultiStateAligner9PacBio.java:2359-2439:
+ * 9 time bits, its own point values and barriers, column 0 as its constructor fills it), maxRows <= 6100,
+ * maxColumns <= 8192; this round every 9PacBio job runs in the one-job-per-thread kernel. */
+#define BBMSA_SCHEME_11TS 0
+#define BBMSA_SCHEME_9PACBIO 1
 
 int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out);
 void bbmsa_destroy(bbmsa_ctx *ctx);

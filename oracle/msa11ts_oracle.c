@@ -18,8 +18,18 @@ enum { K_GAPLEN = 128, K_GAPBUFFER = 64, K_GAPBUFFER2 = 128, K_MINGAP = 256,
        K_GREF_CUSHION = 128 };          /* align2/Shared.java:21-25, MSA.java:761 */
 #define K_GAPC '-'
 
-#define SH(x) ((int32_t)((x) * 2048))   /* x << SCOREOFFSET without UB on negatives */
+#define SH(x) ((int32_t)((x) * (1 << ORC_SCOREOFFSET)))   /* x << SCOREOFFSET without UB on negatives */
 
+#ifdef ORC_PACBIO   /* current/align2/MultiStateAligner9PacBio.java:2375-2407 */
+enum { PTS_NOREF = 0, PTS_NOCALL = 0, PTS_MATCH = 90, PTS_MATCH2 = 100,
+       PTS_SUB = -137, PTS_SUBR = -157, PTS_SUB2 = -49, PTS_SUB3 = -25,
+       PTS_INS = -205, PTS_INS2 = -42, PTS_INS3 = -23, PTS_INS4 = -8,
+       PTS_DEL = -292, PTS_DEL2 = -37, PTS_DEL3 = -17, PTS_DEL4 = -2, PTS_DEL5 = -1,
+       PTS_DEL_REF_N = -10, PTS_GAP = -2 };
+enum { K_TIMESLIP = 4, K_MASK5 = 3, K_BARRIER_I1 = 1, K_BARRIER_D1 = 1,
+       K_LIM3 = 5, K_LIM4 = 20, K_LIM5 = 80, K_MAX_TIME = 511 };
+#define NTAB 8200     /* insNeeded / delNeeded reach the read length (<= 6019 rows) */
+#else
 enum { PTS_NOREF = 0, PTS_NOCALL = 0, PTS_MATCH = 70, PTS_MATCH2 = 100,
        PTS_SUB = -127, PTS_SUBR = -147, PTS_SUB2 = -51, PTS_SUB3 = -25,
        PTS_INS = -395, PTS_INS2 = -39, PTS_INS3 = -23, PTS_INS4 = -8,
@@ -27,14 +37,15 @@ enum { PTS_NOREF = 0, PTS_NOCALL = 0, PTS_MATCH = 70, PTS_MATCH2 = 100,
        PTS_DEL_REF_N = -10, PTS_GAP = -2 /* 0-max(1,128/64) */ };
 enum { K_TIMESLIP = 4, K_MASK5 = 3, K_BARRIER_I1 = 2, K_BARRIER_D1 = 3,
        K_LIM3 = 5, K_LIM4 = 20, K_LIM5 = 80, K_MAX_TIME = 2047 };
+#define NTAB 604
+#endif
 
-#define K_MAX_SCORE ((((1 << 20) - 1)) - 2000)
+#define K_MAX_SCORE ((((1 << (32 - ORC_TIMEBITS - 1)) - 1)) - 2000)
 #define K_MIN_SCORE (0 - K_MAX_SCORE)
 #define K_BAD (K_MIN_SCORE - 1)
 #define K_BADOFF SH(K_BAD)
 #define K_MINOFF_SCORE SH(K_MIN_SCORE)
 
-#define NTAB 604
 static int32_t T_INS[NTAB], T_INSoff[NTAB], T_INS_C[NTAB], T_INSoff_C[NTAB];
 static int32_t T_SUB[NTAB], T_SUBoff[NTAB];
 static int8_t  T_B2N[128];
@@ -99,7 +110,11 @@ orc_msa *orc_msa_new(int maxRows, int maxColumns) {
             int32_t prev = (i < 2) ? 0 : plane[(size_t)(i - 1) * W];
             /* rows beyond the 604-entry table keep extending with the last tier (INS4);
              * the reference only ever builds 601-row matrices for this aligner. */
+#ifdef ORC_PACBIO      /* ...9PacBio.java:91-98: tiers by `i<LIMIT`, one row earlier than the 11ts array */
+            int32_t step = (i < 2) ? i * SH(PTS_INS) : (i < K_LIM3) ? SH(PTS_INS2) : (i < K_LIM4) ? SH(PTS_INS3) : SH(PTS_INS4);
+#else
             int32_t step = (i < NTAB) ? T_INSoff[i] : SH(PTS_INS4);
+#endif
             plane[(size_t)i * W] = prev + step;
         }
     }

@@ -26,11 +26,20 @@
 extern "C" {
 #endif
 
-/* jni/MultiStateAligner11tsJNI.c:30-39 */
+/* jni/MultiStateAligner11tsJNI.c:30-39; with -DORC_PACBIO the same source restates
+ * align2.MultiStateAligner9PacBio (current/align2/MultiStateAligner9PacBio.java:2359-2369) and is
+ * built into liboracle_pacbio.so (fills, traceback2 and score2 only: that class's scoreNoIndels /
+ * calcAffineScore variants differ from 11ts in more than constants and are NOT restated). */
+#ifdef ORC_PACBIO
+#define ORC_TIMEBITS 9
+#define ORC_TIMEMASK 0x1FF
+#define ORC_SCOREMASK ((int32_t)0xFFFFFE00)
+#else
 #define ORC_TIMEBITS 11
-#define ORC_SCOREOFFSET ORC_TIMEBITS
 #define ORC_TIMEMASK 0x7FF
 #define ORC_SCOREMASK ((int32_t)0xFFFFF800)
+#endif
+#define ORC_SCOREOFFSET ORC_TIMEBITS
 
 typedef struct orc_msa {
     int maxRows, maxColumns;          /* current/align2/MSA.java:66-69 */

@@ -17,8 +17,8 @@ c_u8p = C.POINTER(C.c_uint8)
 c_i8p = C.POINTER(C.c_int8)
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+def build(force=False, pacbio=False):
+    so = os.path.join(_HERE, "liboracle_pacbio.so" if pacbio else "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     stale = force or not os.path.exists(so) or any(
         os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
@@ -27,21 +27,35 @@ def build(force=False):
     return so
 
 
+def _declare_msa(L):
+    L.orc_msa_new.restype = C.c_void_p
+    L.orc_msa_new.argtypes = [C.c_int, C.c_int]
+    L.orc_msa_free.argtypes = [C.c_void_p]
+    for name in ("orc_points_ins_array", "orc_pointsoff_ins_array", "orc_points_ins_array_c",
+                 "orc_pointsoff_ins_array_c", "orc_points_sub_array", "orc_pointsoff_sub_array"):
+        getattr(L, name).restype = c_i32p
+    L.orc_base_to_number.restype = c_i8p
+    L.orc_calc_del_score_offset.restype = C.c_int32
+    L.orc_calc_ins_score_offset.restype = C.c_int32
+    return L
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
-        L.orc_msa_new.restype = C.c_void_p
-        L.orc_msa_new.argtypes = [C.c_int, C.c_int]
-        L.orc_msa_free.argtypes = [C.c_void_p]
-        for name in ("orc_points_ins_array", "orc_pointsoff_ins_array", "orc_points_ins_array_c",
-                     "orc_pointsoff_ins_array_c", "orc_points_sub_array", "orc_pointsoff_sub_array"):
-            getattr(L, name).restype = c_i32p
-        L.orc_base_to_number.restype = c_i8p
-        L.orc_calc_del_score_offset.restype = C.c_int32
-        L.orc_calc_ins_score_offset.restype = C.c_int32
-        _LIB = L
+        _LIB = _declare_msa(C.CDLL(build()))
     return _LIB
+
+
+_LIB_PB = None
+
+
+def lib_pacbio():
+    """The DP restatement compiled with the MultiStateAligner9PacBio constants (fills, traceback2, score2 only)."""
+    global _LIB_PB
+    if _LIB_PB is None:
+        _LIB_PB = _declare_msa(C.CDLL(build(pacbio=True)))
+    return _LIB_PB
 
 
 def _u8(b):
@@ -68,8 +82,9 @@ class MSAStruct(C.Structure):
 class OracleMSA:
     """Mirror of align2.MSA's interface over the C restatement."""
 
-    def __init__(self, maxRows=601, maxColumns=3000, bandwidth=0, bandwidthRatio=0.0):
-        self.L = lib()
+    def __init__(self, maxRows=601, maxColumns=3000, bandwidth=0, bandwidthRatio=0.0, scheme="11ts"):
+        assert scheme in ("11ts", "9pacbio")
+        self.L = lib() if scheme == "11ts" else lib_pacbio()
         self.h = self.L.orc_msa_new(maxRows, maxColumns)
         if not self.h:
             raise MemoryError("orc_msa_new failed")

@@ -1,0 +1,105 @@
+"""GPU parity for SURVEY D11 (the MultiStateAligner9PacBio parameter set): the HIP path through the C ABI against the
+restatement compiled with the PacBio constants (oracle/liboracle_pacbio.so).  Parity is pinned by restatement only: the
+reference holds no known answers for this class and there is no JVM to produce any."""
+import random
+
+import numpy as np
+import pytest
+
+from bbmap_amd import msa as M
+from oracle.oracle import OracleMSA
+from tests.problems import rand_seq
+from tests.test_msa_gpu import oracle_align
+
+pytestmark = pytest.mark.gpu
+
+
+def pacbio_problems(seed, n, lo=60, hi=700):
+    """Reads with PacBio-like errors (indel-rich) against a padded window of their origin."""
+    rng = random.Random(seed)
+    genome = rand_seq(rng, 6000)
+    out = []
+    for _ in range(n):
+        L = rng.randint(lo, hi)
+        s = rng.randint(50, len(genome) - L - 200)
+        rd = bytearray(genome[s:s + L])
+        i = 0
+        err = rng.choice([0.0, 0.03, 0.12, 0.2])
+        while i < len(rd):
+            x = rng.random()
+            if x < err * 0.45:
+                rd.insert(i, ord(rng.choice("ACGT"))); i += 2
+            elif x < err * 0.8 and len(rd) > 30:
+                del rd[i]
+            elif x < err:
+                rd[i] = ord(rng.choice("ACGTN")); i += 1
+            else:
+                i += 1
+        rd = bytes(rd[:hi + 40])
+        pad = rng.choice([4, 8, 30])
+        a = max(0, s - pad)
+        b = min(len(genome) - 1, s + L + pad + rng.randint(0, 25))
+        maxq = 90 + 100 * (len(rd) - 1)
+        ms = rng.choice([0, int(maxq * 0.3), int(maxq * 0.56), int(maxq * 0.8), maxq - 50])
+        out.append((rd, genome, a, b, ms))
+    return out
+
+
+def check(problems, flags, maxRows=800, maxColumns=1100):
+    al = M.MultiStateAligner9PacBio(maxRows, maxColumns)
+    got = al.align(problems, flags)
+    om = OracleMSA(maxRows, maxColumns, scheme="9pacbio")
+    n_null = 0
+    for k, (p, g) in enumerate(zip(problems, got)):
+        exp = oracle_align(om, p[0], p[1], p[2], p[3], p[4], flags)
+        ctx = "job %d rows=%d cols=%d ms=%d" % (k, len(p[0]), p[3] - p[2] + 1, p[4])
+        if exp["result"] is not None:
+            assert g["result"] == exp["result"], ctx
+        else:
+            assert g["status"] == M.ST_NULL, ctx
+            n_null += 1
+        assert g["status"] == exp["status"], ctx
+        assert g["iterations"] == exp["iterations"], ctx
+        assert g["fill_kind"] == exp["fill_kind"], ctx
+        assert g["score"] == exp["score"], ctx
+        assert g["match"] == exp["match"], ctx
+    al.ctx.close()
+    return n_null
+
+
+def test_pacbio_perfect_read_scores_90_plus_100_per_base():
+    rng = random.Random(3)
+    g = rand_seq(rng, 900)
+    rd = g[200:500]
+    al = M.MultiStateAligner9PacBio(400, 500)
+    r = al.align([(rd, g, 190, 520, 20000)], M.FILL_LIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK)[0]
+    assert r["result"] == [300, 310, 0, 90 + 100 * 299, 0] and r["iterations"] == 49168
+    assert r["match"] == b"m" * 300
+    r = al.align([(rd, g, 190, 520, 0)], M.FILL_UNLIMITED_RAW)[0]
+    assert r["result"][:4] == [300, 310, 0, 90 + 100 * 299] and r["iterations"] == 300 * 331
+    al.ctx.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_pacbio_fill_score_traceback(seed):
+    probs = pacbio_problems(seed, 120)
+    n_null = check(probs, M.FILL_AND_SCORE_LIMITED | M.DO_TRACEBACK)
+    assert 0 < n_null < len(probs)
+
+
+def test_pacbio_raw_modes():
+    probs = pacbio_problems(9, 80, lo=40, hi=400)
+    check(probs, M.FILL_LIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK)
+    check(probs, M.FILL_UNLIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK)
+
+
+def test_pacbio_long_read():
+    """One 3 kb read: beyond anything the 11ts kernels take (640 rows)."""
+    rng = random.Random(5)
+    g = rand_seq(rng, 5000)
+    rd = bytearray(g[700:3700])
+    for pos in range(100, 2900, 97):
+        del rd[pos]
+    rd = bytes(rd)
+    check([(rd, g, 680, 3760, int((90 + 100 * (len(rd) - 1)) * 0.5))], M.FILL_AND_SCORE_LIMITED | M.DO_TRACEBACK,
+          maxRows=3100, maxColumns=3300)
