@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 ((halfband < 1 || halfband * 3 > columns) && (columns > rows + min(170, rows + 20)))) limited = false;
             else { limited = true; minScore -= 120; }
         }
-        const bool fits = rows <= G * R && columns <= p.fastCols;
+        const bool fits = rows <= G * R && columns <= p.fastCols && columns >= rows - 2;   // (narrower windows: see the cell)
         const bool needGeneric = shapeOK && !fits;
         const bool run = shapeOK && !needGeneric;
         // Banded fill (jni/...c:441-442): a row may only extend one column past the last good column of the
@@ -325,9 +325,14 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const int limit = limitP - 2048;
                 const int delNeeded = max(0, row - c - 1);
                 const int insNeeded = max(0, (rows - row) - insNeededBase);
-                int delPen = delC[delNeeded];
-                int insPen = insC[insNeeded];
+                // A cell needs deletions (left of the corridor) or insertions (right of it), never both: jobs whose window is
+                // more than two columns narrower than the read, the only shape where both can hold, are handed on at job
+                // setup.  So one table serves the cell: X = delC or insC, pen0 = X[needed], and the "still needed after this
+                // streak" term X[time + needed] - X[time] of the plane that continues such a run.
                 const bool needDel = delNeeded > 0, needIns = insNeeded > 0;
+                const int need = delNeeded + insNeeded;
+                const int *X = needDel ? delC : insC;
+                int pen0 = X[need];
                 const int pruneVal = subfloor;                          // what an unvisited cell reads as
 
                 // ---- match / substitution plane
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const int t3 = max(floorP, limitP - (match ? P_MATCH2 : P_SUB3));
                 const bool pruneM = !act || gap || (max(dgM, max(dgD, dgI)) < t3);
                 int subx = subExt[min(streakM, 5)];
-                asm volatile("" : "+v"(subx), "+v"(delPen), "+v"(insPen));
+                asm volatile("" : "+v"(subx), "+v"(pen0));
                 int addA = prevMatch ? (streakM <= 1 ? P_SUBR : P_SUB) : subx;
                 addA = (refN || cl1 == 'N') ? 0 : addA;
                 addA = match ? (prevMatch ? P_MATCH2 : P_MATCH) : addA;
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const bool aWinsM = sa >= sbc;
                 const int scoreM = max(sa, sbc);
                 const int timeM = (aWinsM && (match == prevMatch)) ? streakM + 1 : 1;
-                const int penM = needDel ? delPen : insPen;
+                const int penM = pen0;
                 const bool goodM = !pruneM && (scoreM + penM >= limit);
                 const int nM = goodM ? (scoreM | timeM) : pruneVal;
 
@@ -361,11 +366,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const bool aWinsD = dsa >= dsb;
                 const int scoreD = max(dsa, dsb) + refPen;
                 const int timeD = aWinsD ? 1 : streakD + 1;
-                int d2 = delC[timeD + delNeeded] - delC[timeD];          // 0 when no deletion is still needed
-                asm volatile("" : "+v"(d2));
-                const int penD = needIns ? insPen : d2;
-                const bool goodD = !pruneD && (scoreD + penD >= limit);
-                const int nD = goodD ? (scoreD | (timeD > kMaxTime ? kMaxTime - 3 : timeD)) : pruneVal;
+                // (penD and goodD follow the insertion plane: they share its table lookup)
 
                 // ---- insertion plane (row above, same column)
                 const int streakI = upI & kTimeMask;
@@ -380,9 +381,13 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const bool aWinsI = isa >= isb;
                 const int scoreI = max(isa, isb);
                 const int timeI = aWinsI ? 1 : streakI + 1;
-                int i2 = insC[timeI + insNeeded] - insC[timeI];          // 0 when no insertion is still needed
-                asm volatile("" : "+v"(i2));
-                const int penI = needDel ? delPen : i2;
+                const int timeX = needDel ? timeD : timeI;
+                int x2 = X[timeX + need] - X[timeX];                     // 0 when nothing is still needed
+                asm volatile("" : "+v"(x2));
+                const int penD = needIns ? pen0 : x2;
+                const bool goodD = !pruneD && (scoreD + penD >= limit);
+                const int nD = goodD ? (scoreD | (timeD > kMaxTime ? kMaxTime - 3 : timeD)) : pruneVal;
+                const int penI = needDel ? pen0 : x2;
                 const bool goodI = !pruneI && (scoreI + penI >= limit);
                 const int nI = goodI ? (scoreI | timeI) : pruneVal;
 
