@@ -234,7 +234,7 @@ extern "C" int bbidx_build(int32_t device, int32_t k, int32_t chromBits, int32_t
             const int first = b * cpb > 1 ? b * cpb : 1, last = (b * cpb + cpb - 1) < nchroms ? (b * cpb + cpb - 1) : nchroms;
             long long npos = 0;
             for (int ch = first; ch <= last; ch++) npos += chromArrLen[ch] > k ? chromArrLen[ch] - k : 0;
-            if (npos > 0x7fffffffLL) { bbmap_set_error("bbidx_build: more than 2^31 positions in one block"); rc = BBMAP_E_ARG; goto fail; }
+            if (npos > 0x7fffffffLL - 64) { bbmap_set_error("bbidx_build: more than 2^31 - 64 positions in one block"); rc = BBMAP_E_ARG; goto fail; }   // (cursor look-ahead stays in int range)
             BHIP(hipMemset(d_cnt32, 0, (size_t)nkeys * 4));
             int *d_sites = nullptr, *d_starts = nullptr;
             BHIP(hipMalloc(&d_starts, (size_t)(nkeys + 1) * 4)); c->allocs.push_back(d_starts);

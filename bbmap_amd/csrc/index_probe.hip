@@ -752,6 +752,9 @@ extern "C" int bbidx_create(int32_t device, const bbidx_index_desc *d, bbidx_ctx
     const bbidx_params &p = d->params;
     if (p.k < 8 || p.k > 15 || p.chromBits < 0 || p.chromBits > 16 || d->nblocks < 1 || d->nchroms < 1)
         return ifail(BBMAP_E_ARG, "bbidx_create: bad index geometry (k must be 8..15)");
+    for (int b = 0; b < d->nblocks; b++)
+        if (d->numSites[b] < 0 || (long long)d->numSites[b] > 0x7fffffffLL - 64)
+            return ifail(BBMAP_E_ARG, "bbidx_create: a block holds more than 2^31 - 64 sites");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ifail(BBMAP_E_NODEVICE, "bbidx_create: no HIP device (no CPU path)");
     if (device < 0 || device >= ndev) return ifail(BBMAP_E_ARG, "bbidx_create: bad device ordinal");

@@ -70,6 +70,10 @@ struct U {
 #endif
 constexpr int NB = BBIDX_LIST_BUF;
 typedef const int __attribute__((address_space(1))) *GlobalInts;   // global_load instead of flat_load (no LDS counter traffic)
+#ifndef BBIDX_BULK_MIN
+#define BBIDX_BULK_MIN 256
+#endif
+constexpr int BULK_MIN_ENTRIES = BBIDX_BULK_MIN;      // bulkSkip is tried only when a strand's lists hold at least this many entries
 constexpr int LANE_UNUSED = -(1 << 30);   // `value` of the lanes past the last list: outside every [minsite, maxsite] window
 struct WL {
     int row, stop, value, offs, ksc;
@@ -80,6 +84,7 @@ struct WL {
                                // memory round trip (s_waitcnt counts in order), so the buffers of ALL lists are refilled
                                // together, 64 x NB gathers in flight, whenever a popped list finds its buffer empty
     int n, nlive;              // uniform
+    int bulk;                  // uniform: > 0 = rounds until bulkSkip may be tried again, < 0 = lists too short to bother
     GlobalInts sites;          // uniform
 };
 
@@ -195,6 +200,64 @@ __device__ inline void popSite(const U &u, WL &L, int site, int cutoff, bool per
     }
 }
 
+// Skips, in one step, list entries the reference's loop would pop one by one without ever scoring them.
+//
+// A site s is scored only if at least `cutoff` lists hold a value in [s - lo, s + maxIndel2].  Let e be the number of
+// exhausted lists whose last value can still fall into such a window (value >= site - lo), m = cutoff - 1 - e, and hc the
+// (m+1)-th smallest head.  Heads only grow, so for every later site s < T = hc - maxIndel2 the lists ranked m+1 and up lie
+// beyond s + maxIndel2: at most m live lists and e exhausted ones are in its window, fewer than `cutoff`.  Every list whose
+// head is below T therefore moves straight to its first entry >= T (found by galloping, all lists of the wave probing
+// together), except that a list never gives up its last entry here: running out has consequences (the loop's exit rule)
+// that stay with popSite.  The pops are counted as the reference would count them.
+__device__ inline void bulkSkip(const U &u, WL &L, int site, int lo, int cutoff, int baseChrom, unsigned &counter) {
+    const bbidx_params &p = u.ix->p;
+    const bool live = L.hv != INT_MAX;
+    const int e = popc(__ballot(!live && u.lane < L.n && L.value >= site - lo));
+    const int kth = cutoff - e;                              // 1-based rank of the head that bounds the skip
+    if (kth < 2) { L.bulk = 8; return; }
+    int T = INT_MAX;
+    if (kth <= L.nlive) {
+        int rank = 0;
+        for (u64 m = __ballot(live); m; m &= m - 1) {
+            const int i = __builtin_ctzll(m);
+            const int v = rl(L.hv, i);
+            rank += (v < L.hv || (v == L.hv && i < u.lane)) ? 1 : 0;
+        }
+        const u64 K = __ballot(live && rank == kth - 1);
+        const int hc = rl(L.hv, __builtin_ctzll(K));
+        T = hc - p.maxIndel2;
+    }
+    const int last = L.stop - 1;
+    bool act = live && L.hv < T && L.row < last;
+    if (!__ballot(act)) { L.bulk = 8; return; }
+    // first index in (row, last] whose adjusted value is >= T, or `last`: exponential probe, then bisection
+    int a = L.row, b = last, step = 1;
+    bool bracketed = false;
+    while (__ballot(act)) {
+        const int probe = bracketed ? a + ((b - a) >> 1) : ((b - a > step) ? a + step : b);   // (row indices reach 2^31: no a + b)
+        const int idx = act ? probe : 0;
+        const int v = adjustSite(u, L.sites[idx], L.offs, baseChrom);
+        if (act) {
+            if (v < T) {
+                a = probe;
+                if (!bracketed) { step <<= 1; if (probe == b) act = false; }       // every entry is below T: stop at the last
+            } else { b = probe; bracketed = true; }
+            if (bracketed && b - a <= 1) act = false;
+        }
+    }
+    const bool moved = live && L.hv < T && L.row < last;
+    const int np = moved ? b : L.row;
+    const int total = wsum(np - L.row);
+    counter += (unsigned)total;
+    if (moved) {
+        L.row = np;
+        L.value = adjustSite(u, L.sites[np], L.offs, baseChrom);
+        L.hv = L.value;
+    }
+    refillLists(L);
+    L.bulk = total < 8 ? 16 : 0;
+}
+
 // BBIndex.findMaxQscore2 :2294-2450
 __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, bool perfectOnly, int numKeys, int mqsAllKeys,
                                 int &outQ, int &outHits) {
@@ -221,6 +284,8 @@ __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, boo
                 if (qscore >= mqs) break;
             }
         }
+        else if (approxHitsCutoff >= 2 && L.bulk == 0) { bulkSkip(u, L, site, min(p.maxIndel, indelCutoff), approxHitsCutoff, baseChrom, u.cPrescan); continue; }
+        if (L.bulk > 0) L.bulk--;
         popSite(u, L, site, approxHitsCutoff, perfectOnly, baseChrom, u.cPrescan);
     }
     outQ = topQscore; outHits = maxHits;
@@ -599,6 +664,8 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
             }
         }
         if (uni(finished)) break;
+        if (approxHits < approxHitsCutoff && approxHitsCutoff >= 2 && L.bulk == 0) { bulkSkip(u, L, site, p.maxIndel, approxHitsCutoff, baseChrom, u.cWalk); continue; }
+        if (L.bulk > 0) L.bulk--;
         popSite(u, L, site, approxHitsCutoff, false, baseChrom, u.cWalk);
     }
     bestScores[0] = max(bestScores[0], currentTopScore);
@@ -729,6 +796,7 @@ __device__ int makeListsW(const U &u, WaveLds &S, WL &L, int block, int baseChro
 #pragma unroll
     for (int j = 0; j < NB; j++) L.nb[j] = 0;
     refillLists(L);
+    L.bulk = wsum(live ? L.stop - L.row : 0) >= BULK_MIN_ENTRIES ? 0 : -1;
     return nh;
 }
 
@@ -892,7 +960,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
         for (int chrom = p.minChrom; chrom <= p.maxChrom; chrom = ((chrom & u.c.highMask) + cpb)) ncycles += 2;
         if (ncycles > 64) { result = -2; break; }
         WL L;
-        L.row = L.stop = L.offs = L.ksc = L.nbuf = 0; L.value = LANE_UNUSED; L.hv = INT_MAX; for (int j = 0; j < NB; j++) L.nb[j] = 0; L.n = L.nlive = 0; L.sites = nullptr;
+        L.row = L.stop = L.offs = L.ksc = L.nbuf = 0; L.value = LANE_UNUSED; L.hv = INT_MAX; for (int j = 0; j < NB; j++) L.nb[j] = 0; L.n = L.nlive = 0; L.bulk = -1; L.sites = nullptr;
         int precount = n, prescore = mqs;                 // lane c holds the prescan result of cycle c
         bool dead = false;
         if (prescan) {
