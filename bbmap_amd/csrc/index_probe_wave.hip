@@ -73,7 +73,11 @@ typedef const int __attribute__((address_space(1))) *GlobalInts;   // global_loa
 #ifndef BBIDX_BULK_MIN
 #define BBIDX_BULK_MIN 256
 #endif
-constexpr int BULK_MIN_ENTRIES = BBIDX_BULK_MIN;      // bulkSkip is tried only when a strand's lists hold at least this many entries
+constexpr int BULK_MIN_ENTRIES = BBIDX_BULK_MIN;
+#ifndef BBIDX_BATCH_MIN
+#define BBIDX_BATCH_MIN 64
+#endif
+constexpr int BATCH_MIN_ENTRIES = BBIDX_BATCH_MIN;        // batchPop likewise (the tests also run a build with both at 0)      // bulkSkip is tried only when a strand's lists hold at least this many entries
 constexpr int LANE_UNUSED = -(1 << 30);   // `value` of the lanes past the last list: outside every [minsite, maxsite] window
 struct WL {
     int row, stop, value, offs, ksc;
@@ -85,6 +89,7 @@ struct WL {
                                // together, 64 x NB gathers in flight, whenever a popped list finds its buffer empty
     int n, nlive;              // uniform
     int bulk;                  // uniform: > 0 = rounds until bulkSkip may be tried again, < 0 = lists too short to bother
+    int bwait;                 // uniform: rounds until batchPop is tried again, < 0 = lists too short to bother
     GlobalInts sites;          // uniform
 };
 
@@ -258,6 +263,52 @@ __device__ inline void bulkSkip(const U &u, WL &L, int site, int lo, int cutoff,
     L.bulk = total < 8 ? 16 : 0;
 }
 
+// Pops several list heads in one step.  Every head below W = the smallest *second* entry of any list (a list at its last
+// entry contributes its head: its pop is a death and stays with popSite) comes before every other entry in the global
+// order, so the reference pops exactly these heads next, in ascending order.  For each of them the window count "as of
+// that pop" is evaluated against the other lists' positions at that moment: lists with a smaller head have moved to
+// their next entry, all others are where they are.  The batch ends in front of the first site that reaches the cutoff
+// (that site gets the full treatment in the ordinary path, from the same state the reference has there); the heads in
+// front of it are advanced together.  In the prescan a site seen by one list only has a fixed quick score
+// (keyScore + scoreZ1Key, quickScore/scoreZ2 with one approximate hit) and feeds nothing but the running maximum, so at a
+// cutoff of 1 such sites are folded into `topQscore`/`maxHits` here; anything else at that cutoff ends the batch.
+// Returns the number of entries consumed (0: nothing done).
+__device__ inline int batchPop(const U &u, WL &L, int lo, int hi, int cutoff, bool prescan, int &topQscore, int &maxHits, int mqs,
+                               int baseChrom, unsigned &counter) {
+    const bool live = L.hv != INT_MAX;
+    const bool hasNext = live && L.row + 1 < L.stop;
+    if (__ballot(hasNext && L.nbuf == 0)) refillLists(L);
+    const int nx = adjustSite(u, L.nb[0], L.offs, baseChrom);            // the list's second entry (where hasNext)
+    const int W = wmin(hasNext ? nx : L.hv);
+    const u64 B = __builtin_amdgcn_sicmp(L.hv, W, 40);                    // heads < W
+    if (popc(B) < 2) return 0;
+    const int ceff = prescan ? max(cutoff, 2) : cutoff;
+    const unsigned span = (unsigned)(lo + hi);
+    int firstQual = INT_MAX;
+    for (u64 m = B; m; m &= m - 1) {
+        const int s = rl(L.hv, __builtin_ctzll(m));
+        const int cur = L.hv < s ? nx : L.value;                          // where each list stands when s is popped
+        const int cnt = popc(mask_ule((unsigned)cur - (unsigned)(s - lo), span));
+        if (cnt >= ceff) firstQual = min(firstQual, s);
+    }
+    const int bound = min(W, firstQual);
+    const bool pop = L.hv < bound;
+    const int np = popc(__builtin_amdgcn_sicmp(L.hv, bound, 40));
+    if (np == 0) return 0;
+    if (prescan && cutoff <= 1) {
+        const int q = wmax(pop ? L.ksc + u.scoreZ1Key : INT_MIN);
+        if (q >= mqs) return 0;                                           // the reference's loop would end there
+        if (q > topQscore) { maxHits = max(maxHits, 1); topQscore = q; }
+    }
+    counter += (unsigned)np;
+    L.row += pop ? 1 : 0;
+    L.value = pop ? nx : L.value; L.hv = pop ? nx : L.hv;
+#pragma unroll
+    for (int j = 0; j + 1 < NB; j++) L.nb[j] = pop ? L.nb[j + 1] : L.nb[j];
+    L.nbuf -= pop ? 1 : 0;
+    return np;
+}
+
 // BBIndex.findMaxQscore2 :2294-2450
 __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, bool perfectOnly, int numKeys, int mqsAllKeys,
                                 int &outQ, int &outHits) {
@@ -270,6 +321,10 @@ __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, boo
     else { approxHitsCutoff = max(prevMaxHits, min(p.minApproxHitsToKeep, numHits - 1)); indelCutoff = p.maxIndel2; }
     while (L.nlive > 0) {
         approxHitsCutoff = uni(approxHitsCutoff); topQscore = uni(topQscore); maxHits = uni(maxHits); L.nlive = uni(L.nlive);
+        if (numHits >= 2 && L.bwait == 0) {
+            if (batchPop(u, L, min(p.maxIndel, indelCutoff), p.maxIndel2, approxHitsCutoff, true, topQscore, maxHits, mqs, baseChrom, u.cPrescan) > 0) continue;
+            L.bwait = 3;
+        } else if (L.bwait > 0) L.bwait--;
         const int site = wmin(L.hv);
         const int minsite = site - min(p.maxIndel, indelCutoff), maxsite = site + p.maxIndel2;
         const int approxHits = popc(mask_ule((unsigned)L.value - (unsigned)minsite, (unsigned)(maxsite - minsite)));
@@ -526,6 +581,11 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
         pv.idx = uni(pv.idx); pv.chrom = uni(pv.chrom); pv.strand = uni(pv.strand); pv.start = uni(pv.start); pv.stop = uni(pv.stop);
         pv.score = uni(pv.score); pv.perfect = uni(pv.perfect); pv.semiperfect = uni(pv.semiperfect); pv.ngaps = uni(pv.ngaps);
         ssl.n = uni(ssl.n); ssl.overflow = uni(ssl.overflow); finished = uni(finished); u.cWalk = uni(u.cWalk); u.cExtend = uni(u.cExtend); u.cRefBytes = uni(u.cRefBytes);
+        if (approxHitsCutoff >= 2 && L.bwait == 0) {
+            int unusedQ = 0, unusedH = 0;
+            if (batchPop(u, L, p.maxIndel, p.maxIndel2, approxHitsCutoff, false, unusedQ, unusedH, 0, baseChrom, u.cWalk) > 0) continue;
+            L.bwait = 3;
+        } else if (L.bwait > 0) L.bwait--;
         const int site = wmin(L.hv);
         const int minsite = site - p.maxIndel, maxsite = site + p.maxIndel2;
         const bool inr = (unsigned)L.value - (unsigned)minsite <= (unsigned)(maxsite - minsite);
@@ -796,7 +856,9 @@ __device__ int makeListsW(const U &u, WaveLds &S, WL &L, int block, int baseChro
 #pragma unroll
     for (int j = 0; j < NB; j++) L.nb[j] = 0;
     refillLists(L);
-    L.bulk = wsum(live ? L.stop - L.row : 0) >= BULK_MIN_ENTRIES ? 0 : -1;
+    const int entries = wsum(live ? L.stop - L.row : 0);
+    L.bulk = entries >= BULK_MIN_ENTRIES ? 0 : -1;
+    L.bwait = entries >= BATCH_MIN_ENTRIES ? 0 : -1;
     return nh;
 }
 
@@ -960,7 +1022,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
         for (int chrom = p.minChrom; chrom <= p.maxChrom; chrom = ((chrom & u.c.highMask) + cpb)) ncycles += 2;
         if (ncycles > 64) { result = -2; break; }
         WL L;
-        L.row = L.stop = L.offs = L.ksc = L.nbuf = 0; L.value = LANE_UNUSED; L.hv = INT_MAX; for (int j = 0; j < NB; j++) L.nb[j] = 0; L.n = L.nlive = 0; L.bulk = -1; L.sites = nullptr;
+        L.row = L.stop = L.offs = L.ksc = L.nbuf = 0; L.value = LANE_UNUSED; L.hv = INT_MAX; for (int j = 0; j < NB; j++) L.nb[j] = 0; L.n = L.nlive = 0; L.bulk = -1; L.bwait = -1; L.sites = nullptr;
         int precount = n, prescore = mqs;                 // lane c holds the prescan result of cycle c
         bool dead = false;
         if (prescan) {
