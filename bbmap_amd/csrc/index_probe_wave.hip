@@ -77,6 +77,10 @@ constexpr int BULK_MIN_ENTRIES = BBIDX_BULK_MIN;
 #ifndef BBIDX_BATCH_MIN
 #define BBIDX_BATCH_MIN 64
 #endif
+#ifndef BBIDX_BWAIT
+#define BBIDX_BWAIT 0
+#endif
+constexpr int BATCH_RETRY = BBIDX_BWAIT;                  // ordinary rounds after a batch that found nothing to do
 constexpr int BATCH_MIN_ENTRIES = BBIDX_BATCH_MIN;        // batchPop likewise (the tests also run a build with both at 0)      // bulkSkip is tried only when a strand's lists hold at least this many entries
 constexpr int LANE_UNUSED = -(1 << 30);   // `value` of the lanes past the last list: outside every [minsite, maxsite] window
 struct WL {
@@ -323,7 +327,7 @@ __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, boo
         approxHitsCutoff = uni(approxHitsCutoff); topQscore = uni(topQscore); maxHits = uni(maxHits); L.nlive = uni(L.nlive);
         if (numHits >= 2 && L.bwait == 0) {
             if (batchPop(u, L, min(p.maxIndel, indelCutoff), p.maxIndel2, approxHitsCutoff, true, topQscore, maxHits, mqs, baseChrom, u.cPrescan) > 0) continue;
-            L.bwait = 3;
+            L.bwait = BATCH_RETRY;
         } else if (L.bwait > 0) L.bwait--;
         const int site = wmin(L.hv);
         const int minsite = site - min(p.maxIndel, indelCutoff), maxsite = site + p.maxIndel2;
@@ -584,7 +588,7 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
         if (approxHitsCutoff >= 2 && L.bwait == 0) {
             int unusedQ = 0, unusedH = 0;
             if (batchPop(u, L, p.maxIndel, p.maxIndel2, approxHitsCutoff, false, unusedQ, unusedH, 0, baseChrom, u.cWalk) > 0) continue;
-            L.bwait = 3;
+            L.bwait = BATCH_RETRY;
         } else if (L.bwait > 0) L.bwait--;
         const int site = wmin(L.hv);
         const int minsite = site - p.maxIndel, maxsite = site + p.maxIndel2;

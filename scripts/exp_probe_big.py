@@ -15,4 +15,5 @@ pipe.load_reads(reads)
 for _ in range(2):
     nj = pipe.step()
 st, ms = pipe.probe_stats()
+print("raw stats", st)
 print("probe %.1f ms for %d reads; prescan entries %d, walk entries %d, extend calls %d; per read %.0f / %.0f" % (ms, n, st[0], st[1], st[2], st[0] / n, st[1] / n))
