@@ -202,6 +202,7 @@ extern "C" int bbidx_build(int32_t device, int32_t k, int32_t chromBits, int32_t
         c = new (std::nothrow) bbidx_ctx();
         if (!c) { bbmap_set_error("bbidx_build: out of memory"); return BBMAP_E_NOMEM; }
         c->device = device; c->kernelKind = BBIDX_KERNEL_AUTO; c->blocks = prop.multiProcessorCount * 8;
+        c->totalSites = 0;
         memset(&c->dev, 0, sizeof c->dev);
         const int nblocks = (nchroms >> chromBits) + 1;
         const int cpb = 1 << chromBits, shift = 31 - chromBits, lowMask = cpb - 1;
@@ -235,6 +236,7 @@ extern "C" int bbidx_build(int32_t device, int32_t k, int32_t chromBits, int32_t
             long long npos = 0;
             for (int ch = first; ch <= last; ch++) npos += chromArrLen[ch] > k ? chromArrLen[ch] - k : 0;
             if (npos > 0x7fffffffLL - 64) { bbmap_set_error("bbidx_build: more than 2^31 - 64 positions in one block"); rc = BBMAP_E_ARG; goto fail; }   // (cursor look-ahead stays in int range)
+            c->totalSites += npos;
             BHIP(hipMemset(d_cnt32, 0, (size_t)nkeys * 4));
             int *d_sites = nullptr, *d_starts = nullptr;
             BHIP(hipMalloc(&d_starts, (size_t)(nkeys + 1) * 4)); c->allocs.push_back(d_starts);

@@ -17,6 +17,7 @@ struct bbidx_ctx {
     hipEvent_t ev[2];
     bool timed;
     int kernelKind;       // BBIDX_KERNEL_*
+    long long totalSites; // list entries over all blocks (picks the wave kernel's long-list variant)
 };
 
 

@@ -767,6 +767,8 @@ extern "C" int bbidx_create(int32_t device, const bbidx_index_desc *d, bbidx_ctx
     c->device = device;
     c->kernelKind = BBIDX_KERNEL_AUTO;
     c->blocks = prop.multiProcessorCount * 8;
+    c->totalSites = 0;
+    for (int b = 0; b < d->nblocks; b++) c->totalSites += (long long)d->numSites[b];
     const size_t keyspace = (size_t)1 << (2 * p.k);
     int rc = BBMAP_OK;
     std::vector<const int *> hs((size_t)d->nblocks), hsi((size_t)d->nblocks);
@@ -828,7 +830,11 @@ extern "C" int bbidx_find_batch_device_rc(bbidx_ctx *c, void *stream_, int64_t n
     IHIP(hipEventRecord(c->ev[0], stream));
     if (c->kernelKind == BBIDX_KERNEL_AUTO) {
         // one read per wavefront; reads it cannot take (more than 64 keys) are marked and picked up by the per-lane kernel
-        const int rc = bbidx_launch_wave(P, stream);
+        // average list length >= 1/2: the variant with batched pops / bulk skips (it gates them per strand by list size);
+        // below that (small genomes) the plain variant, which is a few per cent faster there
+        bool longLists = c->totalSites * 2 >= (1LL << (2 * c->dev.p.k)) * (long long)c->dev.nblocks;
+        if (const char *ev = getenv("BBIDX_LONG_LISTS")) { if (*ev) longLists = atoi(ev) != 0; }      // tests force either variant
+        const int rc = bbidx_launch_wave(P, stream, longLists);
         if (rc != BBMAP_OK) return rc;
         P.onlyPending = 1;
     }

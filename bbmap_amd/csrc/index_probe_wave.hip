@@ -314,7 +314,7 @@ __device__ inline int batchPop(const U &u, WL &L, int lo, int hi, int cutoff, bo
 }
 
 // BBIndex.findMaxQscore2 :2294-2450
-__device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, bool perfectOnly, int numKeys, int mqsAllKeys,
+template <bool LONG> __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, bool perfectOnly, int numKeys, int mqsAllKeys,
                                 int &outQ, int &outHits) {
     const bbidx_params &p = u.ix->p;
     const int numHits = L.n;
@@ -325,10 +325,10 @@ __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, boo
     else { approxHitsCutoff = max(prevMaxHits, min(p.minApproxHitsToKeep, numHits - 1)); indelCutoff = p.maxIndel2; }
     while (L.nlive > 0) {
         approxHitsCutoff = uni(approxHitsCutoff); topQscore = uni(topQscore); maxHits = uni(maxHits); L.nlive = uni(L.nlive);
-        if (numHits >= 2 && L.bwait == 0) {
+        if (LONG && numHits >= 2 && L.bwait == 0) {
             if (batchPop(u, L, min(p.maxIndel, indelCutoff), p.maxIndel2, approxHitsCutoff, true, topQscore, maxHits, mqs, baseChrom, u.cPrescan) > 0) continue;
             L.bwait = BATCH_RETRY;
-        } else if (L.bwait > 0) L.bwait--;
+        } else if (LONG && L.bwait > 0) L.bwait--;
         const int site = wmin(L.hv);
         const int minsite = site - min(p.maxIndel, indelCutoff), maxsite = site + p.maxIndel2;
         const int approxHits = popc(mask_ule((unsigned)L.value - (unsigned)minsite, (unsigned)(maxsite - minsite)));
@@ -343,8 +343,8 @@ __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, boo
                 if (qscore >= mqs) break;
             }
         }
-        else if (approxHitsCutoff >= 2 && L.bulk == 0) { bulkSkip(u, L, site, min(p.maxIndel, indelCutoff), approxHitsCutoff, baseChrom, u.cPrescan); continue; }
-        if (L.bulk > 0) L.bulk--;
+        else if (LONG && approxHitsCutoff >= 2 && L.bulk == 0) { bulkSkip(u, L, site, min(p.maxIndel, indelCutoff), approxHitsCutoff, baseChrom, u.cPrescan); continue; }
+        if (LONG && L.bulk > 0) L.bulk--;
         popSite(u, L, site, approxHitsCutoff, perfectOnly, baseChrom, u.cPrescan);
     }
     outQ = topQscore; outHits = maxHits;
@@ -556,7 +556,7 @@ struct SiteOut { bbidx_site *v; int n, cap; bool overflow; };
 struct PrevSite { int idx, chrom, strand, start, stop, score, perfect, semiperfect, ngaps; };
 
 // BBIndex.slowWalk3 :1219-1706
-__device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int mqs, int baseChrom_,
+template <bool LONG> __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int mqs, int baseChrom_,
                            SiteOut &ssl, int *bestScores, bool allBasesCovered, int maxScore, bool fullyDefined) {
     const bbidx_params &p = u.ix->p;
     const int blen = u.blen, lane = u.lane;
@@ -585,11 +585,11 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
         pv.idx = uni(pv.idx); pv.chrom = uni(pv.chrom); pv.strand = uni(pv.strand); pv.start = uni(pv.start); pv.stop = uni(pv.stop);
         pv.score = uni(pv.score); pv.perfect = uni(pv.perfect); pv.semiperfect = uni(pv.semiperfect); pv.ngaps = uni(pv.ngaps);
         ssl.n = uni(ssl.n); ssl.overflow = uni(ssl.overflow); finished = uni(finished); u.cWalk = uni(u.cWalk); u.cExtend = uni(u.cExtend); u.cRefBytes = uni(u.cRefBytes);
-        if (approxHitsCutoff >= 2 && L.bwait == 0) {
+        if (LONG && approxHitsCutoff >= 2 && L.bwait == 0) {
             int unusedQ = 0, unusedH = 0;
             if (batchPop(u, L, p.maxIndel, p.maxIndel2, approxHitsCutoff, false, unusedQ, unusedH, 0, baseChrom, u.cWalk) > 0) continue;
             L.bwait = BATCH_RETRY;
-        } else if (L.bwait > 0) L.bwait--;
+        } else if (LONG && L.bwait > 0) L.bwait--;
         const int site = wmin(L.hv);
         const int minsite = site - p.maxIndel, maxsite = site + p.maxIndel2;
         const bool inr = (unsigned)L.value - (unsigned)minsite <= (unsigned)(maxsite - minsite);
@@ -728,8 +728,8 @@ __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int
             }
         }
         if (uni(finished)) break;
-        if (approxHits < approxHitsCutoff && approxHitsCutoff >= 2 && L.bulk == 0) { bulkSkip(u, L, site, p.maxIndel, approxHitsCutoff, baseChrom, u.cWalk); continue; }
-        if (L.bulk > 0) L.bulk--;
+        if (LONG && approxHits < approxHitsCutoff && approxHitsCutoff >= 2 && L.bulk == 0) { bulkSkip(u, L, site, p.maxIndel, approxHitsCutoff, baseChrom, u.cWalk); continue; }
+        if (LONG && L.bulk > 0) L.bulk--;
         popSite(u, L, site, approxHitsCutoff, false, baseChrom, u.cWalk);
     }
     bestScores[0] = max(bestScores[0], currentTopScore);
@@ -844,7 +844,7 @@ __device__ inline KeyHit minusView(int lane, int n, int cntRC, int startR, int l
 }
 
 // BBIndex.getHits (:354-391) + the heap fill at the top of slowWalk3/findMaxQscore2: builds the compacted lists
-__device__ int makeListsW(const U &u, WaveLds &S, WL &L, int block, int baseChrom, const KeyHit &h, int off, int ksc, int n, int minHits) {
+template <bool LONG> __device__ int makeListsW(const U &u, WaveLds &S, WL &L, int block, int baseChrom, const KeyHit &h, int off, int ksc, int n, int minHits) {
     const bool hit = u.lane < n && h.cnt > 0 && h.len > 0 && h.first != -1;
     const u64 M = __ballot(hit);
     const int nh = popc(M);
@@ -860,16 +860,19 @@ __device__ int makeListsW(const U &u, WaveLds &S, WL &L, int block, int baseChro
 #pragma unroll
     for (int j = 0; j < NB; j++) L.nb[j] = 0;
     refillLists(L);
-    const int entries = wsum(live ? L.stop - L.row : 0);
-    L.bulk = entries >= BULK_MIN_ENTRIES ? 0 : -1;
-    L.bwait = entries >= BATCH_MIN_ENTRIES ? 0 : -1;
+    L.bulk = L.bwait = -1;
+    if (LONG) {
+        const int entries = wsum(live ? L.stop - L.row : 0);
+        L.bulk = entries >= BULK_MIN_ENTRIES ? 0 : -1;
+        L.bwait = entries >= BATCH_MIN_ENTRIES ? 0 : -1;
+    }
     return nh;
 }
 
 #ifndef BBIDX_WAVE_OCC
 #define BBIDX_WAVE_OCC 6
 #endif
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wave_kernel(const Params P) {
+template <bool LONG> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wave_kernel(const Params P) {
     __shared__ WaveLds lds[WAVES_PER_BLOCK];
     __shared__ unsigned blockStats[5];
     __shared__ uint8_t compLut[256];      // AminoAcid.baseToComplementExtended
@@ -1035,11 +1038,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
                 const int baseChrom = u.c.baseChrom(chrom);
                 const int block = baseChrom >> p.chromBits;
                 for (int pmi = 0; pmi < 2 && !earlyOut; pmi++, cycle++) {
-                    const int nh = makeListsW(u, S, L, block, baseChrom, keyHits(block, pmi), pmi ? offM : off, pmi ? kscM : ksc, n, minHitsToScore);
+                    const int nh = makeListsW<LONG>(u, S, L, block, baseChrom, keyHits(block, pmi), pmi ? offM : off, pmi ? kscM : ksc, n, minHitsToScore);
                     if (nh < minHitsToScore) { if (lane == cycle) { prescore = -9999; precount = 0; } }
                     else {
                         int tq, th;
-                        findMaxQscore2W(u, L, baseChrom, minHitsToScore, bestqscore >= mqs && pretend, n, mqs, tq, th);
+                        findMaxQscore2W<LONG>(u, L, baseChrom, minHitsToScore, bestqscore >= mqs && pretend, n, mqs, tq, th);
                         if (lane == cycle) { prescore = tq; precount = th; }
                         bestqscore = max(tq, bestqscore); maxHits = max(maxHits, th);
                         if (bestqscore >= mqs && pretend) { minHitsToScore = max(minHitsToScore, maxHits); earlyOut = true; }
@@ -1072,9 +1075,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
                 for (int j = 0; j < 6; j++) bestScores[j] = uni(bestScores[j]);
                 ssl.n = uni(ssl.n); ssl.overflow = uni(ssl.overflow); cycle = uni(cycle); quit = uni(quit);
                 if (!prescan || rl(precount, cycle) >= hitsCutoff || rl(prescore, cycle) >= qscoreCutoff) {
-                    const int nh = makeListsW(u, S, L, block, baseChrom, keyHits(block, strand), strand ? offM : off, strand ? kscM : ksc, n, p.minApproxHitsToKeep);
+                    const int nh = makeListsW<LONG>(u, S, L, block, baseChrom, keyHits(block, strand), strand ? offM : off, strand ? kscM : ksc, n, p.minApproxHitsToKeep);
                     if (nh >= p.minApproxHitsToKeep)
-                        slowWalk3W(u, S, L, strand, n, mqs, chrom, ssl, bestScores, allBasesCovered, maxScore, fullyDefined);
+                        slowWalk3W<LONG>(u, S, L, strand, n, mqs, chrom, ssl, bestScores, allBasesCovered, maxScore, fullyDefined);
                 }
                 if (p.quitAfterTwoPerfects && bestScores[5] >= 2) quit = true;
             }
@@ -1105,9 +1108,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wa
 
 }  // namespace bbidxw
 
-int bbidx_launch_wave(const bbidx::Params &P, hipStream_t stream) {
+int bbidx_launch_wave(const bbidx::Params &P, hipStream_t stream, bool longLists) {
     const long long blocks = (P.nreads + bbidxw::WAVES_PER_BLOCK - 1) / bbidxw::WAVES_PER_BLOCK;
-    hipLaunchKernelGGL(bbidxw::probe_wave_kernel, dim3((unsigned)blocks), dim3(64 * bbidxw::WAVES_PER_BLOCK), 0, stream, P);
+    if (longLists) hipLaunchKernelGGL(bbidxw::probe_wave_kernel<true>, dim3((unsigned)blocks), dim3(64 * bbidxw::WAVES_PER_BLOCK), 0, stream, P);
+    else hipLaunchKernelGGL(bbidxw::probe_wave_kernel<false>, dim3((unsigned)blocks), dim3(64 * bbidxw::WAVES_PER_BLOCK), 0, stream, P);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         static thread_local char msg[256];

@@ -84,7 +84,7 @@ __device__ int score_no_indels_wave(const uint8_t *read, int len, const uint8_t 
             const int t = pm ? popc(Sm & lt & gt_mask(hibit(pm))) + 1 : popc(Sm & lt) + 1 + carrySub;
             contrib = t > 5 ? -25 : (t > 1 ? -51 : -127);      // POINTS_SUB_ARRAY[t]
         }
-        score += wsum(contrib);
+        score += contrib;                                      // per lane; one reduction after the last step
         if (ev) {
             const int le = hibit(ev);
             if ((Mm >> le) & 1) { carryMatch = true; carrySub = 0; }
@@ -95,7 +95,7 @@ __device__ int score_no_indels_wave(const uint8_t *read, int len, const uint8_t 
             }
         }
     }
-    return score;
+    return wsum(score);
 }
 
 // SiteScore.setPerfect (current/stream/SiteScore.java:239-292) by one wavefront, order-independent form (see

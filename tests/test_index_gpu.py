@@ -1,4 +1,6 @@
 """GPU parity tests: the HIP index probe (through the C ABI) vs the CPU oracle, SiteScore by SiteScore."""
+import os
+
 import pytest
 
 from bbmap_amd.index import HostIndex, DeviceIndex
@@ -23,11 +25,18 @@ def run_case(genomes, k, chromBits, reads, tweak=None, cap=48):
             exp.append(oi.find(bp, bm, bs, ks, offs, cap=cap))
         except RuntimeError:                       # more than `cap` sites: the kernels must report the overflow too
             exp.append(None)
-    for kind in ("auto", "lane"):
+    # the wavefront kernel exists in two variants (with / without batched pops and bulk skips, picked by average list
+    # length); BBIDX_LONG_LISTS forces one, so every case runs through both of them and through the per-lane kernel
+    for kind, variant in (("auto", "1"), ("auto", "0"), ("lane", "")):
         di.set_kernel(kind)
-        got = di.find_batch([(bp, bs, ks, offs) for bp, bm, bs, ks, offs, t in reads], max_sites=cap)
+        os.environ["BBIDX_LONG_LISTS"] = variant
+        try:
+            got = di.find_batch([(bp, bs, ks, offs) for bp, bm, bs, ks, offs, t in reads], max_sites=cap)
+        finally:
+            os.environ.pop("BBIDX_LONG_LISTS", None)
         for i, (bp, bm, bs, ks, offs, truth) in enumerate(reads):
-            assert got[i] == exp[i], "%s kernel, read %d (truth %s): %s != %s" % (kind, i, truth, got[i], exp[i])
+            assert got[i] == exp[i], "%s kernel (long-list variant %r), read %d (truth %s): %s != %s" % (
+                kind, variant, i, truth, got[i], exp[i])
     di.close()
     return sum(bool(e) for e in exp)
 
