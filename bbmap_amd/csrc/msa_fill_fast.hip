@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
 #pragma unroll
             for (int k = 0; k < R; k++) {
                 const int row = r0 + k;
-                bool act = inRange && (started || notLimited);              // rows beyond the read prune through vlimP
+                bool act = inRange & (started | notLimited);              // rows beyond the read prune through vlimP
                 if (BANDED) act = act && (!banded || (c >= row - halfband && c <= upMaxG + 1));
                 const int cl1 = call1[k];
                 const bool match = (cl1 == ref1) && !refN;
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const int sdm = dgM & kScoreMask;
                 const int mDI = max(dgD, dgI) & kScoreMask;
                 const int t3 = max(floorP, limitP - (match ? P_MATCH2 : P_SUB3));
-                const bool pruneM = !act || gap || (max(dgM, max(dgD, dgI)) < t3);
+                const bool pruneM = !act | gap | (max(dgM, max(dgD, dgI)) < t3);      // (bitwise: no short-circuit branches)
                 int subx = subExt[min(streakM, 5)];
                 asm volatile("" : "+v"(subx), "+v"(pen0));
                 int addA = prevMatch ? (streakM <= 1 ? P_SUBR : P_SUB) : subx;
@@ -352,13 +352,13 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const int scoreM = max(sa, sbc);
                 const int timeM = (aWinsM && (match == prevMatch)) ? streakM + 1 : 1;
                 const int penM = pen0;
-                const bool goodM = !pruneM && (scoreM + penM >= limit);
+                const bool goodM = !pruneM & (scoreM + penM >= limit);
                 const int nM = goodM ? (scoreM | timeM) : pruneVal;
 
                 // ---- deletion plane (same row, previous column)
                 const int streakD = pD[k] & kTimeMask;
                 const int slm = pM[k] & kScoreMask, sld = pD[k] & kScoreMask;
-                const bool pruneD = !act || (max(pM[k], pD[k]) < max(limitP, delForce[k]));
+                const bool pruneD = !act | (max(pM[k], pD[k]) < max(limitP, delForce[k]));
                 int dext = delExt[min(streakD, 80 | (streakD & 3))];
                 asm volatile("" : "+v"(dext));
                 const int dsa = slm + P_DEL;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const int sum = upM & kScoreMask, sui = upI & kScoreMask;
                 const int insForce = (k == 0) ? ((rowOne && cGt1) ? INT_MAX : min(insHiForce[k], cLtLastForce))
                                               : min(insHiForce[k], cLtLastForce);
-                const bool pruneI = !act || gap || (max(upM, upI) < max(limitP, insForce));
+                const bool pruneI = !act | gap | (max(upM, upI) < max(limitP, insForce));
                 int iext = insExt[min(streakI, 20)];
                 asm volatile("" : "+v"(iext));
                 const int isa = sum + P_INS;
@@ -385,10 +385,10 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 int x2 = X[timeX + need] - X[timeX];                     // 0 when nothing is still needed
                 asm volatile("" : "+v"(x2));
                 const int penD = needIns ? pen0 : x2;
-                const bool goodD = !pruneD && (scoreD + penD >= limit);
+                const bool goodD = !pruneD & (scoreD + penD >= limit);
                 const int nD = goodD ? (scoreD | (timeD > kMaxTime ? kMaxTime - 3 : timeD)) : pruneVal;
                 const int penI = needDel ? pen0 : x2;
-                const bool goodI = !pruneI && (scoreI + penI >= limit);
+                const bool goodI = !pruneI & (scoreI + penI >= limit);
                 const int nI = goodI ? (scoreI | timeI) : pruneVal;
 
                 // ---- traceback record (MultiStateAligner11tsJNI.java:389-443): what traceback2 would decide here
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 dacc[k] |= nib << sh;
 
                 // ---- bookkeeping
-                const bool good = goodM || goodD || goodI;
+                const bool good = goodM | goodD | goodI;
                 if (BANDED) {
                     if (good && banded && minGood[k] >= 0 && c - maxGood[k] >= 3 && row < rows) bandViolation = 1;
                 }
