@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
             int dgM = svM, dgD = svD, dgI = svI;
             svM = upM; svD = upD; svI = upI;
             bool started = upMin >= 0;
-            bool prevMatch = (call0First == ref0) && (ref0 != 'N');
+            bool prevMatch = (call0First == ref0) & (ref0 != 'N');
 
 #pragma unroll
             for (int k = 0; k < R; k++) {
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 bool act = inRange & (started | notLimited);              // rows beyond the read prune through vlimP
                 if (BANDED) act = act && (!banded || (c >= row - halfband && c <= upMaxG + 1));
                 const int cl1 = call1[k];
-                const bool match = (cl1 == ref1) && !refN;
+                const bool match = (cl1 == ref1) & !refN;
                 const int limitP = max(vlimP[k], hlP);
                 const int limit = limitP - 2048;
                 const int delNeeded = max(0, row - c - 1);
@@ -344,13 +344,13 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 int subx = subExt[min(streakM, 5)];
                 asm volatile("" : "+v"(subx), "+v"(pen0));
                 int addA = prevMatch ? (streakM <= 1 ? P_SUBR : P_SUB) : subx;
-                addA = (refN || cl1 == 'N') ? 0 : addA;
+                addA = (refN | (cl1 == 'N')) ? 0 : addA;
                 addA = match ? (prevMatch ? P_MATCH2 : P_MATCH) : addA;
                 const int sa = sdm + addA;
                 const int sbc = mDI + (match ? P_MATCH : P_SUB);
                 const bool aWinsM = sa >= sbc;
                 const int scoreM = max(sa, sbc);
-                const int timeM = (aWinsM && (match == prevMatch)) ? streakM + 1 : 1;
+                const int timeM = (aWinsM & (match == prevMatch)) ? streakM + 1 : 1;
                 const int penM = pen0;
                 const bool goodM = !pruneM & (scoreM + penM >= limit);
                 const int nM = goodM ? (scoreM | timeM) : pruneVal;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const int nI = goodI ? (scoreI | timeI) : pruneVal;
 
                 // ---- traceback record (MultiStateAligner11tsJNI.java:389-443): what traceback2 would decide here
-                const bool msStay = (timeM > 1) || (sdm >= mDI);
+                const bool msStay = (timeM > 1) | (sdm >= mDI);
                 const unsigned nibM = msStay ? 0u : (((dgD | kTimeMask) >= dgI) ? 1u : 2u);
                 const unsigned nib = nibM | (aWinsD ? 0u : 4u) | (aWinsI ? 0u : 8u);
                 dacc[k] |= nib << sh;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 if (BANDED) {
                     if (good && banded && minGood[k] >= 0 && c - maxGood[k] >= 3 && row < rows) bandViolation = 1;
                 }
-                minGood[k] = (good && minGood[k] < 0) ? c : minGood[k];
+                minGood[k] = (good & (minGood[k] < 0)) ? c : minGood[k];
                 maxGood[k] = good ? c : maxGood[k];
                 // next row of this lane: diag = my previous-column cell, up = my new cell
                 dgM = pM[k]; dgD = pD[k]; dgI = pI[k];
@@ -423,10 +423,10 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 for (int k = 1; k < R; k++) {
                     lm = (lastSlot == k) ? pM[k] : lm; ld = (lastSlot == k) ? pD[k] : ld; li = (lastSlot == k) ? pI[k] : li;
                 }
-                const bool track = ownerLaneFlag && inRange;
-                const bool um = track && (bestMc < 0 || (lm & kScoreMask) > (bestM & kScoreMask));
-                const bool ud = track && (bestDc < 0 || (ld & kScoreMask) > (bestD & kScoreMask));
-                const bool ui = track && (bestIc < 0 || (li & kScoreMask) > (bestI & kScoreMask));
+                const bool track = ownerLaneFlag & inRange;
+                const bool um = track & ((bestMc < 0) | ((lm & kScoreMask) > (bestM & kScoreMask)));
+                const bool ud = track & ((bestDc < 0) | ((ld & kScoreMask) > (bestD & kScoreMask)));
+                const bool ui = track & ((bestIc < 0) | ((li & kScoreMask) > (bestI & kScoreMask)));
                 bestM = um ? lm : bestM; bestMc = um ? c : bestMc;
                 bestD = ud ? ld : bestD; bestDc = ud ? c : bestDc;
                 bestI = ui ? li : bestI; bestIc = ui ? c : bestIc;
