@@ -59,8 +59,8 @@ __device__ inline CellOut cell_eval(int row, int col, int rows, int columns, int
                                     int dM, int dD, int dI, int lM, int lD, int uM, int uI) {
     CellOut o;
     const bool gap = ref1 == '-';
-    const bool match = (call1 == ref1) && ref1 != 'N';
-    const bool prevMatch = (call0 == ref0) && ref0 != 'N';
+    const bool match = (call1 == ref1) & (ref1 != 'N');                  // (bitwise throughout: no short-circuit branches)
+    const bool prevMatch = (call0 == ref0) & (ref0 != 'N');
     const int limit = max(vlimit, hlimit);
     const int limit3 = max(floorv, match ? limit - P_MATCH2 : limit - P_SUB3);
     const int delNeeded = max(0, row - col - 1);
@@ -73,20 +73,20 @@ __device__ inline CellOut cell_eval(int row, int col, int rows, int columns, int
     const int um = uM & kScoreMask, ui = uI & kScoreMask;
 
     int timeM = 0;
-    if (gap || (dm <= limit3 && dd <= limit3 && di <= limit3)) {
+    if (gap | ((dm <= limit3) & (dd <= limit3) & (di <= limit3))) {
         o.M = subfloor;
     } else {
         const int streak = dM & kTimeMask;
         int a, bonus, tA;
         if (match) { a = dm + (prevMatch ? P_MATCH2 : P_MATCH); bonus = P_MATCH; tA = prevMatch ? streak + 1 : 1; }
         else {
-            if (ref1 != 'N' && call1 != 'N') a = dm + (prevMatch ? (streak <= 1 ? P_SUBR : P_SUB) : sub_step_n(streak));
+            if ((ref1 != 'N') & (call1 != 'N')) a = dm + (prevMatch ? (streak <= 1 ? P_SUBR : P_SUB) : sub_step_n(streak));
             else a = dm;
             bonus = P_SUB; tA = prevMatch ? 1 : streak + 1;
         }
         const int bb = dd + bonus, cc = di + bonus;
         int score, time;
-        if (a >= bb && a >= cc) { score = a; time = tA; }
+        if ((a >= bb) & (a >= cc)) { score = a; time = tA; }
         else if (bb >= cc) { score = bb; time = 1; }
         else { score = cc; time = 1; }
         const int limit2 = delNeeded > 0 ? limit - delPen : (insNeeded > 0 ? limit - insPen : limit);
@@ -95,7 +95,7 @@ __device__ inline CellOut cell_eval(int row, int col, int rows, int columns, int
         o.M = score | ctime_n(time);
     }
     bool aWinsD = true;
-    if ((lm <= limit && ld <= limit) || row < 3 || row > rows - 3) {
+    if (((lm <= limit) & (ld <= limit)) | (row < 3) | (row > rows - 3)) {
         o.D = subfloor;
     } else {
         const int streak = lD & kTimeMask;
@@ -111,7 +111,7 @@ __device__ inline CellOut cell_eval(int row, int col, int rows, int columns, int
         o.D = score | ctime_n(time);
     }
     bool aWinsI = true;
-    if (gap || (um <= limit && ui <= limit) || (row < 2 && col > 1) || (row > rows - 2 && col < columns - 1)) {
+    if (gap | ((um <= limit) & (ui <= limit)) | ((row < 2) & (col > 1)) | ((row > rows - 2) & (col < columns - 1))) {
         o.I = subfloor;
     } else {
         const int streak = uI & kTimeMask;
@@ -125,7 +125,7 @@ __device__ inline CellOut cell_eval(int row, int col, int rows, int columns, int
         o.I = score | ctime_n(time);
     }
     // what traceback2 would decide at this cell (MultiStateAligner11tsJNI.java:389-443); see msa_fill_fast.hip
-    const bool msStay = (timeM > 1) || (dm >= max(dd, di));
+    const bool msStay = (timeM > 1) | (dm >= max(dd, di));
     const unsigned nibM = msStay ? 0u : ((dd >= di) ? 1u : 2u);
     o.nib = nibM | (aWinsD ? 0u : 4u) | (aWinsI ? 0u : 8u);
     o.good = anyGood;
