@@ -103,3 +103,38 @@ def test_pacbio_long_read():
     rd = bytes(rd)
     check([(rd, g, 680, 3760, int((90 + 100 * (len(rd) - 1)) * 0.5))], M.FILL_AND_SCORE_LIMITED | M.DO_TRACEBACK,
           maxRows=3100, maxColumns=3300)
+
+
+def test_pacbio_gapped_reference_jobs():
+    """fillAndScoreLimited(..., gaps) with the PacBio scheme: makeGref on the device, fill on the gapped reference in the
+    one-job-per-thread kernel, coordinates translated back (MultiStateAligner9PacBio.java:110-124, 1403-1470)."""
+    rng = random.Random(41)
+    ref = rand_seq(rng, 7000)
+    probs = []
+    for i in range(14):
+        L = rng.choice([300, 450, 600])
+        st = rng.randrange(200, 2500)
+        cut = rng.randrange(80, L - 80)
+        dl = rng.choice([300, 500, 900, 1500])
+        rd = bytearray(ref[st:st + cut] + ref[st + cut + dl: st + dl + L])
+        for pos in range(20 + i, len(rd) - 5, 53):            # PacBio-like: a deletion every ~50 bases
+            del rd[pos]
+        stop = st + dl + L - 1
+        gaps = [st, st + cut - 1 + rng.randint(0, 3), st + cut + dl - rng.randint(0, 3), stop]
+        ms = int(rng.choice([0.3, 0.45]) * (90 + 100 * (len(rd) - 1)))
+        probs.append((bytes(rd), ref, st - 8, stop + 8, ms, gaps))
+    probs.append((probs[0][0], ref, probs[0][2], probs[0][3], probs[0][4], None))
+    al = M.MultiStateAligner9PacBio(maxRows=640, maxColumns=2400)
+    got = al.alignGapped(probs)
+    om = OracleMSA(640, 2400, scheme="9pacbio")
+    nonnull = 0
+    for p, g in zip(probs, got):
+        sv, mx = om.fillAndScoreLimited(p[0], p[1], p[2], p[3], p[4], p[5])
+        assert g["status"] != M.ST_BAD_SHAPE
+        assert g["score"] == sv, (p[2:], g, sv)
+        if sv is not None:
+            nonnull += 1
+            tb = om.traceback(p[0], p[1], max(0, p[2]), min(len(p[1]) - 1, p[3]), mx[0], mx[1], mx[2], gapped=p[5] is not None)
+            assert g["match"] == tb
+    al.ctx.close()
+    assert nonnull > 6
