@@ -16,7 +16,7 @@ EXPORTS = [
     "bbmsa_fill_packed", "bbmsa_last_kernel_ms", "bbmsa_last_kernel_ms3", "bbmsa_last_counts", "bbmsa_align_gapped_batch_device", "bbmsa_align_gapped_batch", "bbmsa_align_batch_device_indirect",
     "bbmsa_align_gapped_batch_device_indirect",
     "bbband_create", "bbband_destroy", "bbband_align_batch_device", "bbband_align_batch",
-    "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch", "bbidx_find_batch_device_rc", "bbidx_last_stats", "bbidx_set_kernel", "bbidx_build", "bbidx_get_params", "bbidx_export_block",
+    "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch", "bbidx_find_batch_device_rc", "bbidx_last_stats", "bbidx_set_kernel", "bbidx_set_max_read_len", "bbidx_build", "bbidx_get_params", "bbidx_export_block",
     "bbpipe_revcomp_device", "bbpipe_select_jobs_device", "bbpipe_quick_rescue_device", "bbpipe_match_no_indels_device",
 ]
 

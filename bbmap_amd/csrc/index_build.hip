@@ -202,7 +202,7 @@ extern "C" int bbidx_build(int32_t device, int32_t k, int32_t chromBits, int32_t
         c = new (std::nothrow) bbidx_ctx();
         if (!c) { bbmap_set_error("bbidx_build: out of memory"); return BBMAP_E_NOMEM; }
         c->device = device; c->kernelKind = BBIDX_KERNEL_AUTO; c->blocks = prop.multiProcessorCount * 8;
-        c->totalSites = 0;
+        c->totalSites = 0; c->maxReadLen = BBIDX_MAX_READ_LEN;
         memset(&c->dev, 0, sizeof c->dev);
         const int nblocks = (nchroms >> chromBits) + 1;
         const int cpb = 1 << chromBits, shift = 31 - chromBits, lowMask = cpb - 1;

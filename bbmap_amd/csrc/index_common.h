@@ -119,4 +119,4 @@ __device__ inline int subArr(int t) { return t > 5 ? -25 : (t > 1 ? -51 : -127);
 }  // namespace bbidx
 
 // launcher of the wave kernel (index_probe_wave.hip)
-int bbidx_launch_wave(const bbidx::Params &P, hipStream_t stream, bool longLists);
+int bbidx_launch_wave(const bbidx::Params &P, hipStream_t stream, bool longLists, int maxReadLen);

@@ -18,6 +18,7 @@ struct bbidx_ctx {
     bool timed;
     int kernelKind;       // BBIDX_KERNEL_*
     long long totalSites; // list entries over all blocks (picks the wave kernel's long-list variant)
+    int maxReadLen;       // bbidx_set_max_read_len: picks the wave kernel's LDS sizing (default BBIDX_MAX_READ_LEN)
 };
 
 

@@ -767,7 +767,7 @@ extern "C" int bbidx_create(int32_t device, const bbidx_index_desc *d, bbidx_ctx
     c->device = device;
     c->kernelKind = BBIDX_KERNEL_AUTO;
     c->blocks = prop.multiProcessorCount * 8;
-    c->totalSites = 0;
+    c->totalSites = 0; c->maxReadLen = BBIDX_MAX_READ_LEN;
     for (int b = 0; b < d->nblocks; b++) c->totalSites += (long long)d->numSites[b];
     const size_t keyspace = (size_t)1 << (2 * p.k);
     int rc = BBMAP_OK;
@@ -834,7 +834,7 @@ extern "C" int bbidx_find_batch_device_rc(bbidx_ctx *c, void *stream_, int64_t n
         // below that (small genomes) the plain variant, which is a few per cent faster there
         bool longLists = c->totalSites * 2 >= (1LL << (2 * c->dev.p.k)) * (long long)c->dev.nblocks;
         if (const char *ev = getenv("BBIDX_LONG_LISTS")) { if (*ev) longLists = atoi(ev) != 0; }      // tests force either variant
-        const int rc = bbidx_launch_wave(P, stream, longLists);
+        const int rc = bbidx_launch_wave(P, stream, longLists, c->maxReadLen);
         if (rc != BBMAP_OK) return rc;
         P.onlyPending = 1;
     }
@@ -906,6 +906,12 @@ extern "C" int bbidx_last_stats(bbidx_ctx *c, int64_t *stats5, float *kernel_ms)
         for (int j = 0; j < 5; j++) stats5[j] = 0;
         for (int s = 0; s < bbidx::STAT_SHARDS; s++) for (int j = 0; j < 5; j++) stats5[j] += (int64_t)h[(size_t)s * 8 + j];
     }
+    return BBMAP_OK;
+}
+
+extern "C" int bbidx_set_max_read_len(bbidx_ctx *c, int32_t max_len) {
+    if (!c || max_len < 1) return ifail(BBMAP_E_ARG, "bbidx_set_max_read_len: bad argument");
+    c->maxReadLen = max_len;
     return BBMAP_OK;
 }
 

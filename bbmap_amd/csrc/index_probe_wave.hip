@@ -37,17 +37,19 @@ using namespace wavep;
 #endif
 
 constexpr int WAVES_PER_BLOCK = 4;
-constexpr int WMAXLEN = 400;      // longest read this kernel takes (longer ones go to the per-lane kernel): keeps a wave's
-                                  // LDS share under 160 KiB / 32 so that LDS never limits occupancy
+constexpr int WMAXLEN = 400;      // longest read the wave kernel takes (longer ones go to the per-lane kernel)
+constexpr int WSHORTLEN = 160;    // its second instantiation: batches whose reads are at most this long (bbidx_set_max_read_len)
+                                  // need 4.2 KB of LDS per wave instead of 6.1 KB and run 8 waves per SIMD instead of 6
 
+template <int WLEN>
 struct WaveLds {
-    int loc[WMAXLEN];             // the per-base location array of extendScore
+    int loc[WLEN];                // the per-base location array of extendScore
     int xch[3][64];               // lane <-> lane exchange (compaction), greedy-trim tables
     int gaps[BBIDX_MAX_GAPS];
     int ngaps;
-    uint8_t base[2][WMAXLEN + 8]; // [0] the read as given, [1] its reverse complement
-    int8_t bsc[WMAXLEN + 8];      // base scores of the plus strand
-    int8_t code[WMAXLEN + 8];     // AminoAcid.baseToNumber of the plus strand (-1 = undefined)
+    uint8_t base[2][WLEN + 8];    // [0] the read as given, [1] its reverse complement
+    int8_t bsc[WLEN + 8];         // base scores of the plus strand
+    int8_t code[WLEN + 8];        // AminoAcid.baseToNumber of the plus strand (-1 = undefined)
     int hits[8][64];              // block 0's list heads per key lane, plus then minus strand {cnt, start, len, first}:
                                   // long-lived, rarely read -> parked here instead of 8 VGPRs (which the compiler spilled)
 };
@@ -356,7 +358,7 @@ template <bool LONG> __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom,
 //   lastLoc    = the last positive element before p         -> highest set bit of the "positive" ballot below p
 //   timeInMode = length of the run of -1 ending at p        -> distance to the highest "not -1" bit below p
 //   contig     = equal-to-previous streak                   -> popcount of "equal" events since the last reset event
-__device__ int calcAffineScoreW(const U &u, const WaveLds &S, int strand, int minContig) {
+template <int WLEN> __device__ int calcAffineScoreW(const U &u, const WaveLds<WLEN> &S, int strand, int minContig) {
     const int blen = u.blen, lane = u.lane;
     int score = 0, carryLastLoc = -3, carryRun = 0, carryContig = 0, maxContig = 0;
     for (int base = 0; base < blen; base += 64) {
@@ -406,7 +408,7 @@ __device__ int calcAffineScoreW(const U &u, const WaveLds &S, int strand, int mi
 }
 
 // BBIndex.extendScore :2558-2833
-__device__ int extendScoreW(U &u, WaveLds &S, int strand, int value, int offs, int numHits, int chrom, int centerIndex) {
+template <int WLEN> __device__ int extendScoreW(U &u, WaveLds<WLEN> &S, int strand, int value, int offs, int numHits, int chrom, int centerIndex) {
     const bbidx_params &p = u.ix->p;
     const int blen = u.blen, lane = u.lane, k = u.k;
     const int centerVal = rl(value, centerIndex), centerLoc = u.c.siteOf(centerVal);
@@ -486,7 +488,7 @@ __device__ int extendScoreW(U &u, WaveLds &S, int strand, int value, int offs, i
 }
 
 // BBIndex.makeGapArray :2837-2878 -- rare (a site spanning more than MINGAP + read length); one lane walks LDS
-__device__ int makeGapArrayW(const U &u, WaveLds &S, int minLoc, int minGap) {
+template <int WLEN> __device__ int makeGapArrayW(const U &u, WaveLds<WLEN> &S, int minLoc, int minGap) {
     if (u.lane == 0) {
         int *locArray = S.loc;
         const int n = u.blen;
@@ -516,7 +518,7 @@ __device__ int makeGapArrayW(const U &u, WaveLds &S, int minLoc, int minGap) {
 }
 
 // SiteScore.setPerfect (current/stream/SiteScore.java:239-292): order-independent form
-__device__ void setPerfectW(const U &u, const WaveLds &S, int chrom, int strand, int start, int stop, int &perfectOut, int &semiOut) {
+template <int WLEN> __device__ void setPerfectW(const U &u, const WaveLds<WLEN> &S, int chrom, int strand, int start, int stop, int &perfectOut, int &semiOut) {
     const int blen = u.blen;
     perfectOut = 0; semiOut = 0;
     if (blen != stop - start + 1) return;
@@ -556,7 +558,7 @@ struct SiteOut { bbidx_site *v; int n, cap; bool overflow; };
 struct PrevSite { int idx, chrom, strand, start, stop, score, perfect, semiperfect, ngaps; };
 
 // BBIndex.slowWalk3 :1219-1706
-template <bool LONG> __device__ void slowWalk3W(U &u, WaveLds &S, WL &L, int strand, int numKeys, int mqs, int baseChrom_,
+template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S, WL &L, int strand, int numKeys, int mqs, int baseChrom_,
                            SiteOut &ssl, int *bestScores, bool allBasesCovered, int maxScore, bool fullyDefined) {
     const bbidx_params &p = u.ix->p;
     const int blen = u.blen, lane = u.lane;
@@ -769,7 +771,7 @@ __device__ long long valueOfElement(const int *offsets, int noffsets, const int 
 // BBIndex.trimExcessHitListsByGreedy :266-350 (+ Solver.findWorstGreedy :46-95): lane j evaluates list position j,
 // the "first strict prefix minimum below the early-termination score" rule comes from an exclusive prefix-min scan.
 // x = lengths[lane] (COUNTS of the lane's key), key = keys[lane]; both are updated in place.
-__device__ int trimByGreedyW(const U &u, WaveLds &S, int off, int ksc, int n, int maxHitLists, int &key, int &x) {
+template <int WLEN> __device__ int trimByGreedyW(const U &u, WaveLds<WLEN> &S, int off, int ksc, int n, int maxHitLists, int &key, int &x) {
     const DevIndex &ix = *u.ix;
     const bbidx_params &p = ix.p;
     const int lane = u.lane;
@@ -820,7 +822,7 @@ __device__ int trimByGreedyW(const U &u, WaveLds &S, int off, int ksc, int n, in
 
 // Compaction: lanes with keep==true move to lanes 0..count-1.  One LDS round trip publishes, for every destination
 // lane, the lane it takes its values from; the values themselves then move with ds_bpermute (no LDS storage).
-__device__ inline int compactSrc(WaveLds &S, int lane, bool keep, int &count) {
+template <int WLEN> __device__ inline int compactSrc(WaveLds<WLEN> &S, int lane, bool keep, int &count) {
     const u64 M = __ballot(keep);
     wsync();
     if (keep) S.xch[0][popc(M & lt_mask(lane))] = lane;
@@ -844,7 +846,7 @@ __device__ inline KeyHit minusView(int lane, int n, int cntRC, int startR, int l
 }
 
 // BBIndex.getHits (:354-391) + the heap fill at the top of slowWalk3/findMaxQscore2: builds the compacted lists
-template <bool LONG> __device__ int makeListsW(const U &u, WaveLds &S, WL &L, int block, int baseChrom, const KeyHit &h, int off, int ksc, int n, int minHits) {
+template <bool LONG, int WLEN> __device__ int makeListsW(const U &u, WaveLds<WLEN> &S, WL &L, int block, int baseChrom, const KeyHit &h, int off, int ksc, int n, int minHits) {
     const bool hit = u.lane < n && h.cnt > 0 && h.len > 0 && h.first != -1;
     const u64 M = __ballot(hit);
     const int nh = popc(M);
@@ -872,8 +874,11 @@ template <bool LONG> __device__ int makeListsW(const U &u, WaveLds &S, WL &L, in
 #ifndef BBIDX_WAVE_OCC
 #define BBIDX_WAVE_OCC 6
 #endif
-template <bool LONG> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WAVE_OCC) void probe_wave_kernel(const Params P) {
-    __shared__ WaveLds lds[WAVES_PER_BLOCK];
+#ifndef BBIDX_LONG_SHORT_OCC
+#define BBIDX_LONG_SHORT_OCC 8      // long-list variant with short reads (measured 8 > 7 > 6 on the hg38-sized reference)
+#endif
+template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WLEN <= WSHORTLEN ? (LONG ? BBIDX_LONG_SHORT_OCC : 8) : BBIDX_WAVE_OCC) void probe_wave_kernel(const Params P) {
+    __shared__ WaveLds<WLEN> lds[WAVES_PER_BLOCK];
     __shared__ unsigned blockStats[5];
     __shared__ uint8_t compLut[256];      // AminoAcid.baseToComplementExtended
     __shared__ int8_t numLut[256];        // AminoAcid.baseToNumber
@@ -882,7 +887,7 @@ template <bool LONG> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WA
     compLut[threadIdx.x] = (uint8_t)complement_extended((int)threadIdx.x);
     numLut[threadIdx.x] = (int8_t)(threadIdx.x < 128 ? base_num((int)threadIdx.x) : -1);
     __syncthreads();
-    WaveLds &S = lds[wave];
+    WaveLds<WLEN> &S = lds[wave];
     const DevIndex &ix = P.ix;
     const bbidx_params &p = ix.p;
     const long long r = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -912,7 +917,7 @@ template <bool LONG> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WA
     if (!done) {
         if (n < 1 || blen < p.k) { result = 0; done = true; }
         else if (n > KB || blen > MAXLEN) { result = -2; done = true; }
-        else if (n > 64 || blen > WMAXLEN) { result = NSITES_PENDING; done = true; }
+        else if (n > 64 || blen > WLEN) { result = NSITES_PENDING; done = true; }
     }
     // one uniform do { } while (0) body per read: `break` = finished with `result`
     if (!done) do {
@@ -1108,10 +1113,18 @@ template <bool LONG> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BBIDX_WA
 
 }  // namespace bbidxw
 
-int bbidx_launch_wave(const bbidx::Params &P, hipStream_t stream, bool longLists) {
-    const long long blocks = (P.nreads + bbidxw::WAVES_PER_BLOCK - 1) / bbidxw::WAVES_PER_BLOCK;
-    if (longLists) hipLaunchKernelGGL(bbidxw::probe_wave_kernel<true>, dim3((unsigned)blocks), dim3(64 * bbidxw::WAVES_PER_BLOCK), 0, stream, P);
-    else hipLaunchKernelGGL(bbidxw::probe_wave_kernel<false>, dim3((unsigned)blocks), dim3(64 * bbidxw::WAVES_PER_BLOCK), 0, stream, P);
+int bbidx_launch_wave(const bbidx::Params &P, hipStream_t stream, bool longLists, int maxReadLen) {
+    using namespace bbidxw;
+    const long long blocks = (P.nreads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    const dim3 g((unsigned)blocks), b(64 * WAVES_PER_BLOCK);
+    const bool shortReads = maxReadLen <= WSHORTLEN;
+    if (longLists) {
+        if (shortReads) hipLaunchKernelGGL((probe_wave_kernel<true, WSHORTLEN>), g, b, 0, stream, P);
+        else hipLaunchKernelGGL((probe_wave_kernel<true, WMAXLEN>), g, b, 0, stream, P);
+    } else {
+        if (shortReads) hipLaunchKernelGGL((probe_wave_kernel<false, WSHORTLEN>), g, b, 0, stream, P);
+        else hipLaunchKernelGGL((probe_wave_kernel<false, WMAXLEN>), g, b, 0, stream, P);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         static thread_local char msg[256];

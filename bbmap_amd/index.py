@@ -384,6 +384,12 @@ class DeviceIndex:
         """kind: "auto" (one read per wavefront, per-lane kernel for the reads that do not fit) or "lane"."""
         _lib.check(self.L.bbidx_set_kernel(self.h, {"auto": 0, "lane": 1}[kind]), "bbidx_set_kernel")
 
+    def set_max_read_len(self, max_len):
+        """Sizing hint for the wavefront kernel (reads of at most 160 bases: 8 waves per SIMD instead of 6)."""
+        self.L.bbidx_set_max_read_len.argtypes = [C.c_void_p, C.c_int32]
+        self.L.bbidx_set_max_read_len.restype = C.c_int
+        _lib.check(self.L.bbidx_set_max_read_len(self.h, int(max_len)), "bbidx_set_max_read_len")
+
     def close(self):
         if getattr(self, "h", None):
             self.L.bbidx_destroy(self.h)

@@ -27,6 +27,7 @@ class MapPipeline:
             self.di = DeviceIndex(host_index, device)
         self.hi = host_index
         self.n, self.read_len, self.max_sites, self.pad, self.min_ratio = n_reads, read_len, max_sites, pad, min_ratio
+        self.di.set_max_read_len(read_len)
         self.max_columns = max_columns
         self.no_iterations = no_iterations       # BBMSA_NO_ITERATIONS on every DP job (visited-cell counters not needed)
         max_rows = ((read_len + 31) // 32) * 32

@@ -324,6 +324,11 @@ int bbidx_export_block(bbidx_ctx *ctx, int32_t block, int32_t *starts, int32_t *
 enum { BBIDX_KERNEL_AUTO = 0, BBIDX_KERNEL_LANE = 1 };
 int bbidx_set_kernel(bbidx_ctx *ctx, int32_t kind);
 
+/* Longest read of the batches to come (default BBIDX_MAX_READ_LEN).  Sizing hint, not a limit: the wavefront kernel keeps a
+ * read's per-base arrays in LDS, and with reads of at most 160 bases it needs a third less of it and runs 8 waves per SIMD
+ * instead of 6; reads longer than announced are still answered (by the per-lane kernel). */
+int bbidx_set_max_read_len(bbidx_ctx *ctx, int32_t max_len);
+
 /* =====================================================================================
  * Pipeline glue (device-resident): which probe sites need a slow alignment.
  *   Mirrors the host logic between the two hot kernels: AbstractMapThread.scoreNoIndels

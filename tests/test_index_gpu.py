@@ -27,16 +27,19 @@ def run_case(genomes, k, chromBits, reads, tweak=None, cap=48):
             exp.append(None)
     # the wavefront kernel exists in two variants (with / without batched pops and bulk skips, picked by average list
     # length); BBIDX_LONG_LISTS forces one, so every case runs through both of them and through the per-lane kernel
-    for kind, variant in (("auto", "1"), ("auto", "0"), ("lane", "")):
+    # ... and with the LDS sizing for short reads (reads longer than the announced 160 bases must come back through the
+    # per-lane kernel, unchanged)
+    for kind, variant, maxlen in (("auto", "1", 600), ("auto", "0", 600), ("auto", "1", 160), ("auto", "0", 160), ("lane", "", 600)):
         di.set_kernel(kind)
+        di.set_max_read_len(maxlen)
         os.environ["BBIDX_LONG_LISTS"] = variant
         try:
             got = di.find_batch([(bp, bs, ks, offs) for bp, bm, bs, ks, offs, t in reads], max_sites=cap)
         finally:
             os.environ.pop("BBIDX_LONG_LISTS", None)
         for i, (bp, bm, bs, ks, offs, truth) in enumerate(reads):
-            assert got[i] == exp[i], "%s kernel (long-list variant %r), read %d (truth %s): %s != %s" % (
-                kind, variant, i, truth, got[i], exp[i])
+            assert got[i] == exp[i], "%s kernel (long-list variant %r, max read length %d), read %d (truth %s): %s != %s" % (
+                kind, variant, maxlen, i, truth, got[i], exp[i])
     di.close()
     return sum(bool(e) for e in exp)
 
