@@ -134,7 +134,10 @@ __device__ inline CellOut cell_eval(int row, int col, int rows, int columns, int
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void msa_fill_narrow_kernel(const NarrowParams p) {
+#ifndef BBMSA_NARROW_OCC
+#define BBMSA_NARROW_OCC 2
+#endif
+__global__ __launch_bounds__(64, BBMSA_NARROW_OCC) void msa_fill_narrow_kernel(const NarrowParams p) {
     const int lane = threadIdx.x;
     unsigned long long *dirw = p.dirbuf + (long long)blockIdx.x * (long long)(p.maxRows + 1) * 64;
     const bool ctxBanded = !(p.bandwidth < 1 && p.bandwidthRatio <= 0.0f);

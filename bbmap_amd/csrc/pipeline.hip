@@ -164,7 +164,10 @@ constexpr int SEL_WAVES = 4, SEL_READS_PER_WAVE = 16, SEL_CAP = 128;
 
 // One wavefront takes SEL_READS_PER_WAVE consecutive reads; the DP jobs it selects are parked in LDS as
 // (read * maxSites + site, minScore) and written out behind ONE reservation on the global job counter per flush.
-__global__ __launch_bounds__(64 * SEL_WAVES) void select_jobs_kernel(const SelectParams P) {
+#ifndef BBPIPE_SEL_OCC
+#define BBPIPE_SEL_OCC 6
+#endif
+__global__ __launch_bounds__(64 * SEL_WAVES, BBPIPE_SEL_OCC) void select_jobs_kernel(const SelectParams P) {
     __shared__ int pendSrc[SEL_WAVES][SEL_CAP], pendMin[SEL_WAVES][SEL_CAP];
     __shared__ unsigned blockCnt[2], waveCnt[SEL_WAVES], blockBase;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
