@@ -30,6 +30,11 @@ namespace bbidxw {
 using namespace bbidx;
 using namespace wavep;
 
+#ifdef BBIDX_BATCH_STATS
+#define BST(u, i, v) ((u).ph[i] += (unsigned)(v))
+#else
+#define BST(u, i, v) do { } while (0)
+#endif
 #ifdef BBIDX_PHASE_TIMERS
 #define PH_MARK(u, i) do { const unsigned long long now_ = __builtin_readcyclecounter(); (u).ph[i] += (unsigned)(now_ - (u).phT); (u).phT = now_; } while (0)
 #else
@@ -61,7 +66,7 @@ struct U {
     int k, baseKeyHitScore, indelPenalty, indelPenaltyMult, maxPenalty, scoreZ1Key;
     int lane, blen;
     unsigned cPrescan, cWalk, cExtend, cRefBytes;
-#ifdef BBIDX_PHASE_TIMERS
+#if defined(BBIDX_PHASE_TIMERS) || defined(BBIDX_BATCH_STATS)
     unsigned ph[5]; unsigned long long phT;     // debug build: cycles per phase instead of the work counters
 #endif
 };
@@ -328,7 +333,8 @@ template <bool LONG> __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom,
     while (L.nlive > 0) {
         approxHitsCutoff = uni(approxHitsCutoff); topQscore = uni(topQscore); maxHits = uni(maxHits); L.nlive = uni(L.nlive);
         if (LONG && numHits >= 2 && L.bwait == 0) {
-            if (batchPop(u, L, min(p.maxIndel, indelCutoff), p.maxIndel2, approxHitsCutoff, true, topQscore, maxHits, mqs, baseChrom, u.cPrescan) > 0) continue;
+            { const int np_ = batchPop(u, L, min(p.maxIndel, indelCutoff), p.maxIndel2, approxHitsCutoff, true, topQscore, maxHits, mqs, baseChrom, u.cPrescan);
+              BST(u, 0, 1); BST(u, 1, np_ > 0); BST(u, 2, np_); if (np_ > 0) continue; }
             L.bwait = BATCH_RETRY;
         } else if (LONG && L.bwait > 0) L.bwait--;
         const int site = wmin(L.hv);
@@ -347,6 +353,7 @@ template <bool LONG> __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom,
         }
         else if (LONG && approxHitsCutoff >= 2 && L.bulk == 0) { bulkSkip(u, L, site, min(p.maxIndel, indelCutoff), approxHitsCutoff, baseChrom, u.cPrescan); continue; }
         if (LONG && L.bulk > 0) L.bulk--;
+        BST(u, 3, 1);
         popSite(u, L, site, approxHitsCutoff, perfectOnly, baseChrom, u.cPrescan);
     }
     outQ = topQscore; outHits = maxHits;
@@ -732,6 +739,7 @@ template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S
         if (uni(finished)) break;
         if (LONG && approxHits < approxHitsCutoff && approxHitsCutoff >= 2 && L.bulk == 0) { bulkSkip(u, L, site, p.maxIndel, approxHitsCutoff, baseChrom, u.cWalk); continue; }
         if (LONG && L.bulk > 0) L.bulk--;
+        BST(u, 4, 1);
         popSite(u, L, site, approxHitsCutoff, false, baseChrom, u.cWalk);
     }
     bestScores[0] = max(bestScores[0], currentTopScore);
@@ -901,7 +909,7 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
     u.scoreZ1Key = Z_MULT * p.k;
     u.lane = lane; u.blen = 0;
     u.cPrescan = u.cWalk = u.cExtend = u.cRefBytes = 0;
-#ifdef BBIDX_PHASE_TIMERS
+#if defined(BBIDX_PHASE_TIMERS) || defined(BBIDX_BATCH_STATS)
     for (int j = 0; j < 5; j++) u.ph[j] = 0;
     u.phT = __builtin_readcyclecounter();
 #endif
@@ -1098,7 +1106,9 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
     }
     if (P.stats) {
         if (lane == 0) {
-#ifdef BBIDX_PHASE_TIMERS
+#if defined(BBIDX_BATCH_STATS)
+            for (int j = 0; j < 5; j++) atomicAdd(&blockStats[j], u.ph[j]);
+#elif defined(BBIDX_PHASE_TIMERS)
             for (int j = 0; j < 5; j++) atomicAdd(&blockStats[j], u.ph[j] >> 4);
 #else
             atomicAdd(&blockStats[0], u.cPrescan); atomicAdd(&blockStats[1], u.cWalk); atomicAdd(&blockStats[2], u.cExtend);
