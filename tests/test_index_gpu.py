@@ -121,3 +121,15 @@ def test_device_build_matches_host_builder():
         for (bp, bm, bs, ks, offs, t), g in zip(reads, got):
             assert g == oi.find(bp, bm, bs, ks, offs, cap=48)
         di.close()
+
+
+def test_long_lists_small_k_two_blocks():
+    # the regime of a large genome in miniature: k=9 over 3 x 1.2 Mbp (262,144 keys, ~14 sites per key and block) in two
+    # blocks, so every read's 22+ lists hold hundreds of interleaved entries: batched pops, bulk skips and the exit rules
+    # of the heap walk all run for real, through every kernel variant
+    import random
+    rng = random.Random(77)
+    genomes = [b"N" * 400 + bytes(rng.choice(b"ACGT") for _ in range(1200000)) + b"N" * 400 for _ in range(3)]
+    reads = make_reads(21, genomes, 120, k=9)
+    tweak = {"maxUsableLength": 400, "maxUsableLength2": 800}      # keep the long lists (analyzeIndex would drop most of them)
+    assert run_case(genomes, 9, 1, reads, tweak=tweak, cap=64) > 40
