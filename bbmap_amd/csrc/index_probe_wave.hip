@@ -10,8 +10,14 @@
 //     location) is recovered from ballot masks with count-leading/trailing-zero arithmetic;
 //   * control flow is wave-uniform by construction (every decision is taken on a ballot/readlane value), so EXEC
 //     stays full and the cross-lane operations are always legal.
+//     Uniform state is also DECLARED uniform (wavep::uni = v_readfirstlane at the top of each loop): LLVM's uniformity
+//     analysis cannot see through a ds_bpermute or a loop with a lane-dependent exit, and one misjudged value turns every
+//     later branch into EXEC-mask bookkeeping;
+//   * the heap walk pops in batches (batchPop: every head below the smallest second entry of any list) and jumps over
+//     entries that cannot reach the hit cutoff (bulkSkip); both reproduce the reference's pop sequence exactly.
 // Nothing per-read is kept in scratch memory: the per-lane kernel (index_probe.hip) spilled ~10 KB per read to HBM.
-// Reads with more than 64 keys are marked NSITES_PENDING and taken by the per-lane kernel afterwards.
+// Reads with more than 64 keys or longer than the instantiation's LDS arrays are marked NSITES_PENDING and taken by the
+// per-lane kernel afterwards.  Four instantiations: <long lists?, LDS read capacity 160 | 400> (see bbidx_launch_wave).
 //
 // Functions follow current/align2/BBIndex.java exactly as index_probe.hip does (same citations); the two kernels and
 // the CPU oracle are compared SiteScore by SiteScore in tests/test_index_gpu.py.
