@@ -55,6 +55,15 @@ def test_index_build_rejects_bad_geometry_and_handles_tiny_chromosomes():
     assert di.find_batch([(b"N" * 60, [0] * 60, [1100, 1100], [0, 49])]) == [[]]
     with pytest.raises(_lib.BBMapAmdError):
         di.find_batch([(b"ACGTAC", [0] * 6, [1100], [0])])
+    # the read-length announcement is a sizing hint: nonsense is refused, and a read longer than announced is still answered
+    with pytest.raises(_lib.BBMapAmdError):
+        di.set_max_read_len(0)
+    rd = (b"ACGTTGCATGCATTGACCAGT" * 40)[5:205]
+    offs = list(range(0, 190, 9))
+    di.set_max_read_len(600)
+    want = di.find_batch([(rd, [0] * len(rd), [1100] * len(offs), offs)])
+    di.set_max_read_len(100)
+    assert di.find_batch([(rd, [0] * len(rd), [1100] * len(offs), offs)]) == want
     di.close()
 
 
