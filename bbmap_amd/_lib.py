@@ -17,6 +17,8 @@ EXPORTS = [
     "bbmsa_align_gapped_batch_device_indirect",
     "bbband_create", "bbband_destroy", "bbband_align_batch_device", "bbband_align_batch",
     "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch", "bbidx_find_batch_device_rc", "bbidx_last_stats", "bbidx_set_kernel", "bbidx_set_max_read_len", "bbidx_build", "bbidx_get_params", "bbidx_export_block",
+    "bbmap_default_config", "bbmap_create", "bbmap_destroy", "bbmap_map_batch_device", "bbmap_get_output", "bbmap_last_stats",
+    "bbmap_copy_to_host", "bbidx_get_chrom_table",
     "bbpipe_revcomp_device", "bbpipe_select_jobs_device", "bbpipe_quick_rescue_device", "bbpipe_match_no_indels_device",
 ]
 

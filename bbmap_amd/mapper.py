@@ -1,0 +1,147 @@
+"""Python binding of the device-resident mapper (bbmap_* in include/bbmap_amd.h): probe -> pairing / trimming -> ungapped
+scores -> scoreSlow in rounds -> rescue, everything in HBM.  Used by bench.py and the tests; needs torch for device buffers."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import msa as M
+from .index import READ_DTYPE
+
+MSITE_DTYPE = np.dtype([("chrom", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("stop", "<i4"), ("hits", "<i4"),
+                        ("quickScore", "<i4"), ("score", "<i4"), ("slowScore", "<i4"), ("pairedScore", "<i4"),
+                        ("perfect", "<i4"), ("semiperfect", "<i4"), ("rescued", "<i4"), ("ngaps", "<i4"),
+                        ("gaps", "<i4", (16,)), ("match_job", "<i4"), ("reserved", "<i4", (2,))])
+JOBINFO_DTYPE = np.dtype([("read", "<i4"), ("seq", "<i4"), ("kind", "<i4"), ("site", "<i4")])
+assert MSITE_DTYPE.itemsize == 128
+GAPPED_BIT = 1 << 30
+
+
+class bbmap_config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("paired", C.c_int32), ("max_reads", C.c_int32), ("max_read_len", C.c_int32),
+                ("max_sites", C.c_int32), ("minRatio", C.c_float)] + [(n, C.c_int32) for n in (
+                    "slowAlignPadding", "slowRescuePadding", "extraPadding", "tipSearchDist", "maxPairDist", "averagePairDist",
+                    "maxRescueDist", "maxRescueMismatches", "maxTrimSitesToRetain", "trimList", "doRescue", "alignColumns",
+                    "clearzone3", "msaMaxColumns", "fastCols", "jobsPerRead")] + [("reserved", C.c_int32 * 4)]
+
+
+class bbmap_output(C.Structure):
+    _fields_ = [("sites", C.c_void_p), ("nsites", C.c_void_p), ("cap", C.c_int32), ("match_stride", C.c_int32),
+                ("gmatch_stride", C.c_int32), ("reserved", C.c_int32), ("n_jobs", C.c_int64), ("n_gapped_jobs", C.c_int64),
+                ("jobs", C.c_void_p), ("results", C.c_void_p), ("jobinfo", C.c_void_p), ("match", C.c_void_p),
+                ("gjobs", C.c_void_p), ("gresults", C.c_void_p), ("gjobinfo", C.c_void_p), ("gmatch", C.c_void_p),
+                ("ggaps", C.c_void_p)]
+
+
+class bbmap_stats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("reads", "reads_overflowed", "reads_without_site", "fills", "gapped_fills", "refills",
+                                         "rescue_scans", "rescue_fills", "rounds", "dp_cells")] + \
+               [(n, C.c_float) for n in ("ms_probe", "ms_begin", "ms_score", "ms_slow", "ms_finish", "ms_rescue", "ms_total",
+                                         "ms_dp_narrow", "ms_dp_wave", "ms_dp_generic", "ms_dp_gapped", "ms_quick_rescue")] + \
+               [("probe_stats", C.c_int64 * 5)]
+
+
+def _bind(L):
+    L.bbmap_default_config.argtypes = [C.POINTER(bbmap_config)]
+    L.bbmap_create.argtypes = [C.c_void_p, C.POINTER(bbmap_config), C.POINTER(C.c_void_p)]
+    L.bbmap_destroy.argtypes = [C.c_void_p]
+    L.bbmap_destroy.restype = None
+    L.bbmap_map_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.bbmap_get_output.argtypes = [C.c_void_p, C.POINTER(bbmap_output)]
+    L.bbmap_last_stats.argtypes = [C.c_void_p, C.POINTER(bbmap_stats)]
+    for f in ("bbmap_default_config", "bbmap_create", "bbmap_map_batch_device", "bbmap_get_output", "bbmap_last_stats"):
+        getattr(L, f).restype = C.c_int
+
+
+def _copy(ptr, nbytes, dev=None):
+    """device memory -> numpy bytes (bbmap_copy_to_host)"""
+    out = np.empty(max(nbytes, 0), np.uint8)
+    if nbytes > 0:
+        L = _lib.load()
+        L.bbmap_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.bbmap_copy_to_host.restype = C.c_int
+        _lib.check(L.bbmap_copy_to_host(out.ctypes.data, C.c_void_p(ptr), nbytes), "bbmap_copy_to_host")
+    return out
+
+
+class Mapper:
+    """One bbmap_ctx over a DeviceIndex.  Reads of one fixed length, all with the same key offsets / key scores."""
+
+    def __init__(self, di, n_reads, read_len, offsets, key_scores, paired=False, device=0, max_sites=32, **cfg_kw):
+        self.L = _lib.load()
+        _bind(self.L)
+        self.di, self.n, self.read_len, self.paired = di, n_reads, read_len, paired
+        self.dev = torch.device("cuda", device)
+        di.set_max_read_len(read_len)
+        cfg = bbmap_config()
+        _lib.check(self.L.bbmap_default_config(C.byref(cfg)), "bbmap_default_config")
+        cfg.device, cfg.paired, cfg.max_reads, cfg.max_read_len, cfg.max_sites = device, int(paired), n_reads, read_len, max_sites
+        for k, v in cfg_kw.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        h = C.c_void_p()
+        _lib.check(self.L.bbmap_create(di.h, C.byref(cfg), C.byref(h)), "bbmap_create")
+        self.h = h
+        self.total_bytes = n_reads * read_len
+        self.bases = torch.zeros(2 * self.total_bytes, dtype=torch.uint8, device=self.dev)       # plus strands, then reverse complements
+        self.base_scores = torch.zeros(self.total_bytes, dtype=torch.int8, device=self.dev)
+        recs = np.zeros(n_reads, READ_DTYPE)
+        recs["bases_off"] = np.arange(n_reads, dtype=np.int64) * read_len
+        recs["keys_off"] = 0
+        recs["len"] = read_len
+        recs["nkeys"] = len(offsets)
+        self.reads = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(self.dev)
+        self.keyinfo = torch.tensor(list(offsets) + list(key_scores), dtype=torch.int32, device=self.dev)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bbmap_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_reads(self, reads_u8):
+        """reads_u8: n_reads x read_len bases; paired mode: mates interleaved (read 2p, 2p+1)."""
+        assert reads_u8.size == self.total_bytes
+        self.bases[: self.total_bytes].copy_(torch.from_numpy(np.ascontiguousarray(reads_u8).reshape(-1)))
+
+    def step(self):
+        """Maps the resident batch; returns when it is done (bbmap_map_batch_device waits for its stream)."""
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.L.bbmap_map_batch_device(self.h, C.c_void_p(stream), self.n, self.reads.data_ptr(), self.bases.data_ptr(),
+                                                 self.total_bytes, self.base_scores.data_ptr(), self.keyinfo.data_ptr()),
+                   "bbmap_map_batch_device")
+
+    def stats(self):
+        st = bbmap_stats()
+        _lib.check(self.L.bbmap_last_stats(self.h, C.byref(st)), "bbmap_last_stats")
+        d = {n: getattr(st, n) for n, _ in bbmap_stats._fields_ if n != "probe_stats"}
+        d["probe_stats"] = list(st.probe_stats)
+        return d
+
+    def fetch(self, with_match=True):
+        """Host copies of a step's results: sites (n x cap, MSITE_DTYPE), nsites, and the two fill logs."""
+        o = bbmap_output()
+        _lib.check(self.L.bbmap_get_output(self.h, C.byref(o)), "bbmap_get_output")
+        n, cap = self.n, o.cap
+        out = dict(cap=cap)
+        out["sites"] = _copy(o.sites, n * cap * 128, self.dev).view(MSITE_DTYPE).reshape(n, cap)
+        out["nsites"] = _copy(o.nsites, n * 4, self.dev).view(np.int32)
+        nj, ng = int(o.n_jobs), int(o.n_gapped_jobs)
+        out["jobs"] = _copy(o.jobs, nj * 40, self.dev).view(M.JOB_DTYPE)
+        out["results"] = _copy(o.results, nj * 80, self.dev).view(M.RESULT_DTYPE)
+        out["jobinfo"] = _copy(o.jobinfo, nj * 16, self.dev).view(JOBINFO_DTYPE)
+        out["gjobs"] = _copy(o.gjobs, ng * 40, self.dev).view(M.JOB_DTYPE)
+        out["gresults"] = _copy(o.gresults, ng * 80, self.dev).view(M.RESULT_DTYPE)
+        out["gjobinfo"] = _copy(o.gjobinfo, ng * 16, self.dev).view(JOBINFO_DTYPE)
+        out["ggaps"] = _copy(o.ggaps, ng * 68, self.dev).view(M.GAPS_DTYPE)
+        out["match_stride"], out["gmatch_stride"] = o.match_stride, o.gmatch_stride
+        if with_match:
+            out["match"] = _copy(o.match, nj * o.match_stride, self.dev).reshape(nj, o.match_stride)
+            out["gmatch"] = _copy(o.gmatch, ng * o.gmatch_stride, self.dev).reshape(ng, o.gmatch_stride)
+        return out

@@ -49,13 +49,18 @@ def make_reference(length, seed, pad=START_PAD, repeat_frac=0.0, families=2000):
 
 def make_reads_and_jobs(ref, n_reads, read_len=150, seed=2, pad=START_PAD, align_pad=4,
                         min_ratio=0.56, perfect_frac=0.5, flags=FILL_AND_SCORE_LIMITED | DO_TRACEBACK,
-                        chunk=131072, max_del=40, max_ins=12, long_del_frac=0.0, long_del=(300, 800)):
-    """Returns (reads_blob uint8[n*read_len... variable], jobs structured array, truth dict)."""
+                        chunk=131072, max_del=40, max_ins=12, long_del_frac=0.0, long_del=(300, 800), starts=None,
+                        hard_frac=0.0):
+    """Returns (reads_blob uint8[n*read_len... variable], jobs structured array, truth dict).  starts: read start
+    coordinates to use instead of drawing them; hard_frac: share of the reads that additionally get 8-12 % substitutions
+    (mates the index probe tends to miss and the paired rescue has to find)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     n = n_reads
     body = len(ref) - 2 * pad
     reach = max(max_del, long_del[1] if long_del_frac > 0 else 0)
     start = rng.integers(pad, pad + body - read_len - reach - 8, size=n, dtype=np.int64)
+    if starts is not None:
+        start = np.clip(np.asarray(starts, np.int64), pad, pad + body - read_len - reach - 9)
     imperfect = rng.random(n) >= perfect_frac
     # event draws (only applied to imperfect reads)
     n_snp = np.where(imperfect & (rng.random(n) < 0.4), rng.integers(1, 4, size=n), 0)
@@ -100,6 +105,15 @@ def make_reads_and_jobs(ref, n_reads, read_len=150, seed=2, pad=START_PAD, align
         rows = np.nonzero(has_n[lo:hi])[0]
         if rows.size:
             block[rows, rng.integers(0, read_len, size=rows.size)] = ord("N")
+        if hard_frac > 0:
+            rows = np.nonzero(rng.random(m) < hard_frac)[0]
+            if rows.size:
+                nsub = rng.integers(int(0.08 * read_len), int(0.12 * read_len) + 1, size=rows.size)
+                for rr_, k_ in zip(rows, nsub):
+                    cols = rng.choice(read_len, size=int(k_), replace=False)
+                    old = block[rr_, cols]
+                    new = BASES[(np.searchsorted(BASES, old) + rng.integers(1, 4, size=cols.size)) % 4]
+                    block[rr_, cols] = np.where(old == ord("N"), old, new)
         reads[lo:hi] = block
         del idx, block, shift, after, ins_mask
 
@@ -116,6 +130,43 @@ def make_reads_and_jobs(ref, n_reads, read_len=150, seed=2, pad=START_PAD, align
     jobs["flags"] = flags
     truth = {"start": start, "span": span, "imperfect": imperfect}
     return reads.reshape(-1), jobs, truth
+
+
+_COMP = np.full(256, 255, np.uint8)
+for _a, _b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[_a] = _b
+
+
+def revcomp_rows(reads2d):
+    """Reverse complement of every row (AminoAcid.reverseComplementBases for the bytes A, C, G, T, N)."""
+    return _COMP[reads2d[:, ::-1]]
+
+
+def make_pairs(ref, n_pairs, read_len=150, seed=3, pad=START_PAD, hard_frac=0.03, middle=(-100, 100)):
+    """Synthetic read pairs as randomreads.sh makes them (current/align2/RandomReads3.java:1726-1727 mateMiddleMin/Max = -100/100,
+    mates on opposite strands): the unsequenced middle between the mates is triangular on [-100, 100] (negative = the mates
+    overlap), each mate carries the mutated mix of make_reads_and_jobs, a share hard_frac of the mates is additionally riddled
+    with substitutions, and half of the fragments come from the minus strand (read 1 and read 2 swap roles).
+    Returns (reads uint8[2 * n_pairs * read_len], mates INTERLEAVED: read 2p is mate 1 of pair p, read 2p+1 its mate 2,
+             truth dict: start1, start2 = leftmost reference coordinate of each mate's alignment, strand1, strand2)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    body = len(ref) - 2 * pad
+    mid = np.rint(rng.triangular(middle[0], 0.5 * (middle[0] + middle[1]), middle[1], size=n_pairs)).astype(np.int64)
+    left = rng.integers(pad, pad + body - 2 * read_len - middle[1] - 64, size=n_pairs, dtype=np.int64)
+    right = left + read_len + mid
+    ra, _, ta = make_reads_and_jobs(ref, n_pairs, read_len=read_len, seed=seed * 7919 + 1, pad=pad, starts=left, hard_frac=hard_frac)
+    rb, _, tb = make_reads_and_jobs(ref, n_pairs, read_len=read_len, seed=seed * 7919 + 2, pad=pad, starts=right, hard_frac=hard_frac)
+    ra = ra.reshape(n_pairs, read_len)
+    rb = revcomp_rows(rb.reshape(n_pairs, read_len))              # the right-hand mate is read from the other strand
+    flip = rng.random(n_pairs) < 0.5                               # fragment from the minus strand: mate 1 is the right-hand one
+    m1 = np.where(flip[:, None], rb, ra)
+    m2 = np.where(flip[:, None], ra, rb)
+    reads = np.empty((2 * n_pairs, read_len), np.uint8)
+    reads[0::2] = m1
+    reads[1::2] = m2
+    truth = {"start1": np.where(flip, tb["start"], ta["start"]), "start2": np.where(flip, ta["start"], tb["start"]),
+             "strand1": flip.astype(np.int32), "strand2": (~flip).astype(np.int32)}
+    return reads.reshape(-1), truth
 
 
 def algorithmic_bytes(jobs):

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define BBMAP_AMD_ABI_VERSION 2
+#define BBMAP_AMD_ABI_VERSION 3
 
 enum {
     BBMAP_OK = 0,
@@ -384,6 +384,110 @@ int bbpipe_quick_rescue_device(void *stream, int64_t n_jobs, const bbresc_job *j
                                const int64_t *chrom_off, const int32_t *chrom_len, const int32_t *chrom_min_index,
                                const uint8_t *refs, bbresc_result *results,
                                int32_t points_match, int32_t points_match2, int32_t use_affine, int32_t base_hit_score);
+
+
+/* =====================================================================================
+ * Mapper control flow around the two hot kernels, device-resident.
+ *   The part of align2.BBMapThread.processRead / processReadPair (current/align2/BBMapThread.java:389-490, :943-1098)
+ *   that decides WHICH probe sites are aligned, with which window and minScore, in which order, and which rescue searches
+ *   run, kept on the device so that a read batch stays in HBM from the probe to the last alignment:
+ *     quickMap tail      AbstractMapThread.java:736-751 (findAdvanced; removeOutOfBounds :2444-2476)
+ *     pairing + trimming BBMapThread.java:736-940 pairSiteScoresInitial, :140-249 trimList (Tools.java:654-674, :1113-1161)
+ *     scoreNoIndels      AbstractMapThread.java:762-856;  findTipDeletions :1075-1141, :2178-2292
+ *     scoreSlow          BBMapThread.java:252-386 -- the exact per-read SEQUENCE: every site's minScore follows the previous
+ *                        sites' results (minMsaLimit, :376) and a fill that asks for more padding is repeated wider (:312-335),
+ *                        so the DP runs in rounds (round j = the j-th fill of every read that still has one)
+ *     mergeDuplicateSites Tools.java:697-759
+ *     rescue / slowRescue AbstractMapThread.java:1144-1306 (quickRescue :2303-2404), mate 1 as anchor, then mate 2
+ *   Configuration: bbmap.sh defaults (BBMap.setDefaults, BBMap.java:45-65), reads without qualities.
+ *   Not carried over: per-thread adaptive state of the Java mapper (DYNAMIC_INSERT_LENGTH, the "mating is not working" skip
+ *   of rescue()), scaffold boundaries inside a chromosome, and everything after the rescue stage (final pairing, ambiguity /
+ *   clearzone policy, genMatchString -> realign_new): those stay on the host side of the boundary.
+ *   Added product: every successful fill also returns its traceback string (as the quickmatch=t branch obtains it,
+ *   BBMapThread.java:345, without fixXY / clipTipIndels); site state follows the default (quickmatch=f) flow.
+ * ===================================================================================== */
+typedef struct bbmap_msite {       /* stream.SiteScore, current/stream/SiteScore.java:999-1011 */
+    int32_t chrom, strand, start, stop, hits;
+    int32_t quickScore, score, slowScore, pairedScore;
+    int32_t perfect, semiperfect, rescued;
+    int32_t ngaps;                 /* 0 = gaps == null */
+    int32_t gaps[BBMSA_MAX_GAPS];
+    int32_t match_job;             /* fill whose result (limits, traceback string) this site carries: index into the job log,
+                                    * bit 30 set = the gapped log; -1 = none */
+    int32_t reserved[2];
+} bbmap_msite;                     /* 128 bytes */
+
+typedef struct bbmap_jobinfo {     /* one entry per fill, parallel to the job / result arrays */
+    int32_t read;                  /* read the fill belongs to */
+    int32_t seq;                   /* its position in that read's sequence of fillAndScoreLimited calls */
+    int32_t kind;                  /* 0 scoreSlow fill, 1 scoreSlow wider refill, 2 slowRescue */
+    int32_t site;                  /* list position of the site when the fill was issued */
+} bbmap_jobinfo;                   /* 16 bytes */
+
+typedef struct bbmap_config {
+    int32_t device;
+    int32_t paired;                /* 0: processRead per read; 1: processReadPair, reads 2p and 2p+1 are mates */
+    int32_t max_reads;             /* capacity in reads (not pairs) */
+    int32_t max_read_len;          /* <= 600 */
+    int32_t max_sites;             /* per-read capacity of the probe output and of the mapper's site list */
+    float   minRatio;              /* MINIMUM_ALIGNMENT_SCORE_RATIO (0.56) */
+    int32_t slowAlignPadding;      /* 4 */
+    int32_t slowRescuePadding;     /* 8 */
+    int32_t extraPadding;          /* 10 */
+    int32_t tipSearchDist;         /* TIP_DELETION_SEARCH_RANGE, 100; 0 switches findTipDeletions off */
+    int32_t maxPairDist;           /* 32000 */
+    int32_t averagePairDist;       /* INITIAL_AVERAGE_PAIR_DIST, 100 */
+    int32_t maxRescueDist;         /* 1200 */
+    int32_t maxRescueMismatches;   /* 32 */
+    int32_t maxTrimSitesToRetain;  /* 800 */
+    int32_t trimList;              /* 1 */
+    int32_t doRescue;              /* 1 */
+    int32_t alignColumns;          /* BBIndex.ALIGN_COLUMNS, 3000 */
+    int32_t clearzone3;            /* PENALIZE_AMBIG ? 800 : 0 */
+    int32_t msaMaxColumns;         /* columns of the MSA instance (3000 in the reference) */
+    int32_t fastCols;              /* first-pass column buffer of the DP kernel (0 = 256) */
+    int32_t jobsPerRead;           /* capacity of the job log = jobsPerRead * max_reads (0 = 3) */
+    int32_t reserved[4];
+} bbmap_config;
+
+typedef struct bbmap_output {      /* device pointers, valid until the next bbmap_map_batch_device / bbmap_destroy */
+    const bbmap_msite *sites;      /* n_reads x cap */
+    const int32_t *nsites;         /* per read: sites in its list, -1 = the probe overflowed max_sites (list not processed) */
+    int32_t cap;
+    int32_t match_stride, gmatch_stride;
+    int32_t reserved;
+    int64_t n_jobs, n_gapped_jobs; /* fills in the two logs */
+    const bbmsa_job *jobs;   const bbmsa_result *results;  const bbmap_jobinfo *jobinfo;  const uint8_t *match;
+    const bbmsa_job *gjobs;  const bbmsa_result *gresults; const bbmap_jobinfo *gjobinfo; const uint8_t *gmatch;
+    const bbmsa_gaps *ggaps;
+} bbmap_output;
+
+typedef struct bbmap_stats {
+    int64_t reads, reads_overflowed, reads_without_site, fills, gapped_fills, refills, rescue_scans, rescue_fills, rounds;
+    int64_t dp_cells;              /* visited cells over all fills (result.iterations) -- filled by bbmap_last_stats on request */
+    float ms_probe, ms_begin, ms_score, ms_slow, ms_finish, ms_rescue, ms_total;
+    float ms_dp_narrow, ms_dp_wave, ms_dp_generic, ms_dp_gapped, ms_quick_rescue;
+    int64_t probe_stats[5];        /* bbidx_last_stats of the probe launch */
+} bbmap_stats;
+
+typedef struct bbmap_ctx bbmap_ctx;
+int bbmap_default_config(bbmap_config *cfg);
+/* The context borrows `index` (which must outlive it) and owns two DP contexts (plain and gapped-reference) and every
+ * intermediate buffer. */
+int bbmap_create(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx **out);
+void bbmap_destroy(bbmap_ctx *ctx);
+/* Maps a batch that is resident on the device.  reads[i].bases_off addresses the plus strand inside `bases`; the call writes
+ * every read's reverse complement at bases_off + minus_delta.  Enqueues on `stream` and waits for it: the call returns when the
+ * batch is done (the rounds of scoreSlow need the job counts on the host). */
+int bbmap_map_batch_device(bbmap_ctx *ctx, void *stream, int64_t n_reads, const bbidx_read *reads, uint8_t *bases,
+                           int64_t minus_delta, const int8_t *baseScores, const int32_t *keyinfo);
+int bbmap_get_output(bbmap_ctx *ctx, bbmap_output *out);
+int bbmap_last_stats(bbmap_ctx *ctx, bbmap_stats *out);
+/* synchronous device-to-host copy of (part of) an output array */
+int bbmap_copy_to_host(void *dst, const void *src_device, int64_t bytes);
+
+/* device tables of an index context: chromArr[c] (device pointer to chromosome c's bytes), chromArrLen[c]; host copies */
+int bbidx_get_chrom_table(bbidx_ctx *ctx, int32_t *nchroms, const uint8_t **chromArr_host_copy, int32_t *chromArrLen_host_copy, int32_t cap);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,64 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.  Interface of mapper_oracle.c: the mapper control flow around the probe and the DP
+ * (BBMapThread.processRead / processReadPair up to the end of the rescue stage), restated on the CPU.
+ */
+#ifndef BBMAP_ORACLE_MAPPER_H
+#define BBMAP_ORACLE_MAPPER_H
+#include <stdint.h>
+
+#include "index_oracle.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_GAPS 16
+
+/* stream.SiteScore (current/stream/SiteScore.java:999-1011); same layout as bbmap_msite (include/bbmap_amd.h) */
+typedef struct orc_msite {
+    int32_t chrom, strand, start, stop, hits;
+    int32_t quickScore, score, slowScore, pairedScore;
+    int32_t perfect, semiperfect, rescued;
+    int32_t ngaps;                 /* 0 = gaps == null */
+    int32_t gaps[ORC_MAX_GAPS];
+    int32_t match_job;             /* index of the fill (job log) whose traceback belongs to this site, -1 = none */
+    int32_t reserved[2];
+} orc_msite;                       /* 128 bytes */
+
+/* the mapper's settings (defaults: bbmap.sh) */
+typedef struct orc_map_params {
+    float minRatio;                /* MINIMUM_ALIGNMENT_SCORE_RATIO 0.56 */
+    int32_t slowAlignPadding;      /* 4 */
+    int32_t slowRescuePadding;     /* 8 */
+    int32_t extraPadding;          /* 10 */
+    int32_t tipSearchDist;         /* TIP_DELETION_SEARCH_RANGE 100; 0 = off */
+    int32_t maxPairDist;           /* 32000 */
+    int32_t averagePairDist;       /* INITIAL_AVERAGE_PAIR_DIST 100 */
+    int32_t maxRescueDist;         /* 1200 */
+    int32_t maxRescueMismatches;   /* 32 */
+    int32_t maxTrimSitesToRetain;  /* 800 */
+    int32_t trimList;              /* 1 */
+    int32_t doRescue;              /* 1 */
+    int32_t alignColumns;          /* BBIndex.ALIGN_COLUMNS 3000 */
+    int32_t clearzone3;            /* PENALIZE_AMBIG ? 800 : 0 */
+    int32_t msaMaxRows, msaMaxColumns;   /* the MSA instance: 601 x 3000 in the reference */
+} orc_map_params;
+
+typedef struct orc_mjob {          /* one MSA.fillAndScoreLimited call */
+    int32_t read, seq, kind;       /* kind: 0 scoreSlow fill, 1 scoreSlow wider refill, 2 slowRescue */
+    int32_t strand, chrom, refStartLoc, refEndLoc, minScore, ngaps;
+    int32_t score_len; int32_t score[8];
+    int32_t match_len, pad_;
+    int64_t iterations;
+} orc_mjob;                        /* 88 bytes */
+
+void orc_map_default_params(orc_map_params *P);
+float orc_ratio_paired(float R);
+float orc_ratio_pre_rescue(float R);
+double orc_map_batch(const orc_index *ix, const orc_map_params *P, const uint8_t *reads1, const uint8_t *reads2, int64_t n, int L,
+                     const int32_t *offsets, const int32_t *keyScores, int nkeys, int cap,
+                     orc_msite *sites1, int32_t *nsites1, orc_msite *sites2, int32_t *nsites2,
+                     orc_mjob *log, int64_t logcap, int64_t *nlog, uint8_t *match, int matchStride, int threads, int64_t *stats4);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -351,3 +351,66 @@ def set_perfect(bases, ref, start, stop):
     out = np.zeros(2, np.int32)
     lib().orc_set_perfect(_p(b, c_u8p), len(bases), _p(f, c_u8p), len(ref), start, stop, _p(out, c_i32p))
     return int(out[0]), int(out[1])
+
+
+# ---------------------------------------------------------------------------------------------- mapper control flow
+MSITE_DTYPE = np.dtype([("chrom", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("stop", "<i4"), ("hits", "<i4"),
+                        ("quickScore", "<i4"), ("score", "<i4"), ("slowScore", "<i4"), ("pairedScore", "<i4"),
+                        ("perfect", "<i4"), ("semiperfect", "<i4"), ("rescued", "<i4"), ("ngaps", "<i4"),
+                        ("gaps", "<i4", (16,)), ("match_job", "<i4"), ("reserved", "<i4", (2,))])
+MJOB_DTYPE = np.dtype([("read", "<i4"), ("seq", "<i4"), ("kind", "<i4"), ("strand", "<i4"), ("chrom", "<i4"),
+                       ("refStartLoc", "<i4"), ("refEndLoc", "<i4"), ("minScore", "<i4"), ("ngaps", "<i4"),
+                       ("score_len", "<i4"), ("score", "<i4", (8,)), ("match_len", "<i4"), ("pad_", "<i4"),
+                       ("iterations", "<i8")])
+assert MSITE_DTYPE.itemsize == 128 and MJOB_DTYPE.itemsize == 88
+
+
+class MapParams(C.Structure):
+    _fields_ = [("minRatio", C.c_float)] + [(n, C.c_int32) for n in (
+        "slowAlignPadding", "slowRescuePadding", "extraPadding", "tipSearchDist", "maxPairDist", "averagePairDist",
+        "maxRescueDist", "maxRescueMismatches", "maxTrimSitesToRetain", "trimList", "doRescue", "alignColumns",
+        "clearzone3", "msaMaxRows", "msaMaxColumns")]
+
+
+def map_default_params(**kw):
+    p = MapParams()
+    lib().orc_map_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def map_batch(oi, reads1, reads2, L, offsets, key_scores, params=None, cap=64, want_log=True, threads=1, match_stride=0):
+    """The mapper control flow (BBMapThread.processRead / processReadPair up to the end of rescue) on the CPU oracle.
+    reads1/reads2: uint8 arrays of n*L bases (reads2 None = single-ended).  Returns a dict: sites1/nsites1 (and 2), the job
+    log (one record per fillAndScoreLimited call, with its traceback string), stats, seconds."""
+    L_ = lib()
+    p = params or map_default_params()
+    r1 = np.ascontiguousarray(reads1, np.uint8)
+    n = r1.size // L
+    r2 = None if reads2 is None else np.ascontiguousarray(reads2, np.uint8)
+    offs = np.asarray(offsets, np.int32).copy()
+    ks = np.asarray(key_scores, np.int32).copy()
+    s1 = np.zeros((n, cap), MSITE_DTYPE)
+    n1 = np.zeros(n, np.int32)
+    s2 = np.zeros((n, cap), MSITE_DTYPE) if r2 is not None else None
+    n2 = np.zeros(n, np.int32) if r2 is not None else None
+    logcap = (n * 8 * (2 if r2 is not None else 1) + 64) if want_log else 0
+    log = np.zeros(max(1, logcap), MJOB_DTYPE)
+    stride = match_stride or (p.msaMaxRows + 700)
+    match = np.zeros((max(1, logcap), stride), np.uint8) if want_log else None
+    nlog = C.c_int64(0)
+    stats = np.zeros(4, np.int64)
+    L_.orc_map_batch.restype = C.c_double
+    L_.orc_map_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    t = L_.orc_map_batch(C.c_void_p(oi.h), C.byref(p), r1.ctypes.data, None if r2 is None else r2.ctypes.data, n, L,
+                         offs.ctypes.data, ks.ctypes.data, len(offs), cap,
+                         s1.ctypes.data, n1.ctypes.data, None if s2 is None else s2.ctypes.data, None if n2 is None else n2.ctypes.data,
+                         log.ctypes.data if want_log else None, logcap, C.addressof(nlog),
+                         match.ctypes.data if want_log else None, stride, threads, stats.ctypes.data)
+    if want_log and nlog.value > logcap:
+        raise RuntimeError("job log overflow")
+    return dict(sites1=s1, nsites1=n1, sites2=s2, nsites2=n2, log=log[:nlog.value] if want_log else None,
+                match=match[:nlog.value] if want_log else None, stats=stats.tolist(), seconds=t)

@@ -1,0 +1,80 @@
+"""Shared by the mapper tests, __graft_entry__.smoke() and bench.py's parity sample: compares what the device mapper (bbmap_*)
+returned for a batch with what the CPU oracle's mapper restatement (oracle/mapper_oracle.c) returns for the same reads."""
+import numpy as np
+
+SITE_FIELDS = ("chrom", "strand", "start", "stop", "hits", "quickScore", "score", "slowScore", "pairedScore",
+               "perfect", "semiperfect", "rescued", "ngaps")
+GAPPED_BIT = 1 << 30
+
+
+def gpu_fills(out):
+    """{(read, seq): dict} over both fill logs of a Mapper.fetch()."""
+    fills = {}
+    for jobs, res, info, match, bit in ((out["jobs"], out["results"], out["jobinfo"], out.get("match"), 0),
+                                        (out["gjobs"], out["gresults"], out["gjobinfo"], out.get("gmatch"), GAPPED_BIT)):
+        for i in range(len(jobs)):
+            key = (int(info["read"][i]), int(info["seq"][i]))
+            assert key not in fills, "two fills with the same (read, seq) %r" % (key,)
+            n = int(res["score_len"][i])
+            ml = int(res["match_len"][i])
+            fills[key] = dict(kind=int(info["kind"][i]), refStartLoc=int(jobs["refStartLoc"][i]), refEndLoc=int(jobs["refEndLoc"][i]),
+                              minScore=int(jobs["minScore"][i]), score=res["score"][i][:n].tolist(), iterations=int(res["iterations"][i]),
+                              match=(match[i, :ml].tobytes() if (match is not None and n > 0 and ml > 0) else b""), index=i | bit)
+    return fills
+
+
+def oracle_fills(orc):
+    fills = {}
+    log, match = orc["log"], orc["match"]
+    for i in range(len(log)):
+        key = (int(log["read"][i]), int(log["seq"][i]))
+        n = int(log["score_len"][i])
+        ml = int(log["match_len"][i])
+        fills[key] = dict(kind=int(log["kind"][i]), refStartLoc=int(log["refStartLoc"][i]), refEndLoc=int(log["refEndLoc"][i]),
+                          minScore=int(log["minScore"][i]), score=log["score"][i][:n].tolist(), iterations=int(log["iterations"][i]),
+                          match=(match[i, :ml].tobytes() if n > 0 else b""), index=i)
+    return fills
+
+
+def compare(out, orc, n_reads, paired, reads_range=None, check_match=True):
+    """Returns a list of human-readable differences (empty = identical).  Read r of the device batch is oracle read r
+    (single-ended) or mate r % 2 of pair r // 2 (paired)."""
+    bad = []
+    gf, of = gpu_fills(out), oracle_fills(orc)
+    rng = range(n_reads) if reads_range is None else reads_range
+    in_range = set(rng)
+    gkeys = {k for k in gf if k[0] in in_range}
+    okeys = {k for k in of if k[0] in in_range}
+    if gkeys != okeys:
+        bad.append("fill sets differ: only on device %s, only in oracle %s" % (sorted(gkeys - okeys)[:5], sorted(okeys - gkeys)[:5]))
+    for k in sorted(gkeys & okeys):
+        a, b = gf[k], of[k]
+        for f in ("kind", "refStartLoc", "refEndLoc", "minScore", "score", "iterations") + (("match",) if check_match else ()):
+            if a[f] != b[f]:
+                bad.append("fill %r field %s: device %r, oracle %r" % (k, f, a[f], b[f]))
+                break
+    g_by_index = {v["index"]: k for k, v in gf.items()}
+    o_by_index = {v["index"]: k for k, v in of.items()}
+    for r in rng:
+        if paired:
+            osites, on = (orc["sites1"], orc["nsites1"]) if r % 2 == 0 else (orc["sites2"], orc["nsites2"])
+            oi = r // 2
+        else:
+            osites, on, oi = orc["sites1"], orc["nsites1"], r
+        gn = int(out["nsites"][r])
+        if gn != int(on[oi]):
+            bad.append("read %d: %d sites on the device, %d in the oracle" % (r, gn, int(on[oi])))
+            continue
+        for s in range(max(gn, 0)):
+            g, o = out["sites"][r, s], osites[oi, s]
+            dif = [f for f in SITE_FIELDS if int(g[f]) != int(o[f])]
+            if not dif and int(g["ngaps"]) and g["gaps"][: int(g["ngaps"])].tolist() != o["gaps"][: int(o["ngaps"])].tolist():
+                dif = ["gaps"]
+            gj, oj = int(g["match_job"]), int(o["match_job"])
+            if not dif and ((gj < 0) != (oj < 0) or (gj >= 0 and g_by_index.get(gj) != o_by_index.get(oj))):
+                dif = ["match_job"]
+            if dif:
+                bad.append("read %d site %d differs in %s: device %s, oracle %s" % (
+                    r, s, dif, {f: int(g[f]) for f in SITE_FIELDS}, {f: int(o[f]) for f in SITE_FIELDS}))
+                break
+    return bad

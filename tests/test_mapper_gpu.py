@@ -1,0 +1,91 @@
+"""GPU tests of the device-resident mapper (bbmap_*): single-ended processRead and paired processReadPair (pairing, trimming,
+ungapped scores, tip deletions, scoreSlow rounds with the exact minScore sequence and wider refills, rescue) against the CPU
+restatement oracle/mapper_oracle.c -- site lists field by field, every fill's window / minScore / score vector / visited-cell
+count / traceback string, and which fill each site took its limits from."""
+import numpy as np
+import pytest
+
+from bbmap_amd import workload as W
+from bbmap_amd.index import DeviceIndex
+from bbmap_amd.mapper import Mapper
+from oracle import oracle as O
+from tests.mapper_check import compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ref, reads, L, k, paired, max_sites=32, cap=64, **cfg):
+    di = DeviceIndex.build([ref], k=k)
+    offs = O.make_offsets(L, k, 1.9)
+    ks = [100 * k] * len(offs)
+    n = reads.size // L
+    mp = Mapper(di, n, L, offs, ks, paired=paired, max_sites=max_sites, **cfg)
+    mp.load_reads(reads)
+    mp.step()
+    out = mp.fetch()
+    st = mp.stats()
+    oi = O.OracleIndex([ref], k=k)
+    params = O.map_default_params(**{k_: v for k_, v in cfg.items() if k_ in ("tipSearchDist", "trimList", "doRescue", "averagePairDist")})
+    if paired:
+        oi.s.p.quitAfterTwoPerfects = 0
+        r = reads.reshape(-1, L)
+        orc = O.map_batch(oi, r[0::2].copy(), r[1::2].copy(), L, offs, ks, params=params, cap=cap)
+    else:
+        orc = O.map_batch(oi, reads, None, L, offs, ks, params=params, cap=cap)
+    mp.close()
+    di.close()
+    return out, orc, st, n
+
+
+def test_single_ended_matches_oracle():
+    L, k = 150, 12
+    ref = W.make_reference(300000, seed=5, pad=2000, repeat_frac=0.15)
+    reads, _, _ = W.make_reads_and_jobs(ref, 3000, read_len=L, seed=9, pad=2000, long_del_frac=0.3, hard_frac=0.05)
+    out, orc, st, n = _run(ref, reads, L, k, paired=False)
+    assert st["reads_overflowed"] == 0
+    bad = compare(out, orc, n, paired=False)
+    assert not bad, "\n".join(bad[:20])
+    assert st["fills"] > 0.1 * n and st["gapped_fills"] > 0        # the workload reaches both fill logs
+    assert st["rounds"] >= 2                                         # and some reads need more than one fill
+
+
+def test_paired_matches_oracle_with_rescue():
+    L, k = 150, 12
+    ref = W.make_reference(300000, seed=6, pad=2000, repeat_frac=0.15)
+    reads, truth = W.make_pairs(ref, 2000, read_len=L, seed=4, pad=2000, hard_frac=0.08)
+    out, orc, st, n = _run(ref, reads, L, k, paired=True)
+    assert st["reads_overflowed"] == 0
+    bad = compare(out, orc, n, paired=True)
+    assert not bad, "\n".join(bad[:20])
+    assert st["rescue_scans"] > 20 and st["rescue_fills"] > 5       # rescue really ran
+    resc = sum(int(out["sites"][r, : max(0, out["nsites"][r])]["rescued"].sum()) for r in range(n))
+    assert resc > 5
+    # planted pairs come back where they were drawn from
+    top = out["sites"][:, 0]
+    ok1 = (out["nsites"][0::2] > 0) & (np.abs(top["start"][0::2] - truth["start1"]) <= 40) & (top["strand"][0::2] == truth["strand1"])
+    assert ok1.mean() > 0.97
+
+
+def test_paired_without_tip_search_and_trimming():
+    L, k = 100, 11
+    ref = W.make_reference(120000, seed=8, pad=1000, repeat_frac=0.3)
+    reads, _ = W.make_pairs(ref, 800, read_len=L, seed=5, pad=1000, hard_frac=0.1)
+    out, orc, st, n = _run(ref, reads, L, k, paired=True, tipSearchDist=0, trimList=0)
+    assert st["reads_overflowed"] == 0
+    bad = compare(out, orc, n, paired=True)
+    assert not bad, "\n".join(bad[:20])
+
+
+def test_overflow_is_reported_not_dropped():
+    """A read with more candidate sites than max_sites is flagged (nsites = -1, counted), never passed off as unmapped."""
+    L, k = 150, 12
+    ref = W.make_reference(200000, seed=11, pad=2000, repeat_frac=0.6, families=3)
+    reads, _, _ = W.make_reads_and_jobs(ref, 1500, read_len=L, seed=2, pad=2000)
+    out, orc, st, n = _run(ref, reads, L, k, paired=False, max_sites=4, cap=256)
+    over = out["nsites"] < 0
+    assert over.sum() == st["reads_overflowed"] and over.sum() > 0
+    # every read the device did map is identical to the oracle; the oracle finds sites for the flagged ones
+    good = [r for r in range(n) if not over[r]]
+    bad = compare(out, orc, n, paired=False, reads_range=good)
+    assert not bad, "\n".join(bad[:20])
+    assert all(orc["nsites1"][r] != 0 for r in np.nonzero(over)[0])
