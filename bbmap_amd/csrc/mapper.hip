@@ -84,6 +84,7 @@ struct Dev {
     bbresc_job *rjobs; RescInfo *rinfo; const bbresc_result *rres; PairResc *pres; long long rescCap;
     Site *rsite;                // per rescue search: the SiteScore under construction
     int pass;                   // rescue pass: 0 = mate 1 anchors, 1 = mate 2 anchors
+    int plainColumns;           // widest window the first DP context takes
 };
 
 __device__ inline int imin(int a, int b) { return a < b ? a : b; }
@@ -574,7 +575,9 @@ __device__ inline bbmsa_job make_job(const Dev &D, const bbidx_read &rr, const S
 __device__ int emit_fill(const Dev &D, long long r, const bbidx_read &rr, const Site &ss, int site, int pad, int minscore, int kind, int seq) {
     bbmap_jobinfo info; info.read = (int)r; info.seq = seq; info.kind = kind; info.site = site;
     const bbmsa_job j = make_job(D, rr, ss, pad, minscore);
-    if (ss.ngaps) {
+    // the wide list (second DP context: BBMap's 3000 columns) takes the sites with a gap array and the windows wider than the
+    // first context's column limit; a job without gaps is an ordinary job there
+    if (ss.ngaps || (imin(j.ref_len - 1, j.refEndLoc) - imax(0, j.refStartLoc) + 1) > D.plainColumns) {
         const unsigned k = atomicAdd(&D.counters[1], 1u);
         if ((long long)k < D.gjobCap) {
             D.gjobs[k] = j; D.ginfo[k] = info;
@@ -863,7 +866,7 @@ struct bbmap_ctx {
     int *d_chromMin;
     long long *d_chromOff;
     long long jobCap, gjobCap, rescCap;
-    int matchStride, gmatchStride, maxRows;
+    int matchStride, gmatchStride, maxRows, plainColumns;
     unsigned *h_counters;           // pinned
     hipEvent_t ev[10];
     bbmap_stats stats;
@@ -951,13 +954,17 @@ extern "C" int bbmap_create(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx
     const int maxRows = ((cfg->max_read_len + 31) / 32) * 32;
     c->maxRows = maxRows;
     bbmsa_config mc; memset(&mc, 0, sizeof mc);
-    mc.device = cfg->device; mc.maxRows = maxRows; mc.maxColumns = cfg->msaMaxColumns;
-    mc.reserved[1] = cfg->fastCols > 0 ? cfg->fastCols : 256;
-    if (mc.reserved[1] > mc.maxColumns) mc.reserved[1] = mc.maxColumns;
+    // two DP contexts.  The first takes the ordinary windows (read length + a few dozen columns): its LDS tables and column
+    // buffers are sized for `fastCols` columns, which is what lets four blocks share a CU.  The second has the reference's own
+    // 3000 columns (BBMapThread.java:27-28) and takes what does not fit the first: gapped references and wide windows.
+    mc.device = cfg->device; mc.maxRows = maxRows;
+    mc.maxColumns = cfg->fastCols > 0 ? cfg->fastCols : 256;
+    if (mc.maxColumns > cfg->msaMaxColumns) mc.maxColumns = cfg->msaMaxColumns;
+    c->plainColumns = mc.maxColumns;
     if ((rc = bbmsa_create(&mc, &c->msa)) != BBMAP_OK) return bail(rc);
     bbmsa_config gc = mc;
-    gc.maxColumns = cfg->msaMaxColumns > 3000 ? cfg->msaMaxColumns : 3000;
-    gc.reserved[0] = 64; gc.reserved[1] = 640;
+    gc.maxColumns = cfg->msaMaxColumns;
+    gc.reserved[0] = 64; gc.reserved[1] = 640 < gc.maxColumns ? 640 : gc.maxColumns;
     if ((rc = bbmsa_create(&gc, &c->msaGapped)) != BBMAP_OK) return bail(rc);
     const long long n = cfg->max_reads;
     const int cap = cfg->max_sites;
@@ -965,7 +972,7 @@ extern "C" int bbmap_create(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx
     c->jobCap = n * jpr + 1024;
     c->gjobCap = n / 8 + 4096;
     c->rescCap = n * 2 + 1024;
-    c->matchStride = ((maxRows + cfg->msaMaxColumns + 15) / 16) * 16;
+    c->matchStride = ((maxRows + c->plainColumns + 15) / 16) * 16;
     // a gapped match string expands every gap symbol to 128 'D's (traceback, MultiStateAligner11tsJNI.java:481-493)
     c->gmatchStride = ((maxRows + gc.maxColumns + 2 + 128 * 8 + 15) / 16) * 16;
     // the plain log rarely needs more than rows + columns of a NARROW window: cap its slot at what first-pass windows need, and
@@ -1044,7 +1051,7 @@ extern "C" int bbmap_map_batch_device(bbmap_ctx *c, void *stream_, int64_t n_rea
     D.chromArr = c->d_chromArr; D.chromArrLen = c->d_chromArrLen; D.refsBase = c->refsBase;
     D.psites = c->d_psites; D.pnsites = c->d_pnsites; D.maxSites = c->cfg.max_sites;
     D.ms = c->d_ms; D.mcount = c->d_mcount; D.cap = c->cfg.max_sites; D.nearArr = c->d_near; D.slow = c->d_slow;
-    D.counters = c->d_counters;
+    D.counters = c->d_counters; D.plainColumns = c->plainColumns;
     D.jobs = c->d_jobs; D.jinfo = c->d_jinfo; D.results = c->d_results; D.jobCap = c->jobCap;
     D.gjobs = c->d_gjobs; D.ggaps = c->d_ggaps; D.ginfo = c->d_ginfo; D.gresults = c->d_gresults; D.gjobCap = c->gjobCap;
     D.rjobs = c->d_rjobs; D.rinfo = c->d_rinfo; D.rres = c->d_rres; D.pres = c->d_pres; D.rescCap = c->rescCap; D.rsite = c->d_rsite;

@@ -444,8 +444,9 @@ typedef struct bbmap_config {
     int32_t doRescue;              /* 1 */
     int32_t alignColumns;          /* BBIndex.ALIGN_COLUMNS, 3000 */
     int32_t clearzone3;            /* PENALIZE_AMBIG ? 800 : 0 */
-    int32_t msaMaxColumns;         /* columns of the MSA instance (3000 in the reference) */
-    int32_t fastCols;              /* first-pass column buffer of the DP kernel (0 = 256) */
+    int32_t msaMaxColumns;         /* columns of the MSA instance (3000 in the reference): limit of the second DP context */
+    int32_t fastCols;              /* column limit of the first DP context, which takes the ordinary windows (0 = 256); wider
+                                    * windows and gapped references go to the second context (the "gapped" log) */
     int32_t jobsPerRead;           /* capacity of the job log = jobsPerRead * max_reads (0 = 3) */
     int32_t reserved[4];
 } bbmap_config;

@@ -179,6 +179,33 @@ void orc_index_free(orc_index *ix) {
     free(ix);
 }
 
+/* An index whose arrays the caller already holds (e.g. exported from a device build that the tests have shown equal to
+ * orc_index_build array by array): nothing is copied, orc_index_free_view frees only the shell. */
+orc_index *orc_index_from_arrays(const orc_index_params *p, int nblocks, int32_t **starts, int32_t **sites, const int64_t *numSites,
+                                 int32_t *counts, const int32_t *lengthHistogram, int nchroms, const uint8_t **chromArr,
+                                 const int32_t *chromArrLen) {
+    orc_index *ix = (orc_index *)calloc(1, sizeof(orc_index));
+    if (!ix) return NULL;
+    ix->p = *p; ix->nblocks = nblocks; ix->nchroms = nchroms;
+    ix->starts = (int32_t **)calloc((size_t)nblocks, sizeof(int32_t *));
+    ix->sites = (int32_t **)calloc((size_t)nblocks, sizeof(int32_t *));
+    ix->numSites = (int64_t *)calloc((size_t)nblocks, sizeof(int64_t));
+    for (int b = 0; b < nblocks; b++) { ix->starts[b] = starts[b]; ix->sites[b] = sites[b]; ix->numSites[b] = numSites[b]; }
+    ix->counts = counts;
+    memcpy(ix->lengthHistogram, lengthHistogram, sizeof ix->lengthHistogram);
+    ix->chromArr = (const uint8_t **)calloc((size_t)nchroms + 1, sizeof(uint8_t *));
+    ix->chromArrLen = (int32_t *)calloc((size_t)nchroms + 1, sizeof(int32_t));
+    ix->chromLengths = (int32_t *)calloc((size_t)nchroms + 1, sizeof(int32_t));
+    for (int c = 1; c <= nchroms; c++) { ix->chromArr[c] = chromArr[c]; ix->chromArrLen[c] = chromArrLen[c]; ix->chromLengths[c] = chromArrLen[c]; }
+    return ix;
+}
+void orc_index_free_view(orc_index *ix) {
+    if (!ix) return;
+    free(ix->starts); free(ix->sites); free(ix->numSites);
+    free((void *)ix->chromArr); free(ix->chromArrLen); free(ix->chromLengths);
+    free(ix);
+}
+
 /* ------------------------------------------------------------------------------------ offsets */
 int orc_make_offsets(int readlen, int blocksize, float density, int minKeysDesired, int32_t *out, int cap) {
     if (readlen < blocksize) return 0;

@@ -52,6 +52,11 @@ typedef struct orc_index {
 orc_index *orc_index_build(int k, int chromBits, int nchroms, const uint8_t **chromArr, const int32_t *chromArrLen,
                            float fractionToExclude);
 void orc_index_free(orc_index *ix);
+/* a view over arrays the caller holds (nothing copied); free with orc_index_free_view */
+orc_index *orc_index_from_arrays(const orc_index_params *p, int nblocks, int32_t **starts, int32_t **sites, const int64_t *numSites,
+                                 int32_t *counts, const int32_t *lengthHistogram, int nchroms, const uint8_t **chromArr,
+                                 const int32_t *chromArrLen);
+void orc_index_free_view(orc_index *ix);
 
 typedef struct orc_site {
     int32_t chrom, strand, start, stop, hits, score, perfect, semiperfect;

@@ -323,6 +323,50 @@ class OracleIndex:
         return (res, st.tolist()) if want_stats else res
 
 
+class OracleIndexView(OracleIndex):
+    """The oracle's probe over index arrays that already exist (a device-built index exported to the host; the GPU tests show
+    that build equal to the oracle's own, array by array).  Keeps bench.py's CPU leg and parity sample affordable on a
+    3 Gbp reference, where the oracle's single-threaded index build would take longer than the whole benchmark."""
+
+    def __init__(self, chroms, k, chromBits, params, blocks):
+        """blocks: list of (starts, sites, counts, lengthHistogram) per block (counts / histogram taken from block 0)."""
+        self.L = lib()
+        self.chroms = [np.ascontiguousarray(c, np.uint8) for c in chroms]
+        self.k, self.chromBits = k, chromBits
+        n, nb = len(self.chroms), len(blocks)
+        self._blocks = [(np.ascontiguousarray(b[0], np.int32), np.ascontiguousarray(b[1], np.int32)) for b in blocks]
+        self._counts = np.ascontiguousarray(blocks[0][2], np.int32)
+        self._hist = np.ascontiguousarray(blocks[0][3], np.int32)
+        p = IndexParams()
+        for name, _ in IndexParams._fields_:
+            if name in params:
+                setattr(p, name, int(params[name]))
+        starts = (c_i32p * nb)(*[b[0].ctypes.data_as(c_i32p) for b in self._blocks])
+        sites = (c_i32p * nb)(*[b[1].ctypes.data_as(c_i32p) for b in self._blocks])
+        num = (C.c_int64 * nb)(*[len(b[1]) for b in self._blocks])
+        arr = (c_u8p * (n + 1))()
+        lens = (C.c_int32 * (n + 1))()
+        for i, c in enumerate(self.chroms):
+            arr[i + 1] = c.ctypes.data_as(c_u8p)
+            lens[i + 1] = len(c)
+        self.L.orc_index_from_arrays.restype = C.c_void_p
+        self.L.orc_index_from_arrays.argtypes = [C.POINTER(IndexParams), C.c_int, C.POINTER(c_i32p), C.POINTER(c_i32p), C.POINTER(C.c_int64),
+                                                 c_i32p, c_i32p, C.c_int, C.POINTER(c_u8p), c_i32p]
+        self.h = self.L.orc_index_from_arrays(C.byref(p), nb, starts, sites, num, self._counts.ctypes.data_as(c_i32p),
+                                              self._hist.ctypes.data_as(c_i32p), n, arr, lens)
+        self.s = IndexStruct.from_address(self.h)
+        self._keep = (starts, sites, num, arr, lens, p)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_index_free_view.argtypes = [C.c_void_p]
+                self.L.orc_index_free_view(C.c_void_p(self.h))
+                self.h = None
+        except Exception:
+            pass
+
+
 def make_offsets(readlen, k, density=1.9, min_keys=2):
     L = lib()
     out = np.zeros(256, np.int32)
