@@ -78,13 +78,14 @@ struct Dev {
     SlowState *slow;
     const int *activeIn; int *activeOut; int nActiveIn;
     unsigned *counters;         // [0] plain fills, [1] gapped fills, [2] next active count, [3] overflowed reads, [4] rescue searches,
-                                // [5] reads without site, [6] refills, [7] rescue fills
+                                // [5] reads without site, [6] refills, [7] rescue fills, [8] fills ahead of time that were dropped
     bbmsa_job *jobs; bbmap_jobinfo *jinfo; const bbmsa_result *results; long long jobCap;
     bbmsa_job *gjobs; bbmsa_gaps *ggaps; bbmap_jobinfo *ginfo; const bbmsa_result *gresults; long long gjobCap;
     bbresc_job *rjobs; RescInfo *rinfo; const bbresc_result *rres; PairResc *pres; long long rescCap;
     Site *rsite;                // per rescue search: the SiteScore under construction
     int pass;                   // rescue pass: 0 = mate 1 anchors, 1 = mate 2 anchors
     int plainColumns;           // widest window the first DP context takes
+    int fillAhead;              // scoreSlow rounds: fill the sites behind the one in flight ahead of time
 };
 
 __device__ inline int imin(int a, int b) { return a < b ? a : b; }
@@ -600,6 +601,7 @@ __device__ void finish_site(const Dev &D, SlowState &st, Site &ss, int job, cons
         const bbmsa_result &res = fill_result(D, job);
         set_slow_score(ss, res.score[0]); set_limits(ss, res.score[1], res.score[2]); ss.match_job = job;
     }
+    ss.reserved[0] = ss.reserved[1] = 0;
     ss.score = ss.slowScore;
     st.minMsaLimit = imax(st.minMsaLimit, ss.slowScore - D.S.clearzone3);
     ss.perfect = (ss.slowScore == maxSw);
@@ -607,8 +609,33 @@ __device__ void finish_site(const Dev &D, SlowState &st, Site &ss, int job, cons
     else if (!ss.semiperfect) set_perfect(ss, bases, len, D.chromArr[ss.chrom], D.chromArrLen[ss.chrom]);
 }
 
+// scoreSlow's per-site opening (BBMapThread.java:278-303): a site whose span differs from the read length loses its ungapped
+// score and flags; an over-long expected window is cut.  Depends on nothing but the site itself, so it gives the same answer
+// whether it is evaluated ahead of time (on a copy) or when the loop reaches the site.
+__device__ inline int prepare_site(const Settings &S, Site &ss, int len, int &expectedLen, bool &needsFill) {
+    if (ss.stop - ss.start != len - 1) { set_slow_score(ss, 0); ss.semiperfect = 0; ss.perfect = 0; }
+    const int sw = ss.slowScore;
+    needsFill = sw < max_imperfect(len) && !ss.semiperfect;
+    expectedLen = 0;
+    if (needsFill) {
+        expectedLen = calc_gref_len(ss);
+        if (expectedLen >= S.expLimit) set_stop(ss, ss.start + imin(len + 40, S.expLimit));
+    }
+    return sw;
+}
+__device__ inline bbmap_jobinfo &job_info(const Dev &D, int job) { return (job & GAPPED_BIT) ? D.ginfo[job & ~GAPPED_BIT] : D.jinfo[job]; }
+
 // One round: every active read consumes the result of its fill in flight and moves on to its next fill (or finishes).
 // activeIn == nullptr: every read of the batch (round 1).
+//
+// Fills ahead of time.  Strictly one fill per read and round would make a read with m candidate sites take m rounds, and a
+// round costs the latency of a whole DP launch sequence however few jobs it holds.  A site's fill depends on the sites before
+// it through ONE number, the running minMsaLimit = max(initial, best slowScore so far - CLEARZONE3) (:376), and once a read's
+// first site is done that number rarely moves (the list is sorted by score, best first).  So while site idx >= 1 is in
+// flight, the sites behind it are filled too, with the limit as it stands (Site.reserved[0] = 1 + job, reserved[1] = the
+// minScore used).  When the loop reaches such a site it recomputes the minScore the reference would use: equal -> the finished
+// fill IS the reference's fill and is adopted (numbered in the read's sequence at that moment); different -> it is dropped
+// (its log entry keeps seq = -1) and the site is filled again.  Results are those of the sequential loop in every case.
 __global__ __launch_bounds__(128) void slow_round_kernel(const Dev D) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long count = D.activeIn ? D.nActiveIn : D.nreads;
@@ -619,7 +646,7 @@ __global__ __launch_bounds__(128) void slow_round_kernel(const Dev D) {
         SlowState st = D.slow[r];
         if (st.phase != 3) {
             const bbidx_read rr = D.reads[r];
-            const int len = rr.len, maxSw = max_quality(len), maxImp = max_imperfect(len);
+            const int len = rr.len, maxSw = max_quality(len);
             const int n = D.mcount[r];
             Site *s = D.ms + r * D.cap;
             while (st.idx < n) {
@@ -648,20 +675,41 @@ __global__ __launch_bounds__(128) void slow_round_kernel(const Dev D) {
                     continue;
                 }
                 // phase 0: look at site idx (:267-309)
-                if (ss.stop - ss.start != len - 1) { set_slow_score(ss, 0); ss.semiperfect = 0; ss.perfect = 0; }
-                const int sw = ss.slowScore;
-                if (sw < maxImp && !ss.semiperfect) {
-                    st.expectedLen = calc_gref_len(ss);
-                    if (st.expectedLen >= D.S.expLimit) set_stop(ss, ss.start + imin(len + 40, D.S.expLimit));
+                bool needsFill;
+                const int early = ss.reserved[0], earlyMin = ss.reserved[1];
+                const int sw = prepare_site(D.S, ss, len, st.expectedLen, needsFill);
+                if (needsFill) {
                     st.minscore = imax(sw, st.minMsaLimit);
+                    if (early && earlyMin == st.minscore) {                        // filled ahead of time with the very same bound: adopt
+                        st.pending = early - 1;
+                        bbmap_jobinfo &ji = job_info(D, st.pending);
+                        ji.seq = st.seq++; ji.site = st.idx;
+                        st.phase = 1; s[st.idx] = ss;
+                        continue;                                                  // its result is there already
+                    }
+                    if (early) atomicAdd(&D.counters[8], 1u);                      // a fill ahead of time that the sequence does not contain
                     st.pending = emit_fill(D, r, rr, ss, st.idx, D.S.slowAlignPadding, st.minscore, 0, st.seq++);
                     st.phase = 1; s[st.idx] = ss; stillActive = true;
                     break;
                 }
+                if (early) atomicAdd(&D.counters[8], 1u);
                 finish_site(D, st, ss, -1, bases, len, maxSw);
                 s[st.idx] = ss; st.idx++;
             }
             if (!stillActive) st.phase = 3;
+            else if (st.idx >= 1 && D.fillAhead) {
+                for (int j = st.idx + 1; j < n; j++) {
+                    Site tmp = s[j];
+                    bool needsFill; int expectedLen;
+                    const int sw = prepare_site(D.S, tmp, len, expectedLen, needsFill);
+                    if (!needsFill) continue;
+                    const int minscore = imax(sw, st.minMsaLimit);
+                    if (tmp.reserved[0] && tmp.reserved[1] == minscore) continue;  // already in the log with this bound
+                    if (tmp.reserved[0]) atomicAdd(&D.counters[8], 1u);
+                    const int job = emit_fill(D, r, rr, tmp, j, D.S.slowAlignPadding, minscore, 0, -1);
+                    s[j].reserved[0] = job + 1; s[j].reserved[1] = minscore;
+                }
+            }
             D.slow[r] = st;
         }
     }
@@ -1051,7 +1099,7 @@ extern "C" int bbmap_map_batch_device(bbmap_ctx *c, void *stream_, int64_t n_rea
     D.chromArr = c->d_chromArr; D.chromArrLen = c->d_chromArrLen; D.refsBase = c->refsBase;
     D.psites = c->d_psites; D.pnsites = c->d_pnsites; D.maxSites = c->cfg.max_sites;
     D.ms = c->d_ms; D.mcount = c->d_mcount; D.cap = c->cfg.max_sites; D.nearArr = c->d_near; D.slow = c->d_slow;
-    D.counters = c->d_counters; D.plainColumns = c->plainColumns;
+    D.counters = c->d_counters; D.plainColumns = c->plainColumns; D.fillAhead = c->cfg.reserved[0] ? 0 : 1;
     D.jobs = c->d_jobs; D.jinfo = c->d_jinfo; D.results = c->d_results; D.jobCap = c->jobCap;
     D.gjobs = c->d_gjobs; D.ggaps = c->d_ggaps; D.ginfo = c->d_ginfo; D.gresults = c->d_gresults; D.gjobCap = c->gjobCap;
     D.rjobs = c->d_rjobs; D.rinfo = c->d_rinfo; D.rres = c->d_rres; D.pres = c->d_pres; D.rescCap = c->rescCap; D.rsite = c->d_rsite;
@@ -1130,7 +1178,7 @@ extern "C" int bbmap_map_batch_device(bbmap_ctx *c, void *stream_, int64_t n_rea
     c->nJobs = c->h_counters[0]; c->nGapped = c->h_counters[1];
     bbmap_stats &st = c->stats;
     st.reads_overflowed = c->h_counters[3]; st.reads_without_site = c->h_counters[5];
-    st.fills = c->nJobs; st.gapped_fills = c->nGapped; st.refills = c->h_counters[6]; st.rescue_fills = c->h_counters[7];
+    st.fills = c->nJobs; st.gapped_fills = c->nGapped; st.refills = c->h_counters[6]; st.rescue_fills = c->h_counters[7]; st.fills_dropped = c->h_counters[8];
     (void)hipEventElapsedTime(&st.ms_probe, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&st.ms_begin, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&st.ms_score, c->ev[2], c->ev[3]);

@@ -36,7 +36,7 @@ class bbmap_output(C.Structure):
 
 class bbmap_stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("reads", "reads_overflowed", "reads_without_site", "fills", "gapped_fills", "refills",
-                                         "rescue_scans", "rescue_fills", "rounds", "dp_cells")] + \
+                                         "rescue_scans", "rescue_fills", "rounds", "fills_dropped")] + \
                [(n, C.c_float) for n in ("ms_probe", "ms_begin", "ms_score", "ms_slow", "ms_finish", "ms_rescue", "ms_total",
                                          "ms_dp_narrow", "ms_dp_wave", "ms_dp_generic", "ms_dp_gapped", "ms_quick_rescue")] + \
                [("probe_stats", C.c_int64 * 5)]

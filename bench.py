@@ -336,7 +336,7 @@ def main():
                                        " -> rescue (quickRescue scan + slowRescue DP) for unpaired mates" if paired else ""),
                        "reads_per_gpu_per_step": n, "read_len": L, "paired": paired, "keys_per_read": nkeys, "max_sites": args.max_sites,
                        "fills_per_step": st["fills"] + st["gapped_fills"], "fills_second_context": st["gapped_fills"],
-                       "refills_per_step": st["refills"], "scoreslow_rounds": st["rounds"],
+                       "refills_per_step": st["refills"], "scoreslow_rounds": st["rounds"], "fills_ahead_dropped_per_step": st["fills_dropped"],
                        "rescue_scans_per_step": st["rescue_scans"], "rescue_fills_per_step": st["rescue_fills"],
                        "reads_overflowed_max_sites": st["reads_overflowed"], "reads_without_site": st["reads_without_site"],
                        "mapped_fraction": mapped / n, "dp_cells_per_step": cells,

@@ -419,7 +419,8 @@ typedef struct bbmap_msite {       /* stream.SiteScore, current/stream/SiteScore
 
 typedef struct bbmap_jobinfo {     /* one entry per fill, parallel to the job / result arrays */
     int32_t read;                  /* read the fill belongs to */
-    int32_t seq;                   /* its position in that read's sequence of fillAndScoreLimited calls */
+    int32_t seq;                   /* its position in that read's sequence of fillAndScoreLimited calls; -1 = a fill issued ahead
+                                    * of time that the sequence turned out not to contain (ignore it) */
     int32_t kind;                  /* 0 scoreSlow fill, 1 scoreSlow wider refill, 2 slowRescue */
     int32_t site;                  /* list position of the site when the fill was issued */
 } bbmap_jobinfo;                   /* 16 bytes */
@@ -448,7 +449,7 @@ typedef struct bbmap_config {
     int32_t fastCols;              /* column limit of the first DP context, which takes the ordinary windows (0 = 256); wider
                                     * windows and gapped references go to the second context (the "gapped" log) */
     int32_t jobsPerRead;           /* capacity of the job log = jobsPerRead * max_reads (0 = 3) */
-    int32_t reserved[4];
+    int32_t reserved[4];           /* [0] != 0: strictly one fill per read and round (no fills ahead of time; for tests) */
 } bbmap_config;
 
 typedef struct bbmap_output {      /* device pointers, valid until the next bbmap_map_batch_device / bbmap_destroy */
@@ -465,7 +466,8 @@ typedef struct bbmap_output {      /* device pointers, valid until the next bbma
 
 typedef struct bbmap_stats {
     int64_t reads, reads_overflowed, reads_without_site, fills, gapped_fills, refills, rescue_scans, rescue_fills, rounds;
-    int64_t dp_cells;              /* visited cells over all fills (result.iterations) -- filled by bbmap_last_stats on request */
+    int64_t fills_dropped;         /* fills issued ahead of time that the reference's sequence turned out not to contain (dropped;
+                                    * their log entries keep seq = -1) */
     float ms_probe, ms_begin, ms_score, ms_slow, ms_finish, ms_rescue, ms_total;
     float ms_dp_narrow, ms_dp_wave, ms_dp_generic, ms_dp_gapped, ms_quick_rescue;
     int64_t probe_stats[5];        /* bbidx_last_stats of the probe launch */

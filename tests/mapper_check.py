@@ -13,6 +13,8 @@ def gpu_fills(out):
     for jobs, res, info, match, bit in ((out["jobs"], out["results"], out["jobinfo"], out.get("match"), 0),
                                         (out["gjobs"], out["gresults"], out["gjobinfo"], out.get("gmatch"), GAPPED_BIT)):
         for i in range(len(jobs)):
+            if int(info["seq"][i]) < 0:                 # issued ahead of time, not part of the reference's sequence
+                continue
             key = (int(info["read"][i]), int(info["seq"][i]))
             assert key not in fills, "two fills with the same (read, seq) %r" % (key,)
             n = int(res["score_len"][i])

@@ -2,6 +2,8 @@
 ungapped scores, tip deletions, scoreSlow rounds with the exact minScore sequence and wider refills, rescue) against the CPU
 restatement oracle/mapper_oracle.c -- site lists field by field, every fill's window / minScore / score vector / visited-cell
 count / traceback string, and which fill each site took its limits from."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -9,7 +11,7 @@ from bbmap_amd import workload as W
 from bbmap_amd.index import DeviceIndex
 from bbmap_amd.mapper import Mapper
 from oracle import oracle as O
-from tests.mapper_check import compare
+from tests.mapper_check import compare, gpu_fills
 
 pytestmark = pytest.mark.gpu
 
@@ -89,3 +91,33 @@ def test_overflow_is_reported_not_dropped():
     bad = compare(out, orc, n, paired=False, reads_range=good)
     assert not bad, "\n".join(bad[:20])
     assert all(orc["nsites1"][r] != 0 for r in np.nonzero(over)[0])
+
+
+def test_fills_ahead_of_time_do_not_change_anything():
+    """The same batch with and without fills ahead of time (bbmap_config.reserved[0]): identical sites and identical fill
+    sequences; the strict mode needs one round per candidate site, the default a handful."""
+    L, k = 150, 12
+    ref = W.make_reference(200000, seed=12, pad=2000, repeat_frac=0.5, families=12)
+    reads, _, _ = W.make_reads_and_jobs(ref, 1500, read_len=L, seed=3, pad=2000, hard_frac=0.3)
+    res = {}
+    for strict in (0, 1):
+        di = DeviceIndex.build([ref], k=k)
+        offs = O.make_offsets(L, k, 1.9)
+        ks = [100 * k] * len(offs)
+        mp = Mapper(di, 1500, L, offs, ks, paired=False, max_sites=48, reserved=(C.c_int32 * 4)(strict, 0, 0, 0))
+        mp.load_reads(reads)
+        mp.step()
+        res[strict] = (mp.fetch(), mp.stats())
+        mp.close()
+        di.close()
+    (a, sa), (b, sb) = res[0], res[1]
+    assert sb["fills_dropped"] == 0 and sa["rounds"] < sb["rounds"] and sb["rounds"] >= 6
+    assert (a["nsites"] == b["nsites"]).all()
+    for f in a["sites"].dtype.names:
+        if f not in ("match_job", "reserved"):
+            assert (a["sites"][f] == b["sites"][f]).all(), f
+    fa, fb = gpu_fills(a), gpu_fills(b)
+    assert fa.keys() == fb.keys()
+    for key in fa:
+        for f in ("kind", "refStartLoc", "refEndLoc", "minScore", "score", "iterations", "match"):
+            assert fa[key][f] == fb[key][f], (key, f)
