@@ -19,7 +19,7 @@ EXPORTS = [
     "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch", "bbidx_find_batch_device_rc", "bbidx_last_stats", "bbidx_set_kernel", "bbidx_set_max_read_len", "bbidx_build", "bbidx_get_params", "bbidx_export_block",
     "bbmap_default_config", "bbmap_create", "bbmap_destroy", "bbmap_map_batch_device", "bbmap_get_output", "bbmap_last_stats",
     "bbmap_copy_to_host", "bbidx_get_chrom_table",
-    "bbpipe_revcomp_device", "bbpipe_select_jobs_device", "bbpipe_quick_rescue_device", "bbpipe_match_no_indels_device",
+    "bbpipe_revcomp_device", "bbpipe_quick_rescue_device",
 ]
 
 
@@ -118,14 +118,6 @@ def load():
     L.bbband_align_batch.restype = C.c_int
     L.bbpipe_revcomp_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bbpipe_revcomp_device.restype = C.c_int
-    L.bbpipe_select_jobs_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
-                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
-                                            C.c_void_p, C.c_int32, C.c_void_p]
-    L.bbpipe_select_jobs_device.restype = C.c_int
-    L.bbpipe_match_no_indels_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
-                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
-    L.bbpipe_match_no_indels_device.restype = C.c_int
     L.bbpipe_quick_rescue_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.bbpipe_quick_rescue_device.restype = C.c_int

@@ -330,42 +330,11 @@ int bbidx_set_kernel(bbidx_ctx *ctx, int32_t kind);
 int bbidx_set_max_read_len(bbidx_ctx *ctx, int32_t max_len);
 
 /* =====================================================================================
- * Pipeline glue (device-resident): which probe sites need a slow alignment.
- *   Mirrors the host logic between the two hot kernels: AbstractMapThread.scoreNoIndels
- *   (current/align2/AbstractMapThread.java:762-856) and the site filter at the top of
- *   BBMapThread.scoreSlow (current/align2/BBMapThread.java:252-309); see bbmap_amd/csrc/pipeline.hip
- *   for what is and is not carried over.  All pointers are device pointers.
+ * Batch helpers (device-resident) used by the mapper below; also callable on their own.
  * ===================================================================================== */
 /* bases_out[read] = reverse complement of bases_in[read] (AminoAcid.reverseComplementBases) */
 int bbpipe_revcomp_device(void *stream, int64_t n_reads, const bbidx_read *reads,
                           const uint8_t *bases_in, uint8_t *bases_out);
-/* Scores every probe site without indels (MSA.scoreNoIndels), updates the site records in place, and appends one
- * bbmsa_job per site that still needs DP.  counters[4] (zeroed by the call): jobs written, reads finished without
- * DP, sites that carry a gap array, reads with no site.  `bases + minus_delta` must hold the
- * reverse-complemented reads at the same offsets.  no_indel_score (optional) receives the ungapped score of every
- * (read, site).  Sites with a gap array need a gapped reference: they are written to the second list
- * (gapped_jobs / gapped_gaps / gapped_src, for bbmsa_align_gapped_batch_device) when it is given, and only counted
- * when it is NULL; at most gapped_cap of them are written (counters[2] keeps counting, so an overflow shows).
- * extra_job_flags: BBMSA_NO_ITERATIONS or 0, OR-ed into the ordinary jobs' flags.  read_state (optional, one int per
- * read): -1 no site, (s << 2) | 1 finished without DP (s = first site with the highest ungapped score), 2 sent to DP.
- * ungapped_match / ungapped_stride / ungapped_len (optional): what bbpipe_match_no_indels_device would write, produced on the
- * way while the read and the reference bytes are in cache. */
-int bbpipe_select_jobs_device(void *stream, int64_t n_reads, const bbidx_read *reads, const uint8_t *bases,
-                              int64_t minus_delta, const int32_t *nsites, bbidx_site *sites, int32_t max_sites,
-                              const int64_t *chrom_off, const int32_t *chrom_len, const uint8_t *refs,
-                              int32_t pad, int32_t max_columns, float min_ratio,
-                              bbmsa_job *jobs, int32_t *job_src, uint32_t *counters, int32_t *no_indel_score,
-                              bbmsa_job *gapped_jobs, bbmsa_gaps *gapped_gaps, int32_t *gapped_src, int32_t gapped_cap,
-                              int32_t extra_job_flags, int32_t *read_state,
-                              uint8_t *ungapped_match, int32_t ungapped_stride, int32_t *ungapped_len);
-/* Match strings of the reads the filter finished without DP: MSA.scoreNoIndelsAndMakeMatchString(read, ref, refStart,
- * matchReturn) (current/align2/MultiStateAligner11tsJNI.java:1244-1318) at the best site of every read whose
- * read_state is (site << 2) | 1.  match_len[r] = read length, 0 (nothing to do for this read) or -1 (the site runs off its
- * chromosome: the reference returns -99999 and writes nothing). */
-int bbpipe_match_no_indels_device(void *stream, int64_t n_reads, const bbidx_read *reads, const uint8_t *bases,
-                                  int64_t minus_delta, const bbidx_site *sites, int32_t max_sites, const int32_t *read_state,
-                                  const int64_t *chrom_off, const int32_t *chrom_len, const uint8_t *refs,
-                                  uint8_t *match, int32_t match_stride, int32_t *match_len);
 
 /* Paired-read rescue scan: AbstractMapThread.quickRescue(bases, chrom, strand, loc, searchDist, searchRight, idealStart,
  * maxAllowedMismatches, POINTS_MATCH, POINTS_MATCH2) (current/align2/AbstractMapThread.java:2300-2391), batched.  `reads`
