@@ -11,7 +11,7 @@ timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fet
 timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/bench_pmc2.log 2>&1 || echo "write pass failed"
 for f in $(find $OUT/trace -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
 python3 scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1
-tail -1 $OUT/bench_trace.log > $OUT/bench_line.json
+grep "^{\"metric\"" $OUT/bench_trace.log > $OUT/bench_line.json
 find $OUT -name "*.csv" -size +2M -delete
 rm -rf $OUT/trace/*/*.db 2>/dev/null
 ls -la $OUT
