@@ -17,6 +17,7 @@ SEMANTICS_JNI_C, SEMANTICS_JAVA = 0, 1
 
 JOB_DTYPE = np.dtype([("query_off", "<i8"), ("ref_off", "<i8"), ("query_len", "<i4"), ("ref_len", "<i4"),
                       ("qstart", "<i4"), ("rstart", "<i4"), ("maxEdits", "<i4"), ("flags", "<i4")])
+PAIR_DTYPE = np.dtype([("query_off", "<i8"), ("ref_off", "<i8"), ("query_len", "<i4"), ("ref_len", "<i4")])
 RESULT_DTYPE = np.dtype([("edits", "<i4"), ("lastQueryLoc", "<i4"), ("lastRefLoc", "<i4"), ("lastRow", "<i4"),
                          ("lastEdits", "<i4"), ("lastOffset", "<i4"), ("status", "<i4"), ("reserved", "<i4")])
 
@@ -62,24 +63,37 @@ class BandedAligner:
         _lib.check(rc, "bbband_align_batch")
         return res
 
-    # BandedAligner.java:39-48, batched over pairs
+    # BandedAligner.java:24-55: the orchestration runs in the library (bbband_align_*_batch), batched over pairs
+    def _pairs(self, pairs):
+        blob = bytearray()
+        recs = np.zeros(len(pairs), PAIR_DTYPE)
+        for n, (q, r) in enumerate(pairs):
+            recs[n] = (len(blob), len(blob) + len(q), len(q), len(r))
+            blob += bytes(q) + bytes(r)
+        return recs, np.frombuffer(bytes(blob) or b"\0", np.uint8)
+
     def alignQuadruple(self, pairs, maxEdits, exact):
-        fw = self.align_batch([(FORWARD, q, r, 0, 0, maxEdits, exact) for q, r in pairs])
-        rv = self.align_batch([(REVERSE, q, r, len(q) - 1, len(r) - 1, maxEdits, exact) for q, r in pairs])
-        out = [0] * len(pairs)
-        todo, me2s = [], []
-        for k, (q, r) in enumerate(pairs):
-            a, b = int(fw[k]["edits"]), int(rv[k]["edits"])
-            me2 = min(maxEdits, max(a, b))
-            out[k] = max(a, b)
-            if me2 != 0:
-                todo.append(k)
-                me2s.append(me2)
-        if todo:
-            c = self.align_batch([(FORWARD_RC, pairs[k][0], pairs[k][1], len(pairs[k][0]) - 1, 0, m, exact)
-                                  for k, m in zip(todo, me2s)])
-            d = self.align_batch([(REVERSE_RC, pairs[k][0], pairs[k][1], 0, len(pairs[k][1]) - 1, m, exact)
-                                  for k, m in zip(todo, me2s)])
-            for n, k in enumerate(todo):
-                out[k] = min(out[k], max(int(c[n]["edits"]), int(d[n]["edits"])))
-        return out
+        recs, seqs = self._pairs(pairs)
+        out = np.zeros(len(pairs), np.int32)
+        self.L.bbband_align_quadruple_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+        _lib.check(self.L.bbband_align_quadruple_batch(self.h, len(pairs), recs.ctypes.data, seqs.ctypes.data, seqs.size, maxEdits,
+                                                       1 if exact else 0, out.ctypes.data), "bbband_align_quadruple_batch")
+        return out.tolist()
+
+    def alignQuadrupleProgressive(self, pairs, minEdits, maxEdits, exact):
+        recs, seqs = self._pairs(pairs)
+        out = np.zeros(len(pairs), np.int32)
+        self.L.bbband_align_quadruple_progressive_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                                                    C.c_int32, C.c_int32, C.c_void_p]
+        _lib.check(self.L.bbband_align_quadruple_progressive_batch(self.h, len(pairs), recs.ctypes.data, seqs.ctypes.data, seqs.size,
+                                                                   minEdits, maxEdits, 1 if exact else 0, out.ctypes.data),
+                   "bbband_align_quadruple_progressive_batch")
+        return out.tolist()
+
+    def alignDouble(self, pairs, maxEdits, exact):
+        recs, seqs = self._pairs(pairs)
+        out = np.zeros(len(pairs), np.int32)
+        self.L.bbband_align_double_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+        _lib.check(self.L.bbband_align_double_batch(self.h, len(pairs), recs.ctypes.data, seqs.ctypes.data, seqs.size, maxEdits,
+                                                    1 if exact else 0, out.ctypes.data), "bbband_align_double_batch")
+        return out.tolist()

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "bbmap_amd.h"
 
@@ -341,4 +342,158 @@ done:
     if (dr) (void)hipFree(dr);
     return rc;
 #undef BGO
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BandedAligner's orchestration (current/align2/BandedAligner.java:24-55), batched over pairs: alignQuadruple (forward +
+// reverse, then the two reverse-complement directions with the tightened maxEdits), alignQuadrupleProgressive (maxEdits grows
+// by 4x until a pair aligns below it) and alignDouble (forward, then forward-RC bounded by the forward result).  Every
+// directional alignment runs in banded_kernel; the host only builds job lists and takes minima / maxima.
+namespace {
+struct PairBatch {
+    bbband_ctx *c; int64_t n; const bbband_pair *pairs; bool exact;
+    uint8_t *d_seqs = nullptr; bbband_job *d_jobs = nullptr; bbband_result *d_res = nullptr;
+    std::vector<bbband_job> jobs; std::vector<bbband_result> res;
+    ~PairBatch() { if (d_seqs) (void)hipFree(d_seqs); if (d_jobs) (void)hipFree(d_jobs); if (d_res) (void)hipFree(d_res); }
+    int init(const uint8_t *seqs, int64_t seq_bytes) {
+        for (int64_t i = 0; i < n; i++) {
+            const bbband_pair &p = pairs[i];
+            if (p.query_len < 0 || p.ref_len < 0 || p.query_off < 0 || p.ref_off < 0 || p.query_off + p.query_len > seq_bytes || p.ref_off + p.ref_len > seq_bytes)
+                return bfail(BBMAP_E_ARG, "bbband pair batch: a sequence lies outside the seqs buffer");
+        }
+        BHIP(hipSetDevice(c->device));
+        BHIP(hipMalloc(&d_seqs, (size_t)(seq_bytes > 0 ? seq_bytes : 1)));
+        BHIP(hipMemcpy(d_seqs, seqs, (size_t)seq_bytes, hipMemcpyHostToDevice));
+        BHIP(hipMalloc(&d_jobs, (size_t)(2 * n) * sizeof(bbband_job)));
+        BHIP(hipMalloc(&d_res, (size_t)(2 * n) * sizeof(bbband_result)));
+        jobs.resize((size_t)(2 * n)); res.resize((size_t)(2 * n));
+        return BBMAP_OK;
+    }
+    // one launch over `m` jobs already written to jobs[0..m)
+    int run(int64_t m) {
+        if (m == 0) return BBMAP_OK;
+        BHIP(hipMemcpy(d_jobs, jobs.data(), (size_t)m * sizeof(bbband_job), hipMemcpyHostToDevice));
+        const int rc = bbband_align_batch_device(c, nullptr, m, d_jobs, d_seqs, d_res);
+        if (rc != BBMAP_OK) return rc;
+        BHIP(hipStreamSynchronize(nullptr));
+        BHIP(hipMemcpy(res.data(), d_res, (size_t)m * sizeof(bbband_result), hipMemcpyDeviceToHost));
+        return BBMAP_OK;
+    }
+    bbband_job job(int64_t i, int dir, int qstart, int rstart, int maxEdits) const {
+        const bbband_pair &p = pairs[i];
+        bbband_job j; j.query_off = p.query_off; j.ref_off = p.ref_off; j.query_len = p.query_len; j.ref_len = p.ref_len;
+        j.qstart = qstart; j.rstart = rstart; j.maxEdits = maxEdits; j.flags = dir | (exact ? BBBAND_EXACT : 0);
+        return j;
+    }
+    // alignQuadruple for the pairs in `idx` with their maxEdits in `me`; out[k] = result for idx[k]
+    int quadruple(const std::vector<int64_t> &idx, const std::vector<int> &me, std::vector<int> &out) {
+        const int64_t m = (int64_t)idx.size();
+        out.assign((size_t)m, 0);
+        for (int64_t k = 0; k < m; k++) {
+            const bbband_pair &p = pairs[idx[(size_t)k]];
+            jobs[(size_t)(2 * k)] = job(idx[(size_t)k], BBBAND_FORWARD, 0, 0, me[(size_t)k]);
+            jobs[(size_t)(2 * k + 1)] = job(idx[(size_t)k], BBBAND_REVERSE, p.query_len - 1, p.ref_len - 1, me[(size_t)k]);
+        }
+        int rc = run(2 * m);
+        if (rc != BBMAP_OK) return rc;
+        std::vector<int64_t> todo; std::vector<int> me2s;
+        for (int64_t k = 0; k < m; k++) {
+            const int a = res[(size_t)(2 * k)].edits, b = res[(size_t)(2 * k + 1)].edits;
+            const int mx = a > b ? a : b;
+            out[(size_t)k] = mx;
+            const int me2 = me[(size_t)k] < mx ? me[(size_t)k] : mx;
+            if (me2 == 0) out[(size_t)k] = 0; else { todo.push_back(k); me2s.push_back(me2); }
+        }
+        for (size_t t = 0; t < todo.size(); t++) {
+            const int64_t i = idx[(size_t)todo[t]];
+            const bbband_pair &p = pairs[i];
+            jobs[2 * t] = job(i, BBBAND_FORWARD_RC, p.query_len - 1, 0, me2s[t]);
+            jobs[2 * t + 1] = job(i, BBBAND_REVERSE_RC, 0, p.ref_len - 1, me2s[t]);
+        }
+        rc = run((int64_t)(2 * todo.size()));
+        if (rc != BBMAP_OK) return rc;
+        for (size_t t = 0; t < todo.size(); t++) {
+            const int cc = res[2 * t].edits, d = res[2 * t + 1].edits;
+            const int mcd = cc > d ? cc : d;
+            int &o = out[(size_t)todo[t]];
+            o = o < mcd ? o : mcd;
+        }
+        return BBMAP_OK;
+    }
+};
+}  // namespace
+
+extern "C" int bbband_align_quadruple_batch(bbband_ctx *c, int64_t n, const bbband_pair *pairs, const uint8_t *seqs, int64_t seq_bytes,
+                                            int32_t maxEdits, int32_t exact, int32_t *edits) {
+    if (!c || n < 0 || (n > 0 && (!pairs || !seqs || !edits)) || seq_bytes < 0) return bfail(BBMAP_E_ARG, "bbband_align_quadruple_batch: bad argument");
+    if (n == 0) return BBMAP_OK;
+    PairBatch B{c, n, pairs, exact != 0};
+    int rc = B.init(seqs, seq_bytes);
+    if (rc != BBMAP_OK) return rc;
+    std::vector<int64_t> idx((size_t)n); std::vector<int> me((size_t)n, maxEdits), out;
+    for (int64_t i = 0; i < n; i++) idx[(size_t)i] = i;
+    rc = B.quadruple(idx, me, out);
+    if (rc != BBMAP_OK) return rc;
+    for (int64_t i = 0; i < n; i++) edits[i] = out[(size_t)i];
+    return BBMAP_OK;
+}
+
+extern "C" int bbband_align_quadruple_progressive_batch(bbband_ctx *c, int64_t n, const bbband_pair *pairs, const uint8_t *seqs, int64_t seq_bytes,
+                                                        int32_t minEdits, int32_t maxEdits, int32_t exact, int32_t *edits) {
+    if (!c || n < 0 || (n > 0 && (!pairs || !seqs || !edits)) || seq_bytes < 0) return bfail(BBMAP_E_ARG, "bbband_align_quadruple_progressive_batch: bad argument");
+    if (n == 0) return BBMAP_OK;
+    PairBatch B{c, n, pairs, exact != 0};
+    int rc = B.init(seqs, seq_bytes);
+    if (rc != BBMAP_OK) return rc;
+    // BandedAligner.java:24-37, every pair with its own loop state (i, me); a round aligns the pairs that are still looping
+    std::vector<long long> iv((size_t)n); std::vector<long long> mev((size_t)n, -1); std::vector<int> maxE((size_t)n);
+    std::vector<char> done((size_t)n, 0);
+    for (int64_t p = 0; p < n; p++) {
+        const int longer = pairs[p].query_len > pairs[p].ref_len ? pairs[p].query_len : pairs[p].ref_len;
+        maxE[(size_t)p] = maxEdits < longer ? maxEdits : longer;
+        iv[(size_t)p] = minEdits < maxE[(size_t)p] ? minEdits : maxE[(size_t)p];
+        edits[p] = maxE[(size_t)p];
+    }
+    for (;;) {
+        std::vector<int64_t> idx; std::vector<int> me, out;
+        for (int64_t p = 0; p < n; p++) {
+            if (done[(size_t)p]) continue;
+            if (!(mev[(size_t)p] < maxE[(size_t)p])) { done[(size_t)p] = 1; continue; }         // the for-loop's condition me < maxEdits
+            long long m = iv[(size_t)p] < maxE[(size_t)p] ? iv[(size_t)p] : maxE[(size_t)p];
+            if (m * 2 > maxE[(size_t)p]) m = maxE[(size_t)p];
+            mev[(size_t)p] = m;
+            idx.push_back(p); me.push_back((int)m);
+        }
+        if (idx.empty()) break;
+        rc = B.quadruple(idx, me, out);
+        if (rc != BBMAP_OK) return rc;
+        for (size_t t = 0; t < idx.size(); t++) {
+            const int64_t p = idx[t];
+            if (out[t] < me[t]) { edits[p] = out[t]; done[(size_t)p] = 1; }
+            else {
+                if (iv[(size_t)p] == 0) { done[(size_t)p] = 1; continue; }        // i = i * 4 stays 0: the reference would loop forever; it never passes minEdits = 0 with maxEdits > 0 unaligned
+                iv[(size_t)p] *= 4;
+            }
+        }
+    }
+    return BBMAP_OK;
+}
+
+extern "C" int bbband_align_double_batch(bbband_ctx *c, int64_t n, const bbband_pair *pairs, const uint8_t *seqs, int64_t seq_bytes,
+                                         int32_t maxEdits, int32_t exact, int32_t *edits) {
+    if (!c || n < 0 || (n > 0 && (!pairs || !seqs || !edits)) || seq_bytes < 0) return bfail(BBMAP_E_ARG, "bbband_align_double_batch: bad argument");
+    if (n == 0) return BBMAP_OK;
+    PairBatch B{c, n, pairs, exact != 0};
+    int rc = B.init(seqs, seq_bytes);
+    if (rc != BBMAP_OK) return rc;
+    for (int64_t i = 0; i < n; i++) B.jobs[(size_t)i] = B.job(i, BBBAND_FORWARD, 0, 0, maxEdits);
+    rc = B.run(n);
+    if (rc != BBMAP_OK) return rc;
+    std::vector<int64_t> todo;
+    for (int64_t i = 0; i < n; i++) { edits[i] = B.res[(size_t)i].edits; if (edits[i] != 0) todo.push_back(i); }
+    for (size_t t = 0; t < todo.size(); t++) B.jobs[t] = B.job(todo[t], BBBAND_FORWARD_RC, pairs[todo[t]].query_len - 1, 0, edits[todo[t]]);
+    rc = B.run((int64_t)todo.size());
+    if (rc != BBMAP_OK) return rc;
+    for (size_t t = 0; t < todo.size(); t++) { const int cc = B.res[t].edits; if (cc < edits[todo[t]]) edits[todo[t]] = cc; }
+    return BBMAP_OK;
 }

@@ -229,6 +229,19 @@ int bbband_align_batch_device(bbband_ctx *ctx, void *stream, int64_t n_jobs, con
 int bbband_align_batch(bbband_ctx *ctx, int64_t n_jobs, const bbband_job *jobs,
                        const uint8_t *seqs, int64_t seq_bytes, bbband_result *results);
 
+/* BandedAligner's orchestration over the four directions (current/align2/BandedAligner.java:24-55), batched over
+ * (query, ref) pairs held in one host buffer `seqs`; edits[i] = the method's return value for pair i.
+ *   alignQuadruple(query, ref, maxEdits, exact)                        :39-48
+ *   alignQuadrupleProgressive(query, ref, minEdits, maxEdits, exact)   :24-37  (minEdits >= 1, as every caller passes)
+ *   alignDouble(query, ref, maxEdits, exact)                           :50-55 */
+typedef struct bbband_pair { int64_t query_off, ref_off; int32_t query_len, ref_len; } bbband_pair;   /* 24 bytes */
+int bbband_align_quadruple_batch(bbband_ctx *ctx, int64_t n_pairs, const bbband_pair *pairs, const uint8_t *seqs, int64_t seq_bytes,
+                                 int32_t maxEdits, int32_t exact, int32_t *edits);
+int bbband_align_quadruple_progressive_batch(bbband_ctx *ctx, int64_t n_pairs, const bbband_pair *pairs, const uint8_t *seqs,
+                                             int64_t seq_bytes, int32_t minEdits, int32_t maxEdits, int32_t exact, int32_t *edits);
+int bbband_align_double_batch(bbband_ctx *ctx, int64_t n_pairs, const bbband_pair *pairs, const uint8_t *seqs, int64_t seq_bytes,
+                              int32_t maxEdits, int32_t exact, int32_t *edits);
+
 /* =====================================================================================
  * k-mer index probe (align2.BBIndex.findAdvanced)
  *   The reference has NO native boundary for the index: BBIndex is pure Java.  This is the new seam

@@ -103,3 +103,51 @@ def test_quadruple_matches_reference_orchestration():
             d = banded_align(3, q, r, 0, len(r) - 1, me2, False, 21, 1)[0]
             exp = min(max(a, b), max(c, d))
         assert g == exp
+
+
+def _quad_oracle(q, r, maxEdits, exact, width, variant):
+    a = banded_align(0, q, r, 0, 0, maxEdits, exact, width, variant)[0]
+    b = banded_align(2, q, r, len(q) - 1, len(r) - 1, maxEdits, exact, width, variant)[0]
+    me2 = min(maxEdits, max(a, b))
+    if me2 == 0:
+        return 0
+    c = banded_align(1, q, r, len(q) - 1, 0, me2, exact, width, variant)[0]
+    d = banded_align(3, q, r, 0, len(r) - 1, me2, exact, width, variant)[0]
+    return min(max(a, b), max(c, d))
+
+
+def test_progressive_and_double_match_reference_orchestration():
+    """alignQuadrupleProgressive (BandedAligner.java:24-37) and alignDouble (:50-55) behind the C ABI, both semantics."""
+    rng = random.Random(11)
+    pairs = []
+    for _ in range(80):
+        a = rand_seq(rng, rng.choice([40, 90, 200]))
+        b = mutate(rng, a, max_events=rng.choice([0, 2, 6, 14]), n_prob=0.0)
+        if rng.random() < 0.5:
+            b = revcomp(b)
+        pairs.append((a, b))
+    for sem in (B.SEMANTICS_JNI_C, B.SEMANTICS_JAVA):
+        width = 41
+        al = B.BandedAligner(width, sem)
+        mw = al.maxWidth
+        for minE, maxE, exact in ((1, 20, False), (2, 9, True), (10, 10, False)):
+            got = al.alignQuadrupleProgressive(pairs, minE, maxE, exact)
+            for (q, r), g in zip(pairs, got):
+                mx = min(maxE, max(len(q), len(r)))
+                i, me, exp = min(minE, mx), -1, mx
+                while me < mx:
+                    me = min(i, mx)
+                    if me * 2 > mx:
+                        me = mx
+                    e = _quad_oracle(q, r, me, exact, mw, sem)
+                    if e < me:
+                        exp = e
+                        break
+                    i *= 4
+                assert g == exp, (sem, minE, maxE, exact, q, r)
+        got = al.alignDouble(pairs, 12, False)
+        for (q, r), g in zip(pairs, got):
+            a = banded_align(0, q, r, 0, 0, 12, False, mw, sem)[0]
+            exp = 0 if a == 0 else min(a, banded_align(1, q, r, len(q) - 1, 0, a, False, mw, sem)[0])
+            assert g == exp
+        al.close()
