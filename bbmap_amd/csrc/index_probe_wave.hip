@@ -41,6 +41,11 @@ using namespace wavep;
 #else
 #define BST(u, i, v) do { } while (0)
 #endif
+#ifdef BBIDX_CYC_STATS              // debug build: {cycles offered to the whole-cycle walk, declined, entries, candidates, candidates visited}
+#define CST(u, i, v) ((u).ph[i] += (unsigned)(v))
+#else
+#define CST(u, i, v) do { } while (0)
+#endif
 #ifdef BBIDX_PHASE_TIMERS
 #define PH_MARK(u, i) do { const unsigned long long now_ = __builtin_readcyclecounter(); (u).ph[i] += (unsigned)(now_ - (u).phT); (u).phT = now_; } while (0)
 #else
@@ -72,7 +77,7 @@ struct U {
     int k, baseKeyHitScore, indelPenalty, indelPenaltyMult, maxPenalty, scoreZ1Key;
     int lane, blen;
     unsigned cPrescan, cWalk, cExtend, cRefBytes;
-#if defined(BBIDX_PHASE_TIMERS) || defined(BBIDX_BATCH_STATS)
+#if defined(BBIDX_PHASE_TIMERS) || defined(BBIDX_BATCH_STATS) || defined(BBIDX_CYC_STATS)
     unsigned ph[5]; unsigned long long phT;     // debug build: cycles per phase instead of the work counters
 #endif
 };
@@ -326,6 +331,191 @@ __device__ inline int batchPop(const U &u, WL &L, int lo, int hi, int cutoff, bo
     return np;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Whole-cycle form of the heap walk (long-list variant).  The reference merges the K lists of a (block, strand) cycle one
+// entry at a time; on a large genome nearly every entry it pops is ISOLATED: no entry of any list within
+// [site - MAX_INDEL, site + MAX_INDEL2], so exactly one list "hits" (approxHits = 1) and the site either cannot reach the hit
+// cutoff (cutoff >= 2: the pop changes nothing) or contributes the fixed quick score keyScore + scoreZ1Key to a running
+// maximum (prescan at cutoff <= 1).  Only a few sites per cycle are anything else.  So instead of K-way merging one pop per
+// wave step:
+//   1. all entries of the cycle are gathered into LDS at once (64 gathers in flight per instruction);
+//   2. presence maps over 32 kbp buckets (two hash functions, 2048 bits each) mark the entries that have company in their
+//      own or a neighbouring bucket: the CANDIDATES (a hash collision only makes a harmless extra candidate);
+//   3. the candidates are visited in ascending site order with exactly the state the reference has there: every list's
+//      head is its first entry >= site (a cursor per lane = per list), an exhausted list keeps its last value;
+//   4. popSite's exit rule -- the loop ends at the first pop at which a list runs out and fewer than `cutoff` stay alive --
+//      needs no visit: the lists' last entries are ranked once, the pop that ends the loop after site s at cutoff c is
+//      max(the (n-c+1)-th smallest last entry, the smallest last entry >= s), and isolated pops at cutoff >= 2 do nothing else;
+//   5. (prescan only) before a candidate is looked at, the isolated entries below it are folded into the running maximum
+//      while the cutoff is still <= 1 (at that cutoff the loop can only end with the very last entry).
+// The sequential functions above remain for the cycles this form declines (more than CYC_EMAX entries or CYC_CMAX candidates,
+// a single list, perfect-only prescans, walks that start at a hit cutoff below 2) and for the plain variant.
+#ifndef BBIDX_CYCLE
+#define BBIDX_CYCLE 1               // 0: always the sequential heap walk (for A/B measurements)
+#endif
+constexpr int CYC_EMAX = 384, CYC_CMAX = 192;
+struct CycleLds {
+    int ent[CYC_EMAX];               // adjusted sites, list after list
+    unsigned short isoq[CYC_EMAX];   // 0 for a candidate, else the entry's prescan quick score keyScore + scoreZ1Key
+    unsigned once[2][64], twice[2][64];   // presence maps over hashed 32 kbp buckets: seen, seen more than once
+};
+struct CycleLanes { int lo, len, last, p, rank; };   // per lane = per list: its slice of ent[], last value, cursor, rank of `last`
+
+__device__ inline unsigned cyc_h1(unsigned b) { return (b * 0x9E3779B1u) >> 21; }
+__device__ inline unsigned cyc_h2(unsigned b) { return ((b ^ (b >> 7)) * 0x85EBCA6Bu) >> 21; }
+__device__ inline bool cyc_bit(const unsigned *m, unsigned sl) { return (m[sl >> 5] >> (sl & 31)) & 1; }
+
+// Gathers the cycle's entries.  Returns the number of candidates (their sites in cs[]), or -1 when the cycle does not fit.
+// xrow/xoff/xlo (S.xch) and xksc (S.loc) are scratch of the load phase; cs aliases xrow..xlo afterwards.
+template <int WLEN> __device__ int cycleLoad(const U &u, CycleLds &C, WaveLds<WLEN> &S, const WL &L, int baseChrom, CycleLanes &cl, int &E) {
+    const int lane = u.lane, n = L.n;
+    int *xrow = S.xch[0], *xoff = S.xch[1], *xlo = S.xch[2], *xksc = S.loc, *cs = S.xch[0];
+    const int len = lane < n ? L.stop - L.row : 0;
+    int inc = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    E = rl(inc, 63);
+    if (E > CYC_EMAX || n < 2) return -1;
+    cl.lo = inc - len; cl.len = len; cl.p = 0;
+    wsync();
+    xlo[lane] = cl.lo; xksc[lane] = L.ksc; xrow[lane] = L.row; xoff[lane] = L.offs;
+    C.once[0][lane] = 0; C.once[1][lane] = 0; C.twice[0][lane] = 0; C.twice[1][lane] = 0;
+    wsync();
+    for (int base = 0; base < E; base += 256) {
+        int raw[4], qs[4], oj[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = base + q * 64 + lane;
+            const bool in = e < E;
+            int a = 0, b = n;                                  // largest j with lo[j] <= e
+            while (b - a > 1) { const int m = (a + b) >> 1; if (xlo[m] <= (in ? e : 0)) a = m; else b = m; }
+            oj[q] = xoff[a]; qs[q] = xksc[a] + u.scoreZ1Key;
+            raw[q] = in ? L.sites[xrow[a] + (e - xlo[a])] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = base + q * 64 + lane;
+            if (e < E) {
+                const int v = adjustSite(u, raw[q], oj[q], baseChrom);
+                C.ent[e] = v; C.isoq[e] = (unsigned short)min(qs[q], 65535);
+                const unsigned b = (unsigned)v >> 15;
+                const unsigned s1 = cyc_h1(b), s2 = cyc_h2(b), b1 = 1u << (s1 & 31), b2 = 1u << (s2 & 31);
+                if (atomicOr(&C.once[0][s1 >> 5], b1) & b1) atomicOr(&C.twice[0][s1 >> 5], b1);
+                if (atomicOr(&C.once[1][s2 >> 5], b2) & b2) atomicOr(&C.twice[1][s2 >> 5], b2);
+            }
+        }
+    }
+    wsync();
+    cl.last = len > 0 ? C.ent[cl.lo + len - 1] : INT_MAX;
+    {   // rank of every list's last entry (ascending, ties by lane): the exit rule's lookup table
+        int rk = 0;
+        for (int i = 0; i < n; i++) { const int li = rl(cl.last, i); rk += (li < cl.last || (li == cl.last && i < lane)) ? 1 : 0; }
+        cl.rank = lane < n ? rk : -1;
+    }
+    wsync();                                                   // the load phase's scratch is dead: cs[] may be written
+    int ncand = 0;
+    for (int base = 0; base < E; base += 64) {
+        const int e = base + lane;
+        bool cand = false; int v = 0;
+        if (e < E) {
+            v = C.ent[e];
+            const unsigned b = (unsigned)v >> 15;
+            cand = (cyc_bit(C.twice[0], cyc_h1(b)) && cyc_bit(C.twice[1], cyc_h2(b)))
+                || (cyc_bit(C.once[0], cyc_h1(b - 1u)) && cyc_bit(C.once[1], cyc_h2(b - 1u)))
+                || (cyc_bit(C.once[0], cyc_h1(b + 1u)) && cyc_bit(C.once[1], cyc_h2(b + 1u)));
+            if (cand) C.isoq[e] = 0;
+        }
+        const u64 M = __ballot(cand);
+        if (ncand + popc(M) > CYC_CMAX) return -1;
+        if (cand) cs[ncand + popc(M & lt_mask(lane))] = v;
+        ncand += popc(M);
+    }
+    wsync();
+    return ncand;
+}
+// smallest candidate site above `prev` (INT_MAX: none left)
+__device__ inline int cycleNext(const U &u, const int *cs, int ncand, int prev) {
+    int m = INT_MAX;
+    for (int i = u.lane; i < ncand; i += 64) { const int v = cs[i]; if (v > prev) m = min(m, v); }
+    return wmin(m);
+}
+// every list's state when `site` is the heap minimum: head = first entry >= site, value = head or, once exhausted, the last entry
+__device__ inline void cycleSeek(const U &u, const CycleLds &C, CycleLanes &cl, WL &L, int site) {
+    const bool mine = u.lane < L.n;
+    bool adv = mine && cl.p < cl.len && C.ent[cl.lo + cl.p] < site;
+    while (__ballot(adv)) { if (adv) { cl.p++; adv = cl.p < cl.len && C.ent[cl.lo + cl.p] < site; } }
+    const bool live = mine && cl.p < cl.len;
+    const int hv = live ? C.ent[cl.lo + cl.p] : INT_MAX;
+    L.hv = hv; L.value = mine ? (live ? hv : cl.last) : LANE_UNUSED;
+}
+// The pop at which the reference's loop ends after the site `s` has been looked at with hit cutoff c >= 1 (popSite's rule: a
+// list runs out and fewer than c stay alive): INT_MAX if none (cannot happen: the very last entry always ends it).
+__device__ inline int cycleExitSite(const U &u, const CycleLanes &cl, int n, int s, int c) {
+    const int firstDeath = wmin((u.lane < n && cl.last >= s) ? cl.last : INT_MAX);
+    int dstar = INT_MIN;
+    if (n - c >= 0) { const u64 K = __ballot(cl.rank == n - c); if (K) dstar = rl(cl.last, __builtin_ctzll(K)); }
+    return max(firstDeath, dstar);
+}
+
+// BBIndex.findMaxQscore2 in the whole-cycle form.  Returns false when the cycle was declined (nothing touched).
+template <int WLEN> __device__ bool findMaxQscore2Cycle(U &u, CycleLds &C, WaveLds<WLEN> &S, WL &L, int baseChrom, int prevMaxHits, int numKeys, int mqsAllKeys, int &outQ, int &outHits) {
+    const bbidx_params &p = u.ix->p;
+    const int numHits = L.n, lane = u.lane;
+    if (wmin(lane < numHits ? L.ksc : INT_MAX) <= 0) return false;       // an isolated site must not be able to reach maxQuickScore
+    if (max(p.maxIndel, p.maxIndel2) > 32768) return false;               // the presence map's buckets must span the hit window
+    CycleLanes cl; int E;
+    const int ncand = cycleLoad(u, C, S, L, baseChrom, cl, E);
+    CST(u, 0, 1);
+    if (ncand < 0) { CST(u, 1, 1); return false; }
+    CST(u, 2, E); CST(u, 3, ncand);
+    const int *cs = S.xch[0];
+    u.cPrescan += (unsigned)E;
+    const int mqs = numHits == numKeys ? mqsAllKeys : maxQuickScoreW(u, L.offs, L.ksc, numHits);
+    int topQscore = -999999999, maxHits = 0;
+    int approxHitsCutoff = max(prevMaxHits, min(p.minApproxHitsToKeep, numHits - 1));
+    const int lo = min(p.maxIndel, p.maxIndel2), hi = p.maxIndel2;
+    int prev = INT_MIN;
+    // at a cutoff >= 2 the pops in front of the first candidate are isolated and the loop may already end among them
+    bool ended = approxHitsCutoff >= 2 && cycleExitSite(u, cl, numHits, INT_MIN, approxHitsCutoff) < cycleNext(u, cs, ncand, INT_MIN);
+    while (!ended) {
+        approxHitsCutoff = uni(approxHitsCutoff); topQscore = uni(topQscore); maxHits = uni(maxHits); prev = uni(prev);
+        const int site = cycleNext(u, cs, ncand, prev);
+        if (approxHitsCutoff <= 1) {
+            // isolated entries below this candidate (all remaining ones after the last candidate): each is a site with one hit
+            int m = 0;
+            for (int base = 0; base < E; base += 64) {
+                const int e = base + lane;
+                if (e < E) { const int v = C.ent[e]; if (v < site && v > prev) m = max(m, (int)C.isoq[e]); }
+            }
+            m = wmax(m);
+            if (m > 0 && m > topQscore) { maxHits = max(maxHits, 1); topQscore = m; }
+        }
+        if (site == INT_MAX) break;
+        CST(u, 4, 1);
+        cycleSeek(u, C, cl, L, site);
+        const int approxHits = popc(mask_ule((unsigned)L.value - (unsigned)(site - lo), (unsigned)(lo + hi)));
+        if (approxHits >= approxHitsCutoff) {
+            const int centerIndex = __builtin_ctzll(mask_eq(L.hv, site));
+            const int qscore = quickScoreW(u, L.value, L.ksc, L.offs, centerIndex, site, approxHits, numHits)
+                             + scoreZ2W(u, L.value, L.offs, site, approxHits, numHits);
+            if (qscore > topQscore) {
+                maxHits = max(approxHits, maxHits);
+                approxHitsCutoff = max(approxHitsCutoff, approxHits - 1);
+                topQscore = qscore;
+                if (qscore >= mqs) break;
+            }
+        }
+        if (approxHitsCutoff >= 2) {
+            // the loop ends at pop X; isolated pops before it change nothing at this cutoff
+            const int X = cycleExitSite(u, cl, numHits, site, approxHitsCutoff);
+            if (X < cycleNext(u, cs, ncand, site) || X == site) break;
+        }
+        prev = site;
+    }
+    outQ = topQscore; outHits = maxHits;
+    return true;
+}
+
 // BBIndex.findMaxQscore2 :2294-2450
 template <bool LONG> __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, bool perfectOnly, int numKeys, int mqsAllKeys,
                                 int &outQ, int &outHits) {
@@ -571,7 +761,7 @@ struct SiteOut { bbidx_site *v; int n, cap; bool overflow; };
 struct PrevSite { int idx, chrom, strand, start, stop, score, perfect, semiperfect, ngaps; };
 
 // BBIndex.slowWalk3 :1219-1706
-template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S, WL &L, int strand, int numKeys, int mqs, int baseChrom_,
+template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S, CycleLds *C, WL &L, int strand, int numKeys, int mqs, int baseChrom_,
                            SiteOut &ssl, int *bestScores, bool allBasesCovered, int maxScore, bool fullyDefined) {
     const bbidx_params &p = u.ix->p;
     const int blen = u.blen, lane = u.lane;
@@ -593,19 +783,16 @@ template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S
 
     PrevSite pv; pv.idx = -1; pv.chrom = pv.strand = pv.start = pv.stop = pv.score = pv.perfect = pv.semiperfect = pv.ngaps = 0;
     bool finished = false;
-    while (L.nlive > 0 && !finished) {
-        // loop-carried uniform state, re-declared uniform at the top of every round (see wavep::uni)
+    // loop-carried uniform state, re-declared uniform at the top of every round (see wavep::uni)
+    auto reuni = [&]() {
         approxHitsCutoff = uni(approxHitsCutoff); cutoff = uni(cutoff); qcutoff = uni(qcutoff); currentTopScore = uni(currentTopScore);
         maxHits = uni(maxHits); perfectsFound = uni(perfectsFound); bestqscore = uni(bestqscore); L.nlive = uni(L.nlive);
         pv.idx = uni(pv.idx); pv.chrom = uni(pv.chrom); pv.strand = uni(pv.strand); pv.start = uni(pv.start); pv.stop = uni(pv.stop);
         pv.score = uni(pv.score); pv.perfect = uni(pv.perfect); pv.semiperfect = uni(pv.semiperfect); pv.ngaps = uni(pv.ngaps);
         ssl.n = uni(ssl.n); ssl.overflow = uni(ssl.overflow); finished = uni(finished); u.cWalk = uni(u.cWalk); u.cExtend = uni(u.cExtend); u.cRefBytes = uni(u.cRefBytes);
-        if (LONG && approxHitsCutoff >= 2 && L.bwait == 0) {
-            int unusedQ = 0, unusedH = 0;
-            if (batchPop(u, L, p.maxIndel, p.maxIndel2, approxHitsCutoff, false, unusedQ, unusedH, 0, baseChrom, u.cWalk) > 0) continue;
-            L.bwait = BATCH_RETRY;
-        } else if (LONG && L.bwait > 0) L.bwait--;
-        const int site = wmin(L.hv);
+    };
+    // one site of the merged lists with every list's head / value in L (the reference's loop body between two polls)
+    auto visit = [&](const int site) -> int {
         const int minsite = site - p.maxIndel, maxsite = site + p.maxIndel2;
         const bool inr = (unsigned)L.value - (unsigned)minsite <= (unsigned)(maxsite - minsite);
         const int approxHits = popc(mask_ule((unsigned)L.value - (unsigned)minsite, (unsigned)(maxsite - minsite)));
@@ -742,6 +929,43 @@ template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S
                 }
             }
         }
+        return approxHits;
+    };
+    bool cycled = false;
+    if (LONG && BBIDX_CYCLE && C != nullptr && approxHitsCutoff >= 2 && max(p.maxIndel, p.maxIndel2) <= 32768) {
+        // whole-cycle form (see findMaxQscore2Cycle): at a hit cutoff >= 2 an isolated entry can neither be scored nor change
+        // any state, so only the candidates are visited, in site order, each followed by popSite's exit rule
+        CycleLanes cl; int E;
+        const int ncand = cycleLoad(u, *C, S, L, baseChrom, cl, E);
+        if (ncand >= 0) {
+            cycled = true;
+            u.cWalk += (unsigned)E;
+            // the candidate sites sit in S.xch, which nothing inside visit() touches (compaction and the greedy trim are over)
+            const int *cs = S.xch[0];
+            int site = cycleNext(u, cs, ncand, INT_MIN);
+            // pops in front of the first candidate are isolated: the loop may already end there
+            if (site != INT_MAX && cycleExitSite(u, cl, numHits, INT_MIN, approxHitsCutoff) < site) site = INT_MAX;
+            while (site != INT_MAX) {
+                reuni(); site = uni(site);
+                cycleSeek(u, *C, cl, L, site);
+                visit(site);
+                if (uni(finished)) break;
+                const int X = cycleExitSite(u, cl, numHits, site, approxHitsCutoff);
+                const int next = cycleNext(u, cs, ncand, site);
+                if (X == site || X < next) break;
+                site = next;
+            }
+        }
+    }
+    while (!cycled && L.nlive > 0 && !finished) {
+        reuni();
+        if (LONG && approxHitsCutoff >= 2 && L.bwait == 0) {
+            int unusedQ = 0, unusedH = 0;
+            if (batchPop(u, L, p.maxIndel, p.maxIndel2, approxHitsCutoff, false, unusedQ, unusedH, 0, baseChrom, u.cWalk) > 0) continue;
+            L.bwait = BATCH_RETRY;
+        } else if (LONG && L.bwait > 0) L.bwait--;
+        const int site = wmin(L.hv);
+        const int approxHits = visit(site);
         if (uni(finished)) break;
         if (LONG && approxHits < approxHitsCutoff && approxHitsCutoff >= 2 && L.bulk == 0) { bulkSkip(u, L, site, p.maxIndel, approxHitsCutoff, baseChrom, u.cWalk); continue; }
         if (LONG && L.bulk > 0) L.bulk--;
@@ -889,10 +1113,11 @@ template <bool LONG, int WLEN> __device__ int makeListsW(const U &u, WaveLds<WLE
 #define BBIDX_WAVE_OCC 6
 #endif
 #ifndef BBIDX_LONG_SHORT_OCC
-#define BBIDX_LONG_SHORT_OCC 8      // long-list variant with short reads (measured 8 > 7 > 6 on the hg38-sized reference)
+#define BBIDX_LONG_SHORT_OCC 5      // long-list variant with short reads: the whole-cycle walk's LDS (7.7 KB per wave) allows 5 waves per SIMD
 #endif
-template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WLEN <= WSHORTLEN ? (LONG ? BBIDX_LONG_SHORT_OCC : 8) : BBIDX_WAVE_OCC) void probe_wave_kernel(const Params P) {
+template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WLEN <= WSHORTLEN ? (LONG ? BBIDX_LONG_SHORT_OCC : 8) : (LONG ? 4 : BBIDX_WAVE_OCC)) void probe_wave_kernel(const Params P) {
     __shared__ WaveLds<WLEN> lds[WAVES_PER_BLOCK];
+    __shared__ CycleLds cyc[LONG ? WAVES_PER_BLOCK : 1];   // whole-cycle walk: the long-list variant only
     __shared__ unsigned blockStats[5];
     __shared__ uint8_t compLut[256];      // AminoAcid.baseToComplementExtended
     __shared__ int8_t numLut[256];        // AminoAcid.baseToNumber
@@ -904,7 +1129,6 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
     WaveLds<WLEN> &S = lds[wave];
     const DevIndex &ix = P.ix;
     const bbidx_params &p = ix.p;
-    const long long r = (long long)blockIdx.x * WAVES_PER_BLOCK + wave;
     U u;
     u.ix = &ix;
     u.c.shift = 31 - p.chromBits; u.c.siteMask = (int)(0xFFFFFFFFu >> (p.chromBits + 1));
@@ -915,14 +1139,21 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
     u.scoreZ1Key = Z_MULT * p.k;
     u.lane = lane; u.blen = 0;
     u.cPrescan = u.cWalk = u.cExtend = u.cRefBytes = 0;
-#if defined(BBIDX_PHASE_TIMERS) || defined(BBIDX_BATCH_STATS)
+#if defined(BBIDX_PHASE_TIMERS) || defined(BBIDX_BATCH_STATS) || defined(BBIDX_CYC_STATS)
     for (int j = 0; j < 5; j++) u.ph[j] = 0;
     u.phT = __builtin_readcyclecounter();
 #endif
     unsigned cSites = 0;
 
+    // persistent waves: a read costs anything from a few microseconds to milliseconds (repeats), and a wave that is done
+    // would otherwise idle until the slowest of its block's four reads finishes
+    for (;;) {
+    long long r = 0;
+    if (lane == 0) r = (long long)atomicAdd(&P.queue[2], 1u);
+    r = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)r);
+    if (r >= P.nreads) break;
     int result = 0;                      // what goes to nsites[r]
-    bool done = (r >= P.nreads);
+    bool done = false;
     bbidx_read rr; rr.len = 0; rr.nkeys = 0; rr.bases_off = 0; rr.keys_off = 0;
     if (!done) rr = P.reads[r];
     const int blen = rr.len;
@@ -1061,7 +1292,9 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
                     if (nh < minHitsToScore) { if (lane == cycle) { prescore = -9999; precount = 0; } }
                     else {
                         int tq, th;
-                        findMaxQscore2W<LONG>(u, L, baseChrom, minHitsToScore, bestqscore >= mqs && pretend, n, mqs, tq, th);
+                        const bool perfectOnly = bestqscore >= mqs && pretend;
+                        if (!(LONG && BBIDX_CYCLE && !perfectOnly && findMaxQscore2Cycle(u, cyc[LONG ? wave : 0], S, L, baseChrom, minHitsToScore, n, mqs, tq, th)))
+                            findMaxQscore2W<LONG>(u, L, baseChrom, minHitsToScore, perfectOnly, n, mqs, tq, th);
                         if (lane == cycle) { prescore = tq; precount = th; }
                         bestqscore = max(tq, bestqscore); maxHits = max(maxHits, th);
                         if (bestqscore >= mqs && pretend) { minHitsToScore = max(minHitsToScore, maxHits); earlyOut = true; }
@@ -1096,23 +1329,25 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
                 if (!prescan || rl(precount, cycle) >= hitsCutoff || rl(prescore, cycle) >= qscoreCutoff) {
                     const int nh = makeListsW<LONG>(u, S, L, block, baseChrom, keyHits(block, strand), strand ? offM : off, strand ? kscM : ksc, n, p.minApproxHitsToKeep);
                     if (nh >= p.minApproxHitsToKeep)
-                        slowWalk3W<LONG>(u, S, L, strand, n, mqs, chrom, ssl, bestScores, allBasesCovered, maxScore, fullyDefined);
+                        slowWalk3W<LONG>(u, S, LONG ? &cyc[wave] : nullptr, L, strand, n, mqs, chrom, ssl, bestScores, allBasesCovered, maxScore, fullyDefined);
                 }
                 if (p.quitAfterTwoPerfects && bestScores[5] >= 2) quit = true;
             }
         }
         result = ssl.overflow ? -1 : ssl.n;
         PH_MARK(u, 3);
-        cSites = (unsigned)ssl.n;
+        cSites += (unsigned)ssl.n;
     } while (0);
 
-    if (r < P.nreads && lane == 0) {
+    if (lane == 0) {
         P.nsites[r] = result;
         if (result == NSITES_PENDING) atomicAdd(&P.queue[1], 1u);
     }
+    wsync();                             // the next read reuses this wave's LDS
+    }   // next read
     if (P.stats) {
         if (lane == 0) {
-#if defined(BBIDX_BATCH_STATS)
+#if defined(BBIDX_BATCH_STATS) || defined(BBIDX_CYC_STATS)
             for (int j = 0; j < 5; j++) atomicAdd(&blockStats[j], u.ph[j]);
 #elif defined(BBIDX_PHASE_TIMERS)
             for (int j = 0; j < 5; j++) atomicAdd(&blockStats[j], u.ph[j] >> 4);
@@ -1131,9 +1366,23 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
 
 int bbidx_launch_wave(const bbidx::Params &P, hipStream_t stream, bool longLists, int maxReadLen) {
     using namespace bbidxw;
-    const long long blocks = (P.nreads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    const dim3 g((unsigned)blocks), b(64 * WAVES_PER_BLOCK);
     const bool shortReads = maxReadLen <= WSHORTLEN;
+    // as many blocks as fit the device at once; they pull reads from a queue (Params.queue[2])
+    static int perCU[4] = {0, 0, 0, 0}, numCUs = 0;
+    const int variant = (longLists ? 2 : 0) + (shortReads ? 1 : 0);
+    if (perCU[variant] == 0) {
+        const void *fn = longLists ? (shortReads ? (const void *)probe_wave_kernel<true, WSHORTLEN> : (const void *)probe_wave_kernel<true, WMAXLEN>)
+                                   : (shortReads ? (const void *)probe_wave_kernel<false, WSHORTLEN> : (const void *)probe_wave_kernel<false, WMAXLEN>);
+        int per = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, 64 * WAVES_PER_BLOCK, 0) != hipSuccess || per < 1) per = 1;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) numCUs = prop.multiProcessorCount;
+        if (numCUs < 1) numCUs = 256;
+        perCU[variant] = per;
+    }
+    long long blocks = (P.nreads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (blocks > (long long)numCUs * perCU[variant]) blocks = (long long)numCUs * perCU[variant];
+    const dim3 g((unsigned)blocks), b(64 * WAVES_PER_BLOCK);
     if (longLists) {
         if (shortReads) hipLaunchKernelGGL((probe_wave_kernel<true, WSHORTLEN>), g, b, 0, stream, P);
         else hipLaunchKernelGGL((probe_wave_kernel<true, WMAXLEN>), g, b, 0, stream, P);
