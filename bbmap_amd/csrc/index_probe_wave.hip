@@ -353,7 +353,7 @@ __device__ inline int batchPop(const U &u, WL &L, int lo, int hi, int cutoff, bo
 #ifndef BBIDX_CYCLE
 #define BBIDX_CYCLE 1               // 0: always the sequential heap walk (for A/B measurements)
 #endif
-constexpr int CYC_EMAX = 384, CYC_CMAX = 192;
+constexpr int CYC_EMAX = 384, CYC_CMAX = 64;
 struct CycleLds {
     int ent[CYC_EMAX];               // adjusted sites, list after list
     unsigned short isoq[CYC_EMAX];   // 0 for a candidate, else the entry's prescan quick score keyScore + scoreZ1Key
@@ -413,23 +413,42 @@ template <int WLEN> __device__ int cycleLoad(const U &u, CycleLds &C, WaveLds<WL
         cl.rank = lane < n ? rk : -1;
     }
     wsync();                                                   // the load phase's scratch is dead: cs[] may be written
-    int ncand = 0;
+    // pass 1: entries with company at bucket granularity (a superset); pass 2: the exact window among those
+    const int lo = min(u.ix->p.maxIndel, u.ix->p.maxIndel2), hi = u.ix->p.maxIndel2;
+    int nflag = 0;
     for (int base = 0; base < E; base += 64) {
         const int e = base + lane;
-        bool cand = false; int v = 0;
+        bool flag = false; int v = 0;
         if (e < E) {
             v = C.ent[e];
             const unsigned b = (unsigned)v >> 15;
-            cand = (cyc_bit(C.twice[0], cyc_h1(b)) && cyc_bit(C.twice[1], cyc_h2(b)))
+            flag = (cyc_bit(C.twice[0], cyc_h1(b)) && cyc_bit(C.twice[1], cyc_h2(b)))
                 || (cyc_bit(C.once[0], cyc_h1(b - 1u)) && cyc_bit(C.once[1], cyc_h2(b - 1u)))
                 || (cyc_bit(C.once[0], cyc_h1(b + 1u)) && cyc_bit(C.once[1], cyc_h2(b + 1u)));
-            if (cand) C.isoq[e] = 0;
         }
-        const u64 M = __ballot(cand);
-        if (ncand + popc(M) > CYC_CMAX) return -1;
-        if (cand) cs[ncand + popc(M & lt_mask(lane))] = v;
+        const u64 M = __ballot(flag);
+        if (nflag + popc(M) > CYC_CMAX) return -1;
+        if (flag) { const int slot = nflag + popc(M & lt_mask(lane)); cs[slot] = v; xlo[slot] = e; }   // xlo (S.xch[2]) holds the entry index
+        nflag += popc(M);
+    }
+    wsync();
+    // an entry needs a visit only if some OTHER entry lies in its hit window [v - lo, v + hi]: only then can a second list hit
+    int ncand = 0;
+    for (int base = 0; base < nflag; base += 64) {
+        const int c = base + lane;
+        const bool in = c < nflag;
+        const int v = in ? cs[c] : 0;
+        bool company = false;
+        for (int i = 0; i < nflag; i++) { const unsigned d = (unsigned)(cs[i] - v) + (unsigned)lo; company |= (i != c) && d <= (unsigned)(lo + hi); }
+        company &= in;
+        if (company) C.isoq[xlo[c]] = 0;
+        const u64 M = __ballot(company);
+        wsync();                                               // every lane has read cs[base..] before it is overwritten below
+        if (company) xoff[ncand + popc(M & lt_mask(lane))] = v;    // xoff (S.xch[1]): the surviving candidates
         ncand += popc(M);
     }
+    wsync();
+    for (int i = lane; i < ncand; i += 64) { const int v = xoff[i]; cs[i] = v; }
     wsync();
     return ncand;
 }
