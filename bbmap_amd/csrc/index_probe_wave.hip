@@ -407,11 +407,7 @@ template <int WLEN> __device__ int cycleLoad(const U &u, CycleLds &C, WaveLds<WL
     }
     wsync();
     cl.last = len > 0 ? C.ent[cl.lo + len - 1] : INT_MAX;
-    {   // rank of every list's last entry (ascending, ties by lane): the exit rule's lookup table
-        int rk = 0;
-        for (int i = 0; i < n; i++) { const int li = rl(cl.last, i); rk += (li < cl.last || (li == cl.last && i < lane)) ? 1 : 0; }
-        cl.rank = lane < n ? rk : -1;
-    }
+    cl.rank = -2;                                              // ranked on first use (cycleExitSite)
     wsync();                                                   // the load phase's scratch is dead: cs[] may be written
     // pass 1: entries with company at bucket granularity (a superset); pass 2: the exact window among those
     const int lo = min(u.ix->p.maxIndel, u.ix->p.maxIndel2), hi = u.ix->p.maxIndel2;
@@ -469,7 +465,12 @@ __device__ inline void cycleSeek(const U &u, const CycleLds &C, CycleLanes &cl, 
 }
 // The pop at which the reference's loop ends after the site `s` has been looked at with hit cutoff c >= 1 (popSite's rule: a
 // list runs out and fewer than c stay alive): INT_MAX if none (cannot happen: the very last entry always ends it).
-__device__ inline int cycleExitSite(const U &u, const CycleLanes &cl, int n, int s, int c) {
+__device__ inline int cycleExitSite(const U &u, CycleLanes &cl, int n, int s, int c) {
+    if (rl(cl.rank, 0) == -2) {                                // rank of every list's last entry (ascending, ties by lane)
+        int rk = 0;
+        for (int i = 0; i < n; i++) { const int li = rl(cl.last, i); rk += (li < cl.last || (li == cl.last && i < u.lane)) ? 1 : 0; }
+        cl.rank = u.lane < n ? rk : -1;
+    }
     const int firstDeath = wmin((u.lane < n && cl.last >= s) ? cl.last : INT_MAX);
     int dstar = INT_MIN;
     if (n - c >= 0) { const u64 K = __ballot(cl.rank == n - c); if (K) dstar = rl(cl.last, __builtin_ctzll(K)); }
@@ -976,6 +977,7 @@ template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S
             }
         }
     }
+    if (LONG && BBIDX_CYCLE && !cycled) refillLists(L);          // makeListsW left the look-ahead buffers to this path
     while (!cycled && L.nlive > 0 && !finished) {
         reuni();
         if (LONG && approxHitsCutoff >= 2 && L.bwait == 0) {
@@ -1103,7 +1105,7 @@ __device__ inline KeyHit minusView(int lane, int n, int cntRC, int startR, int l
 }
 
 // BBIndex.getHits (:354-391) + the heap fill at the top of slowWalk3/findMaxQscore2: builds the compacted lists
-template <bool LONG, int WLEN> __device__ int makeListsW(const U &u, WaveLds<WLEN> &S, WL &L, int block, int baseChrom, const KeyHit &h, int off, int ksc, int n, int minHits) {
+template <bool LONG, int WLEN> __device__ int makeListsW(const U &u, WaveLds<WLEN> &S, WL &L, int block, int baseChrom, const KeyHit &h, int off, int ksc, int n, int minHits, bool refill = true) {
     const bool hit = u.lane < n && h.cnt > 0 && h.len > 0 && h.first != -1;
     const u64 M = __ballot(hit);
     const int nh = popc(M);
@@ -1118,7 +1120,8 @@ template <bool LONG, int WLEN> __device__ int makeListsW(const U &u, WaveLds<WLE
     L.hv = live ? L.value : INT_MAX;
 #pragma unroll
     for (int j = 0; j < NB; j++) L.nb[j] = 0;
-    refillLists(L);
+    L.nbuf = 0;
+    if (refill) refillLists(L);                                 // the whole-cycle walk gathers every entry itself
     L.bulk = L.bwait = -1;
     if (LONG) {
         const int entries = wsum(live ? L.stop - L.row : 0);
@@ -1307,13 +1310,16 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
                 const int baseChrom = u.c.baseChrom(chrom);
                 const int block = baseChrom >> p.chromBits;
                 for (int pmi = 0; pmi < 2 && !earlyOut; pmi++, cycle++) {
-                    const int nh = makeListsW<LONG>(u, S, L, block, baseChrom, keyHits(block, pmi), pmi ? offM : off, pmi ? kscM : ksc, n, minHitsToScore);
+                    const int nh = makeListsW<LONG>(u, S, L, block, baseChrom, keyHits(block, pmi), pmi ? offM : off, pmi ? kscM : ksc, n, minHitsToScore,
+                                                    !(LONG && BBIDX_CYCLE));
                     if (nh < minHitsToScore) { if (lane == cycle) { prescore = -9999; precount = 0; } }
                     else {
                         int tq, th;
                         const bool perfectOnly = bestqscore >= mqs && pretend;
-                        if (!(LONG && BBIDX_CYCLE && !perfectOnly && findMaxQscore2Cycle(u, cyc[LONG ? wave : 0], S, L, baseChrom, minHitsToScore, n, mqs, tq, th)))
+                        if (!(LONG && BBIDX_CYCLE && !perfectOnly && findMaxQscore2Cycle(u, cyc[LONG ? wave : 0], S, L, baseChrom, minHitsToScore, n, mqs, tq, th))) {
+                            if (LONG && BBIDX_CYCLE) refillLists(L);
                             findMaxQscore2W<LONG>(u, L, baseChrom, minHitsToScore, perfectOnly, n, mqs, tq, th);
+                        }
                         if (lane == cycle) { prescore = tq; precount = th; }
                         bestqscore = max(tq, bestqscore); maxHits = max(maxHits, th);
                         if (bestqscore >= mqs && pretend) { minHitsToScore = max(minHitsToScore, maxHits); earlyOut = true; }
@@ -1346,7 +1352,8 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
                 for (int j = 0; j < 6; j++) bestScores[j] = uni(bestScores[j]);
                 ssl.n = uni(ssl.n); ssl.overflow = uni(ssl.overflow); cycle = uni(cycle); quit = uni(quit);
                 if (!prescan || rl(precount, cycle) >= hitsCutoff || rl(prescore, cycle) >= qscoreCutoff) {
-                    const int nh = makeListsW<LONG>(u, S, L, block, baseChrom, keyHits(block, strand), strand ? offM : off, strand ? kscM : ksc, n, p.minApproxHitsToKeep);
+                    const int nh = makeListsW<LONG>(u, S, L, block, baseChrom, keyHits(block, strand), strand ? offM : off, strand ? kscM : ksc, n, p.minApproxHitsToKeep,
+                                                    !(LONG && BBIDX_CYCLE));
                     if (nh >= p.minApproxHitsToKeep)
                         slowWalk3W<LONG>(u, S, LONG ? &cyc[wave] : nullptr, L, strand, n, mqs, chrom, ssl, bestScores, allBasesCovered, maxScore, fullyDefined);
                 }

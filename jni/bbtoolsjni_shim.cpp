@@ -1,55 +1,116 @@
-// Drop-in JNI shim: the symbols BBMap's unmodified Java classes bind with `usejni=t`, implemented on libbbmap_amd.so.
-//
+// libbbtoolsjni.so: the native library BBTools' unmodified Java classes load with `usejni=t`
+// (System.loadLibrary("bbtoolsjni"), current/align2/MultiStateAligner11tsJNI.java:11-38), implemented on libbbmap_amd.so.
+// All nine symbols of the reference's library (jni/makefile.linux builds them from three C files):
 //   Java_align2_MultiStateAligner11tsJNI_fillUnlimitedJNI / fillLimitedXJNI
 //        replace jni/MultiStateAligner11tsJNI.c:707-812 (header jni/align2_MultiStateAligner11tsJNI.h:164-174)
 //   Java_align2_BandedAlignerJNI_align{Forward,ForwardRC,Reverse,ReverseRC}JNI
 //        replace jni/BandedAlignerJNI.c:588-757 (header jni/align2_BandedAlignerJNI.h:17-41)
+//   Java_jgi_BBMergeOverlapper_mateByOverlapJNI / mateByOverlapRatioJNI / mateByOverlapRatioJNI_1WithQualities
+//        replace jni/BBMergeOverlapper.c:389-520 (header jni/jgi_BBMergeOverlapper.h:21-43); host code, see bbmerge_overlap.cpp
 //
-// NOT BUILT OR TESTED IN THIS REPOSITORY'S IMAGE: it has no JDK (no <jni.h>, no JVM), so this file is outside the default
-// build (bbmap_amd/build.py compiles bbmap_amd/csrc only).  On a machine with a JDK:
-//     g++ -O2 -fPIC -shared -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude jni/bbtoolsjni_shim.cpp \
-//         -Lbbmap_amd -lbbmap_amd -Wl,-rpath,'$ORIGIN' -o bbmap_amd/libbbtoolsjni.so
-// and run BBMap with -Djava.library.path=<repo>/bbmap_amd usejni=t.  Everything below is marshalling: the arithmetic is
-// behind the C ABI (include/bbmap_amd.h), which IS tested (tests/test_msa_gpu.py::test_legacy_packed_matrix_feeds_the_java_walkers,
-// tests/test_banded_gpu.py).  The three Java_jgi_BBMergeOverlapper_* symbols of the reference's library are not provided.
+// Two layers.  The bbjni_* functions (extern "C", plain pointers) hold everything that is not JNI marshalling and are tested
+// through ctypes and through the mock JNIEnv of jni/mock_jni_test.cpp.  The Java_* functions only move data across the JNI
+// boundary, and they never wait for the GPU while a GetPrimitiveArrayCritical region is open (a critical region blocks the
+// garbage collector for every other mapping thread): inputs are copied out with Get<Type>ArrayRegion, the fill
+// runs into a per-thread staging matrix, and one short critical region copies the touched rows into `packed`.
 //
-// These per-call entry points keep the reference's shape (one alignment per call, the whole `packed` matrix copied back,
-// SURVEY.md R7); they exist so that nothing on the Java side has to change.  The fast path is the batched ABI
-// (INTEGRATION.md sections 2 and 2b).
+// Compiled against <jni.h> when a JDK is installed, otherwise against jni/jni_min.h (this image has no JDK).
 #if __has_include(<jni.h>)
 #include <jni.h>
+#else
+#include "jni_min.h"
+#endif
 
-#include <mutex>
+#include <cstring>
+#include <vector>
 
 #include "bbmap_amd.h"
+#include "bbmerge_overlap.h"
 
 namespace {
 
-struct MsaSlot { int maxRows, maxColumns; bbmsa_ctx *ctx; };
-thread_local MsaSlot t_msa = {0, 0, nullptr};        // one context per mapping thread, like one MSA per thread in BBMap
-
-bbmsa_ctx *msa_ctx(int maxRows, int maxColumns) {
-    if (t_msa.ctx && t_msa.maxRows == maxRows && t_msa.maxColumns == maxColumns) return t_msa.ctx;
-    if (t_msa.ctx) { bbmsa_destroy(t_msa.ctx); t_msa.ctx = nullptr; }
-    bbmsa_config cfg = {};
-    cfg.device = 0; cfg.maxRows = maxRows; cfg.maxColumns = maxColumns; cfg.bandwidth = 0; cfg.bandwidthRatio = 0.0f;
-    if (bbmsa_create(&cfg, &t_msa.ctx) != BBMAP_OK) return nullptr;
-    t_msa.maxRows = maxRows; t_msa.maxColumns = maxColumns;
-    return t_msa.ctx;
-}
-
+struct MsaSlot { int maxRows, maxColumns, bandwidth; float ratio; bbmsa_ctx *ctx; };
 struct BandSlot { int width; bbband_ctx *ctx; };
-thread_local BandSlot t_band = {0, nullptr};
+// one set of contexts per mapping thread, like one MSA / BandedAligner object per thread in BBMap
+thread_local std::vector<MsaSlot> t_msa;
+thread_local std::vector<BandSlot> t_band;
+thread_local std::vector<int32_t> t_stage;       // staging copy of `packed`
+thread_local char t_err[320] = "";
 
-bbband_ctx *band_ctx(int maxWidth) {
-    if (t_band.ctx && t_band.width == maxWidth) return t_band.ctx;
-    if (t_band.ctx) { bbband_destroy(t_band.ctx); t_band.ctx = nullptr; }
-    bbband_config cfg = {};
-    cfg.device = 0; cfg.width = maxWidth; cfg.semantics = BBBAND_SEMANTICS_JNI_C;      // the C file's semantics, as this symbol had
-    if (bbband_create(&cfg, &t_band.ctx) != BBMAP_OK) return nullptr;
-    t_band.width = maxWidth;
-    return t_band.ctx;
+bbmsa_ctx *msa_ctx(int maxRows, int maxColumns, int bandwidth, float ratio) {
+    for (const MsaSlot &s : t_msa)
+        if (s.maxRows == maxRows && s.maxColumns == maxColumns && s.bandwidth == bandwidth && s.ratio == ratio) return s.ctx;
+    bbmsa_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.device = 0; cfg.maxRows = maxRows; cfg.maxColumns = maxColumns; cfg.bandwidth = bandwidth; cfg.bandwidthRatio = ratio;
+    cfg.reserved[2] = BBMSA_SCHEME_11TS | BBMSA_LEGACY_ONLY;      // per-call fills only: no batch buffers, one scratch matrix
+    bbmsa_ctx *ctx = nullptr;
+    if (bbmsa_create(&cfg, &ctx) != BBMAP_OK) return nullptr;
+    t_msa.push_back(MsaSlot{maxRows, maxColumns, bandwidth, ratio, ctx});
+    return ctx;
 }
+bbband_ctx *band_ctx(int maxWidth) {
+    for (const BandSlot &s : t_band) if (s.width == maxWidth) return s.ctx;
+    bbband_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.device = 0; cfg.width = maxWidth; cfg.semantics = BBBAND_SEMANTICS_JNI_C;      // the C file's semantics, as this symbol had
+    bbband_ctx *ctx = nullptr;
+    if (bbband_create(&cfg, &ctx) != BBMAP_OK) return nullptr;
+    t_band.push_back(BandSlot{maxWidth, ctx});
+    return ctx;
+}
+
+}  // namespace
+
+extern "C" {
+
+// jni/MultiStateAligner11tsJNI.c fillUnlimited (:100-117) / fillLimitedX (:361-382) with their own plain signature, minus the
+// score tables (the kernels carry them).  `packed` is the Java class's matrix (3 x (maxRows+1) x (maxColumns+1) ints); only the
+// rows the fill touches are written.  result: 4 ints (unlimited) or 5 (limited); *iterations is incremented.  0 = ok.
+int bbjni_fill(int limited, const uint8_t *read, int readLen, const uint8_t *ref, int refLen, int refStartLoc, int refEndLoc,
+               int minScore, int32_t *result, int64_t *iterations, int32_t *packed, int maxRows, int maxColumns,
+               int bandwidth, float bandwidthRatio) {
+    bbmsa_ctx *ctx = msa_ctx(maxRows, maxColumns, limited ? bandwidth : 0, limited ? bandwidthRatio : 0.0f);
+    if (!ctx) return BBMAP_E_HIP;
+    int32_t r5[5] = {0, 0, 0, 0, 0};
+    const int rc = bbmsa_fill_packed(ctx, read, readLen, ref, refLen, refStartLoc, refEndLoc, minScore,
+                                     limited ? BBMSA_FILL_LIMITED_RAW : BBMSA_FILL_UNLIMITED_RAW, r5, iterations, packed);
+    if (rc != BBMAP_OK) return rc;
+    for (int i = 0; i < (limited ? 5 : 4); i++) result[i] = r5[i];
+    return BBMAP_OK;
+}
+
+// jni/BandedAlignerJNI.c alignForward / alignForwardRC / alignReverse / alignReverseRC (:123-585): direction = BBBAND_*.
+int bbjni_banded(int direction, const uint8_t *query, int qLen, const uint8_t *ref, int rLen, int qstart, int rstart, int maxEdits,
+                 int exact, int maxWidth, int32_t *returnVals5, int32_t *edits) {
+    bbband_ctx *ctx = band_ctx(maxWidth);
+    if (!ctx) return BBMAP_E_HIP;
+    std::vector<uint8_t> seqs((size_t)qLen + (size_t)rLen + 1);
+    memcpy(seqs.data(), query, (size_t)qLen);
+    memcpy(seqs.data() + qLen, ref, (size_t)rLen);
+    bbband_job job;
+    job.query_off = 0; job.ref_off = qLen; job.query_len = qLen; job.ref_len = rLen;
+    job.qstart = qstart; job.rstart = rstart; job.maxEdits = maxEdits;
+    job.flags = direction | (exact ? BBBAND_EXACT : 0);
+    bbband_result res;
+    const int rc = bbband_align_batch(ctx, 1, &job, seqs.data(), (int64_t)qLen + rLen, &res);
+    if (rc != BBMAP_OK) return rc;
+    returnVals5[0] = res.lastQueryLoc; returnVals5[1] = res.lastRefLoc; returnVals5[2] = res.lastRow;
+    returnVals5[3] = res.lastEdits; returnVals5[4] = res.lastOffset;
+    *edits = res.edits;
+    return BBMAP_OK;
+}
+
+// frees the calling thread's contexts (a mapping thread that ends; tests)
+void bbjni_release_thread(void) {
+    for (MsaSlot &s : t_msa) bbmsa_destroy(s.ctx);
+    for (BandSlot &s : t_band) bbband_destroy(s.ctx);
+    t_msa.clear(); t_band.clear(); t_stage.clear(); t_stage.shrink_to_fit();
+}
+
+}  // extern "C"
+
+namespace {
 
 void throw_runtime(JNIEnv *env, const char *what) {
     jclass cls = env->FindClass("java/lang/RuntimeException");
@@ -58,56 +119,71 @@ void throw_runtime(JNIEnv *env, const char *what) {
 
 // shared by the two fills; `limited` selects fillLimitedX
 void fill_common(JNIEnv *env, bool limited, jbyteArray read, jbyteArray ref, jint refStartLoc, jint refEndLoc, jint minScore,
-                 jintArray result, jlongArray iterations, jintArray packed, jint maxRows, jint maxColumns) {
-    bbmsa_ctx *ctx = msa_ctx(maxRows, maxColumns);
-    if (!ctx) { throw_runtime(env, bbmap_last_error()); return; }
+                 jintArray result, jlongArray iterations, jintArray packed, jint maxRows, jint maxColumns, jint bandwidth, jfloat ratio) {
     const jsize readLen = env->GetArrayLength(read), refLen = env->GetArrayLength(ref);
-    // the reference borrows every array with GetPrimitiveArrayCritical (jni/MultiStateAligner11tsJNI.c:723-748); so does this
-    jbyte *jread = (jbyte *)env->GetPrimitiveArrayCritical(read, nullptr);
-    jbyte *jref = (jbyte *)env->GetPrimitiveArrayCritical(ref, nullptr);
-    jint *jresult = (jint *)env->GetPrimitiveArrayCritical(result, nullptr);
-    jlong *jiter = (jlong *)env->GetPrimitiveArrayCritical(iterations, nullptr);
-    jint *jpacked = (jint *)env->GetPrimitiveArrayCritical(packed, nullptr);
-    int rc = BBMAP_E_ARG;
-    if (jread && jref && jresult && jiter && jpacked) {
-        int32_t r5[5] = {0, 0, 0, 0, 0};
-        int64_t it = jiter[0];
-        rc = bbmsa_fill_packed(ctx, (const uint8_t *)jread, readLen, (const uint8_t *)jref, refLen, refStartLoc, refEndLoc,
-                               minScore, limited ? BBMSA_FILL_LIMITED_RAW : BBMSA_FILL_UNLIMITED_RAW, r5, &it, (int32_t *)jpacked);
-        if (rc == BBMAP_OK) {
-            const int n = limited ? 5 : 4;
-            for (int i = 0; i < n; i++) jresult[i] = r5[i];
-            jiter[0] = it;                                   // incremented, not set (jni/...c:471)
-        }
+    // the window the fill reads is all of `ref` it needs: copy [0, refEndLoc] (bases past the window are never touched)
+    const jsize refNeed = refEndLoc + 1 < refLen ? refEndLoc + 1 : refLen;
+    std::vector<jbyte> rd((size_t)readLen + 1), rf((size_t)(refNeed > 0 ? refNeed : 0) + 1);
+    env->GetByteArrayRegion(read, 0, readLen, rd.data());
+    if (refNeed > 0) env->GetByteArrayRegion(ref, 0, refNeed, rf.data());
+    jlong it = 0;
+    env->GetLongArrayRegion(iterations, 0, 1, &it);
+    const size_t plane = (size_t)(maxRows + 1) * (size_t)(maxColumns + 1);
+    if (t_stage.size() < 3 * plane) t_stage.resize(3 * plane);
+    int32_t r5[5] = {0, 0, 0, 0, 0};
+    int64_t it64 = it;
+    const int rc = bbjni_fill(limited ? 1 : 0, (const uint8_t *)rd.data(), readLen, (const uint8_t *)rf.data(), refNeed, refStartLoc,
+                              refEndLoc, minScore, r5, &it64, t_stage.data(), maxRows, maxColumns, bandwidth, ratio);
+    if (rc != BBMAP_OK) {                                          // the reference calls exit(0) here (jni/...c:130-132)
+        snprintf(t_err, sizeof t_err, "bbtoolsjni: fill failed (%d): %s", rc, bbmap_last_error());
+        throw_runtime(env, t_err);
+        return;
     }
-    if (jpacked) env->ReleasePrimitiveArrayCritical(packed, jpacked, 0);
-    if (jiter) env->ReleasePrimitiveArrayCritical(iterations, jiter, 0);
-    if (jresult) env->ReleasePrimitiveArrayCritical(result, jresult, 0);
-    if (jref) env->ReleasePrimitiveArrayCritical(ref, jref, JNI_ABORT);
-    if (jread) env->ReleasePrimitiveArrayCritical(read, jread, JNI_ABORT);
-    if (rc != BBMAP_OK) throw_runtime(env, bbmap_last_error());     // the reference calls exit(0) here (jni/...c:130-132)
+    // one short critical region: rows 0..rows of the three planes (what score2 / traceback2 read, current/align2/
+    // MultiStateAligner11tsJNI.java:376-658) go into the Java matrix; nothing below blocks
+    const size_t rowInts = (size_t)maxColumns + 1, rowsTouched = (size_t)readLen + 1;
+    jint *jp = (jint *)env->GetPrimitiveArrayCritical(packed, nullptr);
+    if (jp) {
+        for (int s = 0; s < 3; s++) memcpy(jp + s * plane, t_stage.data() + s * plane, rowsTouched * rowInts * sizeof(int32_t));
+        env->ReleasePrimitiveArrayCritical(packed, jp, 0);
+    }
+    env->SetIntArrayRegion(result, 0, limited ? 5 : 4, (const jint *)r5);
+    it = it64;
+    env->SetLongArrayRegion(iterations, 0, 1, &it);                // incremented, not set (jni/...c:471)
 }
 
 jint band_common(JNIEnv *env, int direction, jbyteArray query, jbyteArray ref, jint qstart, jint rstart, jint maxEdits,
                  jboolean exact, jint maxWidth, jintArray returnVals) {
-    bbband_ctx *ctx = band_ctx(maxWidth);
-    if (!ctx) { throw_runtime(env, bbmap_last_error()); return 0; }
     const jsize qLen = env->GetArrayLength(query), rLen = env->GetArrayLength(ref);
-    // one job: the two sequences back to back in one buffer
-    uint8_t *seqs = new uint8_t[(size_t)qLen + (size_t)rLen + 1];
-    env->GetByteArrayRegion(query, 0, qLen, (jbyte *)seqs);
-    env->GetByteArrayRegion(ref, 0, rLen, (jbyte *)(seqs + qLen));
-    bbband_job job;
-    job.query_off = 0; job.ref_off = qLen; job.query_len = qLen; job.ref_len = rLen;
-    job.qstart = qstart; job.rstart = rstart; job.maxEdits = maxEdits;
-    job.flags = direction | (exact ? BBBAND_EXACT : 0);
-    bbband_result res;
-    const int rc = bbband_align_batch(ctx, 1, &job, seqs, (int64_t)qLen + rLen, &res);
-    delete[] seqs;
-    if (rc != BBMAP_OK) { throw_runtime(env, bbmap_last_error()); return 0; }
-    const jint vals[5] = {res.lastQueryLoc, res.lastRefLoc, res.lastRow, res.lastEdits, res.lastOffset};
-    env->SetIntArrayRegion(returnVals, 0, 5, vals);          // fully rewritten, jni/BandedAlignerJNI.c:604-630
-    return res.edits;
+    std::vector<jbyte> q((size_t)qLen + 1), r((size_t)rLen + 1);
+    env->GetByteArrayRegion(query, 0, qLen, q.data());
+    env->GetByteArrayRegion(ref, 0, rLen, r.data());
+    int32_t vals[5] = {0, 0, 0, 0, 0}, edits = 0;
+    const int rc = bbjni_banded(direction, (const uint8_t *)q.data(), qLen, (const uint8_t *)r.data(), rLen, qstart, rstart, maxEdits,
+                                exact ? 1 : 0, maxWidth, vals, &edits);
+    if (rc != BBMAP_OK) {
+        snprintf(t_err, sizeof t_err, "bbtoolsjni: banded alignment failed (%d): %s", rc, bbmap_last_error());
+        throw_runtime(env, t_err);
+        return 0;
+    }
+    env->SetIntArrayRegion(returnVals, 0, 5, (const jint *)vals);   // fully rewritten, jni/BandedAlignerJNI.c:604-630
+    return edits;
+}
+
+// BBMerge natives: arrays are small (two reads); copied in, probabilities and rvector copied back
+struct MergeArrays {
+    std::vector<jbyte> a, b, aq, bq; std::vector<jfloat> ap, bp; jint rv[5];
+    jsize alen, blen;
+};
+void merge_in(JNIEnv *env, MergeArrays &M, jbyteArray a, jbyteArray b, jbyteArray aq, jbyteArray bq, jfloatArray ap, jfloatArray bp, jintArray rv) {
+    M.alen = env->GetArrayLength(a); M.blen = env->GetArrayLength(b);
+    M.a.resize((size_t)M.alen + 1); M.b.resize((size_t)M.blen + 1);
+    env->GetByteArrayRegion(a, 0, M.alen, M.a.data()); env->GetByteArrayRegion(b, 0, M.blen, M.b.data());
+    if (aq) { M.aq.resize((size_t)M.alen + 1); env->GetByteArrayRegion(aq, 0, M.alen, M.aq.data()); }
+    if (bq) { M.bq.resize((size_t)M.blen + 1); env->GetByteArrayRegion(bq, 0, M.blen, M.bq.data()); }
+    if (ap) M.ap.assign((size_t)M.alen + 1, 0.0f);
+    if (bp) M.bp.assign((size_t)M.blen + 1, 0.0f);
+    env->GetIntArrayRegion(rv, 0, 5, M.rv);
 }
 
 }  // namespace
@@ -119,23 +195,16 @@ JNIEXPORT void JNICALL Java_align2_MultiStateAligner11tsJNI_fillUnlimitedJNI(
     JNIEnv *env, jobject, jbyteArray read, jbyteArray ref, jint refStartLoc, jint refEndLoc, jintArray result,
     jlongArray iterationsUnlimited, jintArray packed, jintArray /*POINTSoff_SUB_ARRAY*/, jintArray /*POINTSoff_INS_ARRAY*/,
     jint maxRows, jint maxColumns) {
-    fill_common(env, false, read, ref, refStartLoc, refEndLoc, 0, result, iterationsUnlimited, packed, maxRows, maxColumns);
+    fill_common(env, false, read, ref, refStartLoc, refEndLoc, 0, result, iterationsUnlimited, packed, maxRows, maxColumns, 0, 0.0f);
 }
 
-// ([B[BIII[I[J[I[I[IIIIF[I[I[B[I)V -- bandwidth / bandwidthRatio of the Java statics are honoured through the context
+// ([B[BIII[I[J[I[I[IIIIF[I[I[B[I)V -- MSA.bandwidth / bandwidthRatio arrive per call and select the context
 JNIEXPORT void JNICALL Java_align2_MultiStateAligner11tsJNI_fillLimitedXJNI(
     JNIEnv *env, jobject, jbyteArray read, jbyteArray ref, jint refStartLoc, jint refEndLoc, jint minScore, jintArray result,
     jlongArray iterationsLimited, jintArray packed, jintArray, jintArray, jint maxRows, jint maxColumns, jint bandwidth,
     jfloat bandwidthRatio, jintArray /*vertLimit*/, jintArray /*horizLimit*/, jbyteArray /*baseToNumber*/, jintArray /*INS_ARRAY_C*/) {
-    if (bandwidth >= 1 || bandwidthRatio > 0.0f) {
-        // a band changes the fill window: use a context created with that band (not cached per thread here)
-        bbmsa_config cfg = {};
-        cfg.device = 0; cfg.maxRows = maxRows; cfg.maxColumns = maxColumns; cfg.bandwidth = bandwidth; cfg.bandwidthRatio = bandwidthRatio;
-        if (t_msa.ctx) { bbmsa_destroy(t_msa.ctx); t_msa.ctx = nullptr; }
-        if (bbmsa_create(&cfg, &t_msa.ctx) != BBMAP_OK) { throw_runtime(env, bbmap_last_error()); return; }
-        t_msa.maxRows = maxRows; t_msa.maxColumns = maxColumns;
-    }
-    fill_common(env, true, read, ref, refStartLoc, refEndLoc, minScore, result, iterationsLimited, packed, maxRows, maxColumns);
+    fill_common(env, true, read, ref, refStartLoc, refEndLoc, minScore, result, iterationsLimited, packed, maxRows, maxColumns,
+                bandwidth, bandwidthRatio);
 }
 
 JNIEXPORT jint JNICALL Java_align2_BandedAlignerJNI_alignForwardJNI(
@@ -159,5 +228,54 @@ JNIEXPORT jint JNICALL Java_align2_BandedAlignerJNI_alignReverseRCJNI(
     return band_common(env, BBBAND_REVERSE_RC, query, ref, qstart, rstart, maxEdits, exact, maxWidth, returnVals);
 }
 
+// ([B[B[B[B[F[F[IIIIIIII)I
+JNIEXPORT jint JNICALL Java_jgi_BBMergeOverlapper_mateByOverlapJNI(
+    JNIEnv *env, jclass, jbyteArray a_bases, jbyteArray b_bases, jbyteArray a_quality, jbyteArray b_quality, jfloatArray aprob,
+    jfloatArray bprob, jintArray rvector, jint minOverlap0, jint minOverlap, jint minInsert0, jint margin, jint maxMismatches0,
+    jint maxMismatches, jint minq) {
+    MergeArrays M;
+    merge_in(env, M, a_bases, b_bases, a_quality, b_quality, aprob, bprob, rvector);
+    const jint r = bbmerge_mate_by_overlap(M.a.data(), M.alen, M.b.data(), M.blen, a_quality ? M.aq.data() : nullptr,
+                                           b_quality ? M.bq.data() : nullptr, M.ap.data(), M.bp.data(), M.rv, minOverlap0, minOverlap,
+                                           minInsert0, margin, maxMismatches0, maxMismatches, minq);
+    env->SetIntArrayRegion(rvector, 0, 5, M.rv);                    // the reference releases aprob/bprob with JNI_ABORT: not copied back
+    return r;
+}
+
+// ([B[B[B[B[F[F[IIIIIFFF)I -- the Java method is mateByOverlapRatioJNI_WithQualities (current/jgi/BBMergeOverlapper.java:56), whose
+// JNI name escapes the underscore as _1 (as jni/jgi_BBMergeOverlapper.h:32 declares it); the reference's C file defines
+// ..._mateByOverlapJNI_WithQualities instead (jni/BBMergeOverlapper.c:389), which no Java method resolves to.  Both are exported.
+JNIEXPORT jint JNICALL Java_jgi_BBMergeOverlapper_mateByOverlapRatioJNI_1WithQualities(
+    JNIEnv *env, jclass, jbyteArray a_bases, jbyteArray b_bases, jbyteArray a_quality, jbyteArray b_quality, jfloatArray aprob,
+    jfloatArray bprob, jintArray rvector, jint minOverlap0, jint minOverlap, jint minInsert0, jint minInsert, jfloat maxRatio,
+    jfloat margin, jfloat offset) {
+    MergeArrays M;
+    merge_in(env, M, a_bases, b_bases, a_quality, b_quality, aprob, bprob, rvector);
+    const jint r = bbmerge_mate_by_overlap_ratio_with_qualities(M.a.data(), M.alen, M.b.data(), M.blen, M.aq.data(), M.bq.data(),
+                                                                M.ap.data(), M.bp.data(), M.rv, minOverlap0, minOverlap, minInsert0,
+                                                                minInsert, maxRatio, margin, offset);
+    env->SetIntArrayRegion(rvector, 0, 5, M.rv);
+    return r;
+}
+JNIEXPORT jint JNICALL Java_jgi_BBMergeOverlapper_mateByOverlapJNI_WithQualities(
+    JNIEnv *env, jclass c, jbyteArray a_bases, jbyteArray b_bases, jbyteArray a_quality, jbyteArray b_quality, jfloatArray aprob,
+    jfloatArray bprob, jintArray rvector, jint minOverlap0, jint minOverlap, jint minInsert0, jint minInsert, jfloat maxRatio,
+    jfloat margin, jfloat offset) {
+    return Java_jgi_BBMergeOverlapper_mateByOverlapRatioJNI_1WithQualities(env, c, a_bases, b_bases, a_quality, b_quality, aprob, bprob,
+                                                                          rvector, minOverlap0, minOverlap, minInsert0, minInsert, maxRatio,
+                                                                          margin, offset);
+}
+
+// ([B[B[IIIIIFFFFF)I
+JNIEXPORT jint JNICALL Java_jgi_BBMergeOverlapper_mateByOverlapRatioJNI(
+    JNIEnv *env, jclass, jbyteArray a_bases, jbyteArray b_bases, jintArray rvector, jint minOverlap0, jint minOverlap, jint minInsert0,
+    jint minInsert, jfloat maxRatio, jfloat margin, jfloat offset, jfloat gIncr, jfloat bIncr) {
+    MergeArrays M;
+    merge_in(env, M, a_bases, b_bases, nullptr, nullptr, nullptr, nullptr, rvector);
+    const jint r = bbmerge_mate_by_overlap_ratio(M.a.data(), M.alen, M.b.data(), M.blen, M.rv, minOverlap0, minOverlap, minInsert0,
+                                                 minInsert, maxRatio, margin, offset, gIncr, bIncr);
+    env->SetIntArrayRegion(rvector, 0, 5, M.rv);
+    return r;
+}
+
 }  // extern "C"
-#endif  // __has_include(<jni.h>)
