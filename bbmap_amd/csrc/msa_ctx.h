@@ -39,5 +39,6 @@ struct bbmsa_ctx {
     hipEvent_t ev[4];      // start, after wavefront kernel, after generic kernel, after narrow kernel
     bool timed;
     bool banded;
+    bool legacyOnly;            // created with BBMSA_LEGACY_ONLY: bbmsa_fill_packed only
 };
 

@@ -48,7 +48,8 @@ static int env_int(const char *name, int dflt) {
 extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     if (!cfg || !out) return fail(BBMAP_E_ARG, "bbmsa_create: null argument");
     *out = nullptr;
-    const int scheme = cfg->reserved[2];
+    const int scheme = cfg->reserved[2] & 0xFF;
+    const bool legacyOnly = (cfg->reserved[2] & BBMSA_LEGACY_ONLY) != 0;
     if (scheme != BBMSA_SCHEME_11TS && scheme != BBMSA_SCHEME_9PACBIO) return fail(BBMAP_E_ARG, "bbmsa_create: unknown scoring scheme");
     if (scheme == BBMSA_SCHEME_11TS && (cfg->maxRows < 1 || cfg->maxRows > 640 || cfg->maxColumns < 1 || cfg->maxColumns > 4096))
         return fail(BBMAP_E_ARG, "bbmsa_create: maxRows must be 1..640 and maxColumns 1..4096");
@@ -72,6 +73,22 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     c->numCUs = prop.multiProcessorCount;
 
     c->scheme = scheme;
+    c->legacyOnly = legacyOnly;
+    // every failure below leaves through bbmsa_destroy(c): nothing allocated so far is leaked
+    struct Guard { bbmsa_ctx *c; ~Guard() { if (c) bbmsa_destroy(c); } } guard{c};
+    if (legacyOnly) {
+        // a context for bbmsa_fill_packed only (the per-call JNI shape): one scratch matrix, no batch buffers
+        HIP_TRY(hipMalloc(&c->d_counters, 64));
+        HIP_TRY(hipMemset(c->d_counters, 0, 64));
+        const long long planeInts = (long long)(cfg->maxRows + 1) * (cfg->maxColumns + 2);
+        c->genThreads = 1;
+        HIP_TRY(hipMalloc(&c->d_matrix, (size_t)(3 * planeInts * 4)));
+        HIP_TRY(hipMalloc(&c->d_limits, (size_t)((cfg->maxRows + cfg->maxColumns + 4) * 4)));
+        for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+        guard.c = nullptr;
+        *out = c;
+        return BBMAP_OK;
+    }
     if (scheme != BBMSA_SCHEME_11TS) {
         // 9PacBio: every job runs in the generic kernel (the wavefront and narrow kernels are written for the 11ts constants
         // and for reads of at most 640 bases)
@@ -79,15 +96,16 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
         HIP_TRY(hipMemset(c->d_counters, 0, 64));
         const long long planeInts = (long long)(cfg->maxRows + 1) * (cfg->maxColumns + 2);
         const long long perThread = 3 * planeInts * 4;
-        long long budget = (long long)env_int("BBMSA_GENERIC_SCRATCH_MB", 8192) << 20;
+        long long budget = (long long)env_int("BBMSA_GENERIC_SCRATCH_MB", 40960) << 20;   // 6019 x 7600 (mapPacBio) needs 35 GB for one wavefront of matrices
         long long threads = budget / perThread;
         if (threads > 16384) threads = 16384;
         threads = (threads / 64) * 64;
-        if (threads < 64) threads = 64;
+        if (threads < 64) return fail(BBMAP_E_NOMEM, "bbmsa_create: BBMSA_GENERIC_SCRATCH_MB cannot hold one wavefront of scratch matrices for this maxRows x maxColumns");
         c->genThreads = (int)threads;
         HIP_TRY(hipMalloc(&c->d_matrix, (size_t)(threads * perThread)));
         HIP_TRY(hipMalloc(&c->d_limits, (size_t)(threads * (cfg->maxRows + cfg->maxColumns + 4) * 4)));
         for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+        guard.c = nullptr;
         *out = c;
         return BBMAP_OK;
     }
@@ -114,11 +132,11 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     if (c->tableLen > bbmsa::kTableLen) c->tableLen = bbmsa::kTableLen;
     c->tableLen = (c->tableLen + 3) & ~3;
     c->ldsBytes = (bbmsa::lds_table_ints(c->tableLen) + 4 * jobsPerWave * perJobInts) * 4;
-    if (c->ldsBytes > 160 * 1024) { delete c; return fail(BBMAP_E_ARG, "bbmsa_create: fast-path LDS budget exceeded; lower reserved[1] (fastCols)"); }
+    if (c->ldsBytes > 160 * 1024) return fail(BBMAP_E_ARG, "bbmsa_create: fast-path LDS budget exceeded; lower reserved[1] (fastCols)");
 
     c->banded = !(cfg->bandwidth < 1 && cfg->bandwidthRatio <= 0.0f);
     const void *kfn = bbmsa::fast_kernel_for(c->R, c->banded);
-    if (!kfn) { delete c; return fail(BBMAP_E_ARG, "bbmsa_create: no kernel for this rows-per-lane"); }
+    if (!kfn) return fail(BBMAP_E_ARG, "bbmsa_create: no kernel for this rows-per-lane");
     if (c->ldsBytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, c->ldsBytes));
     int blocksPerCU = 0;
@@ -179,6 +197,7 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
         HIP_TRY(hipMalloc(&c->d_narrowDir, (size_t)c->narrowBlocks * (size_t)(cfg->maxRows + 1) * 64 * 8));
     }
     for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+    guard.c = nullptr;
     *out = c;
     return BBMAP_OK;
 }
@@ -227,6 +246,7 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
     if (match && match_stride < 1) return fail(BBMAP_E_ARG, "bbmsa_align_batch_device: match_stride must be positive");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->legacyOnly) return fail(BBMAP_E_ARG, "bbmsa_align_batch_device: this context was created for bbmsa_fill_packed only (BBMSA_LEGACY_ONLY)");
     if (c->scheme != BBMSA_SCHEME_11TS) {
         HIP_TRY(hipMemsetAsync(c->d_counters, 0, 64, stream));
         HIP_TRY(hipEventRecord(c->ev[0], stream));

@@ -108,6 +108,9 @@ typedef struct bbmsa_config {
  * maxColumns <= 8192; this round every 9PacBio job runs in the one-job-per-thread kernel. */
 #define BBMSA_SCHEME_11TS 0
 #define BBMSA_SCHEME_9PACBIO 1
+/* OR-ed into reserved[2]: a context for bbmsa_fill_packed only (what the per-call JNI symbols use, one per mapping thread):
+ * one scratch matrix and no batch buffers, instead of gigabytes of batch scratch per thread */
+#define BBMSA_LEGACY_ONLY 0x100
 
 int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out);
 void bbmsa_destroy(bbmsa_ctx *ctx);

@@ -21,6 +21,7 @@
 #include "jni_min.h"
 #endif
 
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -181,8 +182,11 @@ void merge_in(JNIEnv *env, MergeArrays &M, jbyteArray a, jbyteArray b, jbyteArra
     env->GetByteArrayRegion(a, 0, M.alen, M.a.data()); env->GetByteArrayRegion(b, 0, M.blen, M.b.data());
     if (aq) { M.aq.resize((size_t)M.alen + 1); env->GetByteArrayRegion(aq, 0, M.alen, M.aq.data()); }
     if (bq) { M.bq.resize((size_t)M.blen + 1); env->GetByteArrayRegion(bq, 0, M.blen, M.bq.data()); }
-    if (ap) M.ap.assign((size_t)M.alen + 1, 0.0f);
-    if (bp) M.bp.assign((size_t)M.blen + 1, 0.0f);
+    // the probability arrays are the caller's scratch: mateByOverlap reads bprob[j] with j running over read a (jni/BBMergeOverlapper.c:70),
+    // i.e. up to max(alen, blen) entries of whatever the Java array holds; copy the whole array (zero-padded to that length)
+    const jsize need = (M.alen > M.blen ? M.alen : M.blen) + 1;
+    if (ap) { const jsize n = env->GetArrayLength(ap); M.ap.assign((size_t)(n > need ? n : need), 0.0f); env->GetFloatArrayRegion(ap, 0, n, M.ap.data()); }
+    if (bp) { const jsize n = env->GetArrayLength(bp); M.bp.assign((size_t)(n > need ? n : need), 0.0f); env->GetFloatArrayRegion(bp, 0, n, M.bp.data()); }
     env->GetIntArrayRegion(rv, 0, 5, M.rv);
 }
 
@@ -238,7 +242,11 @@ JNIEXPORT jint JNICALL Java_jgi_BBMergeOverlapper_mateByOverlapJNI(
     const jint r = bbmerge_mate_by_overlap(M.a.data(), M.alen, M.b.data(), M.blen, a_quality ? M.aq.data() : nullptr,
                                            b_quality ? M.bq.data() : nullptr, M.ap.data(), M.bp.data(), M.rv, minOverlap0, minOverlap,
                                            minInsert0, margin, maxMismatches0, maxMismatches, minq);
-    env->SetIntArrayRegion(rvector, 0, 5, M.rv);                    // the reference releases aprob/bprob with JNI_ABORT: not copied back
+    env->SetIntArrayRegion(rvector, 0, 5, M.rv);
+    // the reference writes the probabilities through its critical pointers (direct pointers in HotSpot, so JNI_ABORT discards
+    // nothing): the Java scratch arrays keep them, and a later call can read them past its own read length
+    if (aprob) env->SetFloatArrayRegion(aprob, 0, M.alen, M.ap.data());
+    if (bprob) env->SetFloatArrayRegion(bprob, 0, M.blen, M.bp.data());
     return r;
 }
 
@@ -255,6 +263,8 @@ JNIEXPORT jint JNICALL Java_jgi_BBMergeOverlapper_mateByOverlapRatioJNI_1WithQua
                                                                 M.ap.data(), M.bp.data(), M.rv, minOverlap0, minOverlap, minInsert0,
                                                                 minInsert, maxRatio, margin, offset);
     env->SetIntArrayRegion(rvector, 0, 5, M.rv);
+    if (aprob) env->SetFloatArrayRegion(aprob, 0, M.alen, M.ap.data());
+    if (bprob) env->SetFloatArrayRegion(bprob, 0, M.blen, M.bp.data());
     return r;
 }
 JNIEXPORT jint JNICALL Java_jgi_BBMergeOverlapper_mateByOverlapJNI_WithQualities(

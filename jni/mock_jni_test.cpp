@@ -1,0 +1,130 @@
+// Exercises the Java_* entry points of libbbtoolsjni.so against a mock JNIEnv (no JVM in this image): arrays are plain
+// buffers behind jobject handles, the function table carries the calls the shim makes, and the mock FAILS the test if a
+// critical region is open while any other JNI call is made or while more than one region is open (the JNI
+// specification forbids blocking inside a critical region).  Usage: mock_jni_test merge | gpu   (exit code 0 = pass)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "jni_min.h"
+#include "bbmerge_overlap.h"
+
+struct _jobject { void *data; int len; int elem; };
+static int g_critical = 0, g_violations = 0, g_thrown = 0;
+static void touch() { if (g_critical) g_violations++; }
+
+static jclass mFindClass(JNIEnv *, const char *) { touch(); static _jobject cls = {nullptr, 0, 0}; return &cls; }
+static jint mThrowNew(JNIEnv *, jclass, const char *msg) { touch(); g_thrown++; fprintf(stderr, "thrown: %s\n", msg); return 0; }
+static jsize mGetArrayLength(JNIEnv *, jarray a) { touch(); return a->len; }
+template <class T> static void getRegion(jarray a, jsize s, jsize l, T *b) { touch(); memcpy(b, (T *)a->data + s, sizeof(T) * (size_t)l); }
+template <class T> static void setRegion(jarray a, jsize s, jsize l, const T *b) { touch(); memcpy((T *)a->data + s, b, sizeof(T) * (size_t)l); }
+static void mGetByte(JNIEnv *, jbyteArray a, jsize s, jsize l, jbyte *b) { getRegion(a, s, l, b); }
+static void mGetInt(JNIEnv *, jintArray a, jsize s, jsize l, jint *b) { getRegion(a, s, l, b); }
+static void mGetLong(JNIEnv *, jlongArray a, jsize s, jsize l, jlong *b) { getRegion(a, s, l, b); }
+static void mGetFloat(JNIEnv *, jfloatArray a, jsize s, jsize l, jfloat *b) { getRegion(a, s, l, b); }
+static void mSetInt(JNIEnv *, jintArray a, jsize s, jsize l, const jint *b) { setRegion(a, s, l, b); }
+static void mSetLong(JNIEnv *, jlongArray a, jsize s, jsize l, const jlong *b) { setRegion(a, s, l, b); }
+static void mSetFloat(JNIEnv *, jfloatArray a, jsize s, jsize l, const jfloat *b) { setRegion(a, s, l, b); }
+static void *mGetCritical(JNIEnv *, jarray a, jboolean *) { if (g_critical) g_violations++; g_critical++; return a->data; }
+static void mReleaseCritical(JNIEnv *, jarray, void *, jint) { g_critical--; }
+
+extern "C" {
+void Java_align2_MultiStateAligner11tsJNI_fillUnlimitedJNI(JNIEnv *, jobject, jbyteArray, jbyteArray, jint, jint, jintArray, jlongArray, jintArray, jintArray, jintArray, jint, jint);
+void Java_align2_MultiStateAligner11tsJNI_fillLimitedXJNI(JNIEnv *, jobject, jbyteArray, jbyteArray, jint, jint, jint, jintArray, jlongArray, jintArray, jintArray, jintArray, jint, jint, jint, jfloat, jintArray, jintArray, jbyteArray, jintArray);
+jint Java_align2_BandedAlignerJNI_alignForwardJNI(JNIEnv *, jobject, jbyteArray, jbyteArray, jint, jint, jint, jboolean, jint, jbyteArray, jintArray);
+jint Java_jgi_BBMergeOverlapper_mateByOverlapJNI(JNIEnv *, jclass, jbyteArray, jbyteArray, jbyteArray, jbyteArray, jfloatArray, jfloatArray, jintArray, jint, jint, jint, jint, jint, jint, jint);
+jint Java_jgi_BBMergeOverlapper_mateByOverlapRatioJNI_1WithQualities(JNIEnv *, jclass, jbyteArray, jbyteArray, jbyteArray, jbyteArray, jfloatArray, jfloatArray, jintArray, jint, jint, jint, jint, jfloat, jfloat, jfloat);
+jint Java_jgi_BBMergeOverlapper_mateByOverlapRatioJNI(JNIEnv *, jclass, jbyteArray, jbyteArray, jintArray, jint, jint, jint, jint, jfloat, jfloat, jfloat, jfloat, jfloat);
+int bbjni_fill(int, const uint8_t *, int, const uint8_t *, int, int, int, int, int32_t *, int64_t *, int32_t *, int, int, int, float);
+void bbjni_release_thread(void);
+}
+
+#define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
+
+static unsigned rnd(unsigned &s) { s = s * 1664525u + 1013904223u; return s >> 8; }
+
+static int test_merge(JNIEnv *env) {
+    unsigned seed = 7;
+    for (int trial = 0; trial < 200; trial++) {
+        const int alen = 60 + (int)(rnd(seed) % 90), blen = 60 + (int)(rnd(seed) % 90), ov = 20 + (int)(rnd(seed) % 40);
+        std::vector<jbyte> a((size_t)alen), b((size_t)blen), aq((size_t)alen), bq((size_t)blen);
+        for (auto &x : a) x = "ACGT"[rnd(seed) & 3];
+        for (int i = 0; i < blen; i++) b[(size_t)i] = (i < ov) ? a[(size_t)(alen - ov + i)] : "ACGT"[rnd(seed) & 3];   // b overlaps a's tail
+        for (int i = 0; i < (int)(rnd(seed) % 4); i++) b[(size_t)(rnd(seed) % (unsigned)ov)] = 'N';
+        for (auto &x : aq) x = (jbyte)(2 + rnd(seed) % 39);
+        for (auto &x : bq) x = (jbyte)(2 + rnd(seed) % 39);
+        const int cap = (alen > blen ? alen : blen) + 1;
+        std::vector<jfloat> ap((size_t)cap, 0.0f), bp((size_t)cap, 0.0f), ap2((size_t)cap, 0.0f), bp2((size_t)cap, 0.0f);
+        jint rv[5] = {0, 0, 0, 0, 0}, rv2[5] = {0, 0, 0, 0, 0};
+        _jobject ja{a.data(), alen, 1}, jb{b.data(), blen, 1}, jaq{aq.data(), alen, 1}, jbq{bq.data(), blen, 1};
+        _jobject jap{ap.data(), cap, 4}, jbp{bp.data(), cap, 4}, jrv{rv, 5, 4};
+        const jint r1 = Java_jgi_BBMergeOverlapper_mateByOverlapRatioJNI(env, nullptr, &ja, &jb, &jrv, 8, 12, 35, 35, 0.075f, 2.0f, 0.55f, 0.65f, 0.95f);
+        const jint e1 = bbmerge_mate_by_overlap_ratio(a.data(), alen, b.data(), blen, rv2, 8, 12, 35, 35, 0.075f, 2.0f, 0.55f, 0.65f, 0.95f);
+        CHECK(r1 == e1 && memcmp(rv, rv2, sizeof rv) == 0);
+        const jint r2 = Java_jgi_BBMergeOverlapper_mateByOverlapRatioJNI_1WithQualities(env, nullptr, &ja, &jb, &jaq, &jbq, &jap, &jbp, &jrv, 8, 12, 35, 35, 0.075f, 2.0f, 0.55f);
+        const jint e2 = bbmerge_mate_by_overlap_ratio_with_qualities(a.data(), alen, b.data(), blen, aq.data(), bq.data(), ap2.data(), bp2.data(), rv2, 8, 12, 35, 35, 0.075f, 2.0f, 0.55f);
+        CHECK(r2 == e2 && memcmp(rv, rv2, sizeof rv) == 0);
+        const jint r3 = Java_jgi_BBMergeOverlapper_mateByOverlapJNI(env, nullptr, &ja, &jb, &jaq, &jbq, &jap, &jbp, &jrv, 8, 14, 35, 2, 3, 3, 10);
+        const jint e3 = bbmerge_mate_by_overlap(a.data(), alen, b.data(), blen, aq.data(), bq.data(), ap2.data(), bp2.data(), rv2, 8, 14, 35, 2, 3, 3, 10);
+        if (!(r3 == e3 && memcmp(rv, rv2, sizeof rv) == 0)) fprintf(stderr, "trial %d r3=%d e3=%d rv=%d,%d,%d,%d,%d rv2=%d,%d,%d,%d,%d\n", trial, r3, e3, rv[0],rv[1],rv[2],rv[3],rv[4], rv2[0],rv2[1],rv2[2],rv2[3],rv2[4]);
+        CHECK(r3 == e3 && memcmp(rv, rv2, sizeof rv) == 0);
+    }
+    CHECK(g_violations == 0 && g_critical == 0 && g_thrown == 0);
+    printf("mock JNI: 600 BBMerge calls equal the plain functions, no JNI call inside a critical region\n");
+    return 0;
+}
+
+static int test_gpu(JNIEnv *env) {
+    const int maxRows = 160, maxColumns = 300;
+    unsigned seed = 11;
+    std::vector<jbyte> ref(2000);
+    for (auto &x : ref) x = "ACGT"[rnd(seed) & 3];
+    const size_t plane = (size_t)(maxRows + 1) * (maxColumns + 1);
+    std::vector<jint> packed(3 * plane, 0x55555555), packed2(3 * plane, 0x55555555);
+    for (int trial = 0; trial < 12; trial++) {
+        const int st = 100 + (int)(rnd(seed) % 1500), len = 100 + (int)(rnd(seed) % 50);
+        std::vector<jbyte> rd(ref.begin() + st, ref.begin() + st + len);
+        rd[(size_t)(rnd(seed) % (unsigned)len)] = 'T';
+        if (trial & 1) rd.erase(rd.begin() + 40, rd.begin() + 43);
+        const int rlen = (int)rd.size(), a = st - 4, b = st + len + 3;
+        const int minScore = (int)(0.56f * (70 + 100 * (rlen - 1)));
+        jint res[5] = {0, 0, 0, 0, 0}; jlong it[1] = {1000};
+        _jobject jrd{rd.data(), rlen, 1}, jrf{ref.data(), (int)ref.size(), 1}, jres{res, 5, 4}, jit{it, 1, 8}, jpk{packed.data(), (int)packed.size(), 4};
+        const bool limited = (trial % 3) != 0;
+        const int bw = (trial % 4 == 3) ? 40 : 0; const float bwr = bw ? 0.18f : 0.0f;
+        if (limited) Java_align2_MultiStateAligner11tsJNI_fillLimitedXJNI(env, nullptr, &jrd, &jrf, a, b, minScore, &jres, &jit, &jpk, nullptr, nullptr, maxRows, maxColumns, bw, bwr, nullptr, nullptr, nullptr, nullptr);
+        else Java_align2_MultiStateAligner11tsJNI_fillUnlimitedJNI(env, nullptr, &jrd, &jrf, a, b, &jres, &jit, &jpk, nullptr, nullptr, maxRows, maxColumns);
+        CHECK(g_thrown == 0 && g_violations == 0 && g_critical == 0);
+        // the same call through the plain layer (what tests/test_msa_gpu.py checks against the oracle's walkers)
+        int32_t r2[5] = {0, 0, 0, 0, 0}; int64_t it2 = 1000;
+        CHECK(bbjni_fill(limited, (const uint8_t *)rd.data(), rlen, (const uint8_t *)ref.data(), (int)ref.size(), a, b, minScore, r2, &it2, packed2.data(), maxRows, maxColumns, bw, bwr) == 0);
+        for (int i = 0; i < (limited ? 5 : 4); i++) CHECK(res[i] == r2[i]);
+        CHECK(it[0] == it2 && it2 > 1000);
+        for (int s = 0; s < 3; s++) CHECK(memcmp(packed.data() + s * plane, packed2.data() + s * plane, (size_t)(rlen + 1) * (maxColumns + 1) * 4) == 0);
+        CHECK(res[0] == rlen);
+    }
+    {   // BandedAligner symbol: the survey's known answer (edits 2, {19,18,19,2,1})
+        jbyte q[] = "ACGTTGCAAGCTTAGGCTTA", r[] = "ACGTTGCAGCTTAGGCTTAC";
+        jint rv[5] = {9, 9, 9, 9, 9};
+        _jobject jq{q, 20, 1}, jr{r, 20, 1}, jrv{rv, 5, 4};
+        const jint e = Java_align2_BandedAlignerJNI_alignForwardJNI(env, nullptr, &jq, &jr, 0, 0, 5, 1, 11, nullptr, &jrv);
+        CHECK(e == 2 && rv[0] == 19 && rv[1] == 18 && rv[2] == 19 && rv[3] == 2 && rv[4] == 1);
+    }
+    bbjni_release_thread();
+    CHECK(g_violations == 0 && g_critical == 0 && g_thrown == 0);
+    printf("mock JNI: fills and the banded symbol through the JNI layer equal the plain layer, one short critical region per fill\n");
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    JNINativeInterface_ tbl;
+    memset(&tbl, 0, sizeof tbl);
+    tbl.FindClass = mFindClass; tbl.ThrowNew = mThrowNew; tbl.GetArrayLength = mGetArrayLength;
+    tbl.GetByteArrayRegion = mGetByte; tbl.GetIntArrayRegion = mGetInt; tbl.GetLongArrayRegion = mGetLong; tbl.GetFloatArrayRegion = mGetFloat;
+    tbl.SetIntArrayRegion = mSetInt; tbl.SetLongArrayRegion = mSetLong; tbl.SetFloatArrayRegion = mSetFloat;
+    tbl.GetPrimitiveArrayCritical = mGetCritical; tbl.ReleasePrimitiveArrayCritical = mReleaseCritical;
+    JNIEnv_ env; env.functions = &tbl;
+    if (argc > 1 && !strcmp(argv[1], "gpu")) return test_gpu(&env);
+    return test_merge(&env);
+}
