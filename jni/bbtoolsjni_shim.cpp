@@ -140,12 +140,16 @@ void fill_common(JNIEnv *env, bool limited, jbyteArray read, jbyteArray ref, jin
         throw_runtime(env, t_err);
         return;
     }
-    // one short critical region: rows 0..rows of the three planes (what score2 / traceback2 read, current/align2/
-    // MultiStateAligner11tsJNI.java:376-658) go into the Java matrix; nothing below blocks
+    // one short critical region: the rectangle the fill touched (rows 0..rows, columns 0..columns+1 of the three planes -- what
+    // score2 / traceback2 read, current/align2/MultiStateAligner11tsJNI.java:376-658) goes into the Java matrix; nothing in here blocks
     const size_t rowInts = (size_t)maxColumns + 1, rowsTouched = (size_t)readLen + 1;
+    size_t width = (size_t)(refEndLoc - refStartLoc + 1) + 2;
+    if (width > rowInts) width = rowInts;
     jint *jp = (jint *)env->GetPrimitiveArrayCritical(packed, nullptr);
     if (jp) {
-        for (int s = 0; s < 3; s++) memcpy(jp + s * plane, t_stage.data() + s * plane, rowsTouched * rowInts * sizeof(int32_t));
+        for (int s = 0; s < 3; s++)
+            for (size_t r = 0; r < rowsTouched; r++)
+                memcpy(jp + s * plane + r * rowInts, t_stage.data() + s * plane + r * rowInts, width * sizeof(int32_t));
         env->ReleasePrimitiveArrayCritical(packed, jp, 0);
     }
     env->SetIntArrayRegion(result, 0, limited ? 5 : 4, (const jint *)r5);
