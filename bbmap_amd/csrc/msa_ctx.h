@@ -40,5 +40,10 @@ struct bbmsa_ctx {
     bool timed;
     bool banded;
     bool legacyOnly;            // created with BBMSA_LEGACY_ONLY: bbmsa_fill_packed only
+    // strip-tiled wavefront kernel of the 9PacBio scheme (msa_fill_strip.hip)
+    int stripBlocks, stripLds;
+    long long stripDwords, stripSlotDwords;
+    int *d_stripBoundary;
+    uint8_t *d_stripTmp;
 };
 

@@ -1,0 +1,548 @@
+// Strip-tiled wavefront DP for long reads (gfx950): the MultiStateAligner9PacBio parameter set, reads of up to 6,100 bases
+// against windows of up to 8,192 columns (mapPacBio: ALIGN_ROWS 6020, ALIGN_COLUMNS 7600, current/align2/BBMapThreadPacBio.java:27-28;
+// recurrence current/align2/MultiStateAligner9PacBio.java:128-560, constants :2359-2439 -- the same skeleton as
+// jni/MultiStateAligner11tsJNI.c:100-704 with other constants, 9 time bits and barriers of 1).
+//
+// One alignment per wavefront.  The read is cut into horizontal STRIPS of 64 x R rows; inside a strip lane l owns R consecutive
+// rows and sweeps them left to right one column behind lane l-1 (the anti-diagonal wavefront of msa_fill_fast.hip: the three
+// values a row needs from the row above arrive by DPP, nothing else leaves the lane's registers).  Between strips only the
+// boundary row travels: the last row's three planes (one int per column and plane) go to HBM as the last lane produces them and
+// come back 64 columns at a time, coalesced, to feed lane 0 of the next strip through a readlane; the first / last "good" column
+// of that row travel as two scalars.  A 6,000 x 7,600 matrix is 549 MB in the reference (3 planes of int32) and never exists
+// here; what is kept per cell is the 4-bit traceback record (what traceback2 / score2 would decide at that cell), 23 MB per job
+// in HBM, and the walk reads it back cooperatively, 64 diagonal cells per step, across strip borders.
+// The score-pruned window of fillLimitedX is reproduced exactly as in msa_fill_fast.hip: cells outside
+// a row's window read as `subfloor`, over-computing provably-pruned cells changes nothing, and the visited-cell count is
+// recovered from the rows' first / last good columns.  Banded fills and windows more than two columns narrower than the read
+// are handed to the one-job-per-thread kernel (msa_fill_generic.hip), as the wavefront kernel does.
+#include "msa_common.h"
+
+namespace bbmsa {
+
+struct StripParams {
+    const bbmsa_job *jobs;
+    const uint8_t *reads;
+    const uint8_t *refs;
+    bbmsa_result *results;
+    uint8_t *match;
+    long long njobs;
+    const unsigned int *njobs_dev;
+    unsigned int *queue;          // work-queue head (zeroed before launch)
+    unsigned int *dirbuf;         // per resident wave: strips x dir_strip_dwords
+    long long dir_slot_dwords, dir_strip_dwords;
+    int *boundary;                // per resident wave: 2 x 3 x (maxColumns + 2) ints (ping-pong boundary rows)
+    uint8_t *tmpbuf;              // per resident wave: maxRows + maxColumns + 8 bytes (reversed match string)
+    int *slow_list;               // jobs handed to the generic kernel
+    unsigned int *slow_count;
+    int match_stride;
+    int maxRows, maxColumns;
+    int bandwidth;
+    float bandwidthRatio;
+};
+
+namespace {
+
+__device__ __forceinline__ int lane_up(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }
+
+template <class S> __device__ __forceinline__ int ctime(int t) { return t > S::MAXT ? S::MAXT - 3 : t; }
+template <class S> __device__ __forceinline__ int del_ext(int streak) {
+    int c = (streak & 3) == 0 ? S::DEL5 : 0;
+    c = streak < 80 ? S::DEL4 : c; c = streak < 20 ? S::DEL3 : c; c = streak < 5 ? S::DEL2 : c; c = streak == 0 ? S::DEL : c;
+    return c;
+}
+template <class S> __device__ __forceinline__ int ins_ext(int streak) {
+    int c = S::INS4;
+    c = streak < 20 ? S::INS3 : c; c = streak < 5 ? S::INS2 : c; c = streak == 0 ? S::INS : c;
+    return c;
+}
+template <class S> __device__ __forceinline__ int sub_ext(int streak) {
+    int c = S::SUB3;
+    c = streak < 5 ? S::SUB2 : c; c = streak == 0 ? S::SUB : c;
+    return c;
+}
+__device__ __forceinline__ unsigned load_coherent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// what this wave wrote earlier (boundary rows, the reversed match string) is read back past the vector L1, which may still hold
+// the lines as they were before the writes
+__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint8_t ld_agent_u8(const uint8_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+}  // namespace
+
+template <class S, int R>
+__global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p) {
+    extern __shared__ int lds[];
+    int2 *colinfo = reinterpret_cast<int2 *>(lds);                   // [c] = {horizLimit[c] + ONE, ref byte of column c}
+    constexpr int ONE = 1 << S::OFF;                                 // one score unit: a packed cell p = score|time satisfies
+                                                                     // score <= L  <=>  p < L + ONE for bounds that are multiples of ONE
+    constexpr int STRIP = 64 * R;
+    const int lane = threadIdx.x;
+    const long long slot = blockIdx.x;
+    unsigned *dirSlot = p.dirbuf + slot * p.dir_slot_dwords;
+    int *bnd = p.boundary + slot * 6LL * (p.maxColumns + 2);
+    uint8_t *tmp = p.tmpbuf + slot * (long long)(p.maxRows + p.maxColumns + 8);
+    const long long total = job_count(p.njobs, p.njobs_dev);
+
+    for (;;) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(p.queue, 1u);
+        const long long j = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (j >= total) break;
+
+        // ------------------------------------------------------------------ job setup (as msa_fill_fast.hip)
+        const bbmsa_job jb = p.jobs[j];
+        const int rows = jb.read_len;
+        int a = jb.refStartLoc, b = jb.refEndLoc;
+        const int mode = jb.flags & BBMSA_MODE_MASK;
+        if (jb.flags & BBMSA_CLAMP_WINDOW) {
+            a = max(0, a);
+            b = min(jb.ref_len - 1, b);
+            if (b - a >= p.maxColumns) b = min(jb.ref_len - 1, a + p.maxColumns - 1);
+        }
+        const int columns = b - a + 1;
+        const bool shapeOK = rows >= 1 && columns >= 1 && rows <= p.maxRows && columns <= p.maxColumns;
+        int halfband = 0;
+        if (!(p.bandwidth < 1 && p.bandwidthRatio <= 0.0f)) {
+            const int bwA = p.bandwidth < 1 ? 9999999 : p.bandwidth;
+            const int bwB = p.bandwidthRatio <= 0.0f ? 9999999 : 8 + (int)__fmul_rn((float)rows, p.bandwidthRatio);
+            halfband = max(min(bwA, bwB), columns - rows + 8) / 2;
+        }
+        int minScore = jb.minScore;
+        bool limited;
+        if (mode == BBMSA_FILL_UNLIMITED_RAW) limited = false;
+        else if (mode == BBMSA_FILL_LIMITED_RAW) limited = true;
+        else {
+            if (minScore < 1 || (columns + rows < 90) ||
+                ((halfband < 1 || halfband * 3 > columns) && (columns > rows + min(170, rows + 20)))) limited = false;
+            else { limited = true; minScore -= 120; }
+        }
+        const bool banded = limited && halfband > 0;
+        if (!shapeOK) {
+            if (lane == 0) {
+                bbmsa_result r;
+                for (int i = 0; i < 5; i++) r.result[i] = 0;
+                r.status = BBMSA_ST_BAD_SHAPE; r.iterations = 0;
+                for (int i = 0; i < 8; i++) r.score[i] = 0;
+                r.score_len = 0; r.match_len = 0; r.fill_kind = 0; r.columns = columns;
+                p.results[j] = r;
+            }
+            continue;
+        }
+        if (banded || columns < rows - 2) {                         // the generic kernel takes these
+            if (lane == 0) { const unsigned k = atomicAdd(p.slow_count, 1u); p.slow_list[k] = (int)j; }
+            continue;
+        }
+
+        const uint8_t *rd = p.reads + jb.read_off;
+        const uint8_t *rf = p.refs + jb.ref_off + a;                 // rf[c-1] is the reference byte of column c
+        const int maxGain = (rows - 1) * S::MATCH2 + S::MATCH;
+        const int minScoreOff = minScore * ONE;
+        const int floorv = limited ? minScoreOff - maxGain : kNegInf;
+        const int subfloor = limited ? floorv - 5 * S::MATCH2 : 0 - 2 * maxGain;
+        const int floorP = floorv + ONE;
+        const bool notLimited = !limited;
+        const int nstrips = (rows + STRIP - 1) / STRIP;
+
+        // column info: reference bytes by the whole wave, horizLimit by lane 0 (jni/...c:427-438)
+        for (int c = lane + 1; c <= columns; c += 64) colinfo[c].y = rf[c - 1];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            int h = minScoreOff;
+            bool prevDef = false;
+            for (int i = columns - 1; i >= 0; i--) {
+                colinfo[i + 1].x = (limited ? h : kNegInf) + ONE;
+                const int cb = colinfo[i + 1].y;
+                const bool def = fully_defined(cb);
+                const int cost = def ? (prevDef ? S::MATCH2 : S::MATCH) : ((prevDef && cb == '-') ? S::DEL : 0);
+                h = max(h - cost, floorv);
+                prevDef = def;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // vertLimit needs, per row, the gain still available from the bases after it: cost of base i = defined ?
+        // (next defined ? MATCH2 : MATCH) : 0 (jni/...c:413-425).  suffixAfter = that sum over the strips below the current one.
+        auto base_cost = [&](int i) -> int {                          // i = 0-based base index
+            if (i >= rows || !fully_defined(rd[i])) return 0;
+            return (i + 1 < rows && fully_defined(rd[i + 1])) ? S::MATCH2 : S::MATCH;
+        };
+        // first / last good column of the row above the current strip, visited-cell bookkeeping, last-row argmax
+        int bMin = 1, bMax = columns;                                 // row 0: the reference starts with minGoodCol 1, maxGoodCol columns
+        long long iters = 0;
+        int noEnterRow = INT_MAX;                                     // first row the limited fill does not enter
+        int lastColStart = 1, lastHasGood = 0;
+        int bestM = 0, bestD = 0, bestI = 0, bestMc = -1, bestDc = -1, bestIc = -1;
+
+        for (int s = 0; s < nstrips; s++) {
+            const int rowBase = s * STRIP;                            // rows rowBase+1 .. rowBase+STRIP
+            const int r0 = rowBase + lane * R + 1;
+            unsigned *dir = dirSlot + (long long)s * p.dir_strip_dwords;
+            const int *bIn = bnd + (s & 1) * 3 * (p.maxColumns + 2);          // boundary row written by strip s-1
+            int *bOut = bnd + ((s + 1) & 1) * 3 * (p.maxColumns + 2);
+            const int W = p.maxColumns + 2;
+
+            int call1[R], vlimP[R], delForce[R], insHiForce[R], mPrev[R];
+            bool rowValid[R];
+            int call0First = '?';
+            {
+                if (r0 >= 2 && r0 - 2 < rows) call0First = rd[r0 - 2];
+                int cst[R], laneSum = 0;
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    const int row = r0 + k;
+                    rowValid[k] = row <= rows;
+                    call1[k] = rowValid[k] ? rd[row - 1] : 0;
+                    cst[k] = base_cost(row);                          // base index `row` = the first base after this row
+                    laneSum += cst[k];
+                }
+                int inc = laneSum;                                    // inclusive suffix sum over the lanes
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_down(inc, d, 64); if (lane + d < 64) inc += o; }
+                // the bases of the strips below: summed by the whole wave once per strip (a few passes over the read)
+                int below = 0;
+                for (int i = rowBase + STRIP + 1 + lane; i < rows; i += 64) below += base_cost(i);
+                for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d, 64);
+                // (cost indices: row r's limit counts bases r .. rows-1; lane sums cover r0 .. rowBase+STRIP, `below` the rest)
+                int suffix = inc - laneSum + below;
+#pragma unroll
+                for (int k = R - 1; k >= 0; k--) {
+                    suffix += cst[k];
+                    const int v = limited ? max(minScoreOff - suffix, floorv) : kNegInf;
+                    vlimP[k] = rowValid[k] ? v + ONE : (1 << 30);
+                }
+            }
+            int pM[R], pD[R], pI[R], minGood[R], maxGood[R];
+            unsigned dacc[R];
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const int row = r0 + k;
+                const int c0v = S::col0(min(row, rows));
+                pM[k] = c0v; pD[k] = c0v; pI[k] = c0v;
+                minGood[k] = -1; maxGood[k] = -2; dacc[k] = 0;
+                mPrev[k] = (call1[k] == '!') ? 1 : 0;
+                delForce[k] = (row < S::BAR_D1 || row > rows - S::BAR_D1) ? INT_MAX : INT_MIN;
+                insHiForce[k] = (row > rows - S::BAR_I1) ? INT_MAX : INT_MIN;
+            }
+            const bool lead = lane == 0;
+            const bool rowOneLow = (r0 < S::BAR_I1);                  // slot 0 of lane 0 in strip 0 when BAR_I1 > 1 (never for 9PacBio)
+            const int rowAbove0 = S::col0(r0 - 1);                    // column 0 of the row above my first row (0 for row 0)
+            int svM = rowBase == 0 && lead ? 0 : rowAbove0, svD = svM, svI = svM;
+            if (lead && s > 0) { svM = ld_agent(bIn); svD = ld_agent(bIn + W); svI = ld_agent(bIn + 2 * W); }
+            int lastRef = '!';
+            const int lastSlot = (rows - 1) % R;
+            const bool ownerLaneFlag = (rows - 1) / STRIP == s && lane == ((rows - 1) % STRIP) / R;
+            const bool lastLane = lane == 63;
+            const int steps = columns + 63;
+            int bufM = 0, bufD = 0, bufI = 0;                         // 64 columns of the boundary row above, one per lane
+
+            for (int t = 1; t <= steps; t++) {
+                if (s > 0 && ((t - 1) & 63) == 0) {                   // columns t .. t+63 of the previous strip's last row
+                    const int cc = min(t + lane, columns);
+                    bufM = ld_agent(bIn + cc); bufD = ld_agent(bIn + W + cc); bufI = ld_agent(bIn + 2 * W + cc);
+                }
+                const int c = t - lane;
+                if (c >= 1) {
+                    const bool inRange = c <= columns;
+                    const int cc = min(c, columns);
+                    const int2 ci = colinfo[cc];
+                    const int hlP = ci.x, ref1 = ci.y;
+                    const int ref0 = c < 2 ? '!' : lastRef;
+                    const bool gap = ref1 == '-', refN = ref1 == 'N';
+                    const int refPen = refN ? S::DEL_REF_N : (gap ? S::GAP : 0);
+                    const int insNeededBase = (columns - c) + 1;
+                    const bool cGt1 = c > 1;
+                    const int cLtLastForce = (c < columns - 1) ? INT_MAX : INT_MIN;
+                    const unsigned sh = (unsigned)(t & 7) * 4u;
+
+                    int upM = lane_up(pM[R - 1], 0), upD = lane_up(pD[R - 1], 0), upI = lane_up(pI[R - 1], 0);
+                    int upMin = lane_up(minGood[R - 1], 1);
+                    if (lead) {
+                        if (s == 0) { upM = 0; upD = 0; upI = 0; upMin = 1; }                // row 0 is all zero
+                        else {
+                            // lane 0 is at column t: entry (t - 1) & 63 of the buffered boundary columns
+                            const int src = (t - 1) & 63;
+                            upM = __builtin_amdgcn_readlane(bufM, src); upD = __builtin_amdgcn_readlane(bufD, src); upI = __builtin_amdgcn_readlane(bufI, src);
+                            upMin = (bMin >= 0 && c >= bMin) ? bMin : -1;
+                        }
+                    }
+                    int dgM = svM, dgD = svD, dgI = svI;
+                    svM = upM; svD = upD; svI = upI;
+                    bool started = upMin >= 0;
+                    bool prevMatch = (call0First == ref0) & (ref0 != 'N');
+#pragma unroll
+                    for (int k = 0; k < R; k++) {
+                        const int row = r0 + k;
+                        const bool act = inRange & (started | notLimited);
+                        const int cl1 = call1[k];
+                        const bool match = (cl1 == ref1) & !refN;
+                        const int limitP = max(vlimP[k], hlP);
+                        const int limit = limitP - ONE;
+                        const int delNeeded = max(0, row - c - 1);
+                        const int insNeeded = max(0, (rows - row) - insNeededBase);
+                        const int delPen = S::del_off(delNeeded), insPen = S::ins_cum_off(insNeeded);
+
+                        // ---- match / substitution plane
+                        const int streakM = dgM & S::TMASK;
+                        const int sdm = dgM & S::SMASK;
+                        const int mDI = max(dgD, dgI) & S::SMASK;
+                        const int t3 = max(floorP, limitP - (match ? S::MATCH2 : S::SUB3));
+                        const bool pruneM = !act | gap | (max(dgM, max(dgD, dgI)) < t3);
+                        int addA = prevMatch ? (streakM <= 1 ? S::SUBR : S::SUB) : sub_ext<S>(streakM);
+                        addA = (refN | (cl1 == 'N')) ? 0 : addA;
+                        addA = match ? (prevMatch ? S::MATCH2 : S::MATCH) : addA;
+                        const int sa = sdm + addA;
+                        const int sbc = mDI + (match ? S::MATCH : S::SUB);
+                        const bool aWinsM = sa >= sbc;
+                        const int scoreM = max(sa, sbc);
+                        const int timeM = (aWinsM & (match == prevMatch)) ? streakM + 1 : 1;
+                        const int penM = delNeeded > 0 ? delPen : (insNeeded > 0 ? insPen : 0);
+                        const bool goodM = !pruneM & (scoreM + penM >= limit);     // the offsets are negative: score >= limit - offset
+                        const int nM = goodM ? (scoreM | ctime<S>(timeM)) : subfloor;
+
+                        // ---- deletion plane (same row, previous column)
+                        const int streakD = pD[k] & S::TMASK;
+                        const int slm = pM[k] & S::SMASK, sld = pD[k] & S::SMASK;
+                        const bool pruneD = !act | (max(pM[k], pD[k]) < max(limitP, delForce[k]));
+                        const int dsa = slm + S::DEL, dsb = sld + del_ext<S>(streakD);
+                        const bool aWinsD = dsa >= dsb;
+                        const int scoreD = max(dsa, dsb) + refPen;
+                        const int timeD = aWinsD ? 1 : streakD + 1;
+                        const int penD = insNeeded > 0 ? insPen : (delNeeded > 0 ? S::del_off(timeD + delNeeded) - S::del_off(timeD) : 0);
+                        const bool goodD = !pruneD & (scoreD + penD >= limit);
+                        const int nD = goodD ? (scoreD | ctime<S>(timeD)) : subfloor;
+
+                        // ---- insertion plane (row above, same column)
+                        const int streakI = upI & S::TMASK;
+                        const int sum = upM & S::SMASK, sui = upI & S::SMASK;
+                        const int insLow = (k == 0 && rowOneLow && cGt1) ? INT_MAX : INT_MIN;
+                        const int insForce = max(insLow, min(insHiForce[k], cLtLastForce));
+                        const bool pruneI = !act | gap | (max(upM, upI) < max(limitP, insForce));
+                        const int isa = sum + S::INS, isb = sui + ins_ext<S>(streakI);
+                        const bool aWinsI = isa >= isb;
+                        const int scoreI = max(isa, isb);
+                        const int timeI = aWinsI ? 1 : streakI + 1;
+                        const int penI = delNeeded > 0 ? delPen : (insNeeded > 0 ? S::ins_cum_off(timeI + insNeeded) - S::ins_cum_off(timeI) : 0);
+                        const bool goodI = !pruneI & (scoreI + penI >= limit);
+                        const int nI = goodI ? (scoreI | ctime<S>(timeI)) : subfloor;
+
+                        // ---- traceback record: what traceback2 / score2 would decide at this cell (time > 1: stay; else the
+                        // predecessor comparison on scores); the clamped time decides "stay", as it does on the stored cell
+                        const bool msStay = (ctime<S>(timeM) > 1) | (sdm >= mDI);
+                        const unsigned nibM = msStay ? 0u : (((dgD | S::TMASK) >= dgI) ? 1u : 2u);
+                        const unsigned nib = nibM | (aWinsD ? 0u : 4u) | (aWinsI ? 0u : 8u);
+                        dacc[k] |= nib << sh;
+
+                        const bool good = goodM | goodD | goodI;
+                        minGood[k] = (good & (minGood[k] < 0)) ? c : minGood[k];
+                        maxGood[k] = good ? c : maxGood[k];
+                        dgM = pM[k]; dgD = pD[k]; dgI = pI[k];
+                        pM[k] = nM; pD[k] = nD; pI[k] = nI;
+                        upM = nM; upI = nI;
+                        started = minGood[k] >= 0;
+                        const int mp = mPrev[k];
+                        mPrev[k] = match ? 1 : 0;
+                        prevMatch = mp != 0;
+                    }
+                    lastRef = ref1;
+
+                    if (lastLane && inRange) {                        // the strip's last row: next strip's boundary
+                        bOut[c] = pM[R - 1]; bOut[W + c] = pD[R - 1]; bOut[2 * W + c] = pI[R - 1];
+                    }
+                    {   // last row of the read: first strict maximum per plane, ascending column
+                        int lm = pM[0], ld = pD[0], li = pI[0];
+#pragma unroll
+                        for (int k = 1; k < R; k++) { lm = (lastSlot == k) ? pM[k] : lm; ld = (lastSlot == k) ? pD[k] : ld; li = (lastSlot == k) ? pI[k] : li; }
+                        const bool track = ownerLaneFlag & inRange;
+                        const bool um = track & ((bestMc < 0) | ((lm & S::SMASK) > (bestM & S::SMASK)));
+                        const bool ud = track & ((bestDc < 0) | ((ld & S::SMASK) > (bestD & S::SMASK)));
+                        const bool ui = track & ((bestIc < 0) | ((li & S::SMASK) > (bestI & S::SMASK)));
+                        bestM = um ? lm : bestM; bestMc = um ? c : bestMc;
+                        bestD = ud ? ld : bestD; bestDc = ud ? c : bestDc;
+                        bestI = ui ? li : bestI; bestIc = ui ? c : bestIc;
+                    }
+                }
+                if ((t & 7) == 7) {
+                    const long long o = (long long)(t >> 3) * R * 64 + lane;
+#pragma unroll
+                    for (int k = 0; k < R; k++) { dir[o + (long long)k * 64] = dacc[k]; dacc[k] = 0; }
+                }
+            }
+            if ((steps & 7) != 7) {
+                const long long o = (long long)(steps >> 3) * R * 64 + lane;
+#pragma unroll
+                for (int k = 0; k < R; k++) dir[o + (long long)k * 64] = dacc[k];
+            }
+            if (lastLane) { const int v = S::col0(min(rowBase + STRIP, rows)); bOut[0] = v; bOut[W] = v; bOut[2 * W] = v; }
+
+            // ---- row extents of this strip -> iterations, first row not entered (jni/...c:441-449, :660-661)
+            {
+                int pMin = lane_up(minGood[R - 1], 1), pMax = lane_up(maxGood[R - 1], columns);
+                if (lead) { pMin = bMin; pMax = bMax; }
+                long long it = 0;
+                int firstNoEnter = INT_MAX;
+                long long itersRow[R];
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    const int row = r0 + k;
+                    itersRow[k] = 0;
+                    if (rowValid[k]) {
+                        const int hasGood = minGood[k] >= 0;
+                        const int colStart = pMin, colStop = pMax;
+                        const bool enter = pMin >= 0 && colStart >= 0 && colStop >= colStart;
+                        if (!enter && firstNoEnter == INT_MAX) firstNoEnter = row;
+                        const int endc = min(columns, max(colStop, hasGood ? maxGood[k] : -2) + 1);
+                        itersRow[k] = (long long)(endc - colStart + 1);
+                        if (row == rows) { lastColStart = colStart; lastHasGood = hasGood; }
+                    }
+                    pMin = minGood[k]; pMax = maxGood[k];
+                }
+                int g = firstNoEnter;
+                for (int d = 1; d < 64; d <<= 1) g = min(g, __shfl_xor(g, d, 64));
+                noEnterRow = min(noEnterRow, g);
+#pragma unroll
+                for (int k = 0; k < R; k++) if (rowValid[k] && r0 + k < noEnterRow) it += itersRow[k];
+                for (int d = 1; d < 64; d <<= 1) it += __shfl_xor(it, d, 64);
+                iters += it;
+            }
+            // the last row's extents for the next strip
+            bMin = __builtin_amdgcn_readlane(minGood[R - 1], 63);
+            bMax = __builtin_amdgcn_readlane(maxGood[R - 1], 63);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the boundary row is in L2 before the next strip reads it
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            __builtin_amdgcn_wave_barrier();
+            if (limited && noEnterRow <= rows) break;                // the fill died inside this strip: no row below is entered
+        }
+        if (!limited) iters = (long long)rows * columns;
+
+        // ------------------------------------------------------------------ result[] (as msa_fill_fast.hip)
+        const int ownerLane = ((rows - 1) % STRIP) / R;
+        int bScore, bCol, bState, bPacked;
+        {
+            int sx = bestMc >= 0 ? (bestM & S::SMASK) : INT_MIN, cbest = bestMc, st = 0, pk = bestM;
+            if (bestDc >= 0 && (bestD & S::SMASK) > sx) { sx = bestD & S::SMASK; cbest = bestDc; st = 1; pk = bestD; }
+            if (bestIc >= 0 && (bestI & S::SMASK) > sx) { sx = bestI & S::SMASK; cbest = bestIc; st = 2; pk = bestI; }
+            bScore = __shfl(sx, ownerLane, 64); bCol = __shfl(cbest, ownerLane, 64); bState = __shfl(st, ownerLane, 64); bPacked = __shfl(pk, ownerLane, 64);
+            lastColStart = __shfl(lastColStart, ownerLane, 64); lastHasGood = __shfl(lastHasGood, ownerLane, 64);
+        }
+        int res1, res2, res3, res4 = 0;
+        bool fillNull = false;
+        if (!limited) { res1 = bCol; res2 = bState; res3 = bScore >> S::OFF; }
+        else if (noEnterRow <= rows) { res1 = 1; res2 = 0; res3 = S::BADOFF; res4 = 1; fillNull = true; }
+        else if (!lastHasGood) { res1 = max(1, lastColStart - 1); res2 = 0; res3 = subfloor; res4 = 1; fillNull = true; }
+        else if (bScore < minScoreOff) { res1 = bCol; res2 = bState; res3 = bScore; res4 = 1; fillNull = true; }
+        else { res1 = bCol; res2 = bState; res3 = bScore >> S::OFF; }
+
+        // ------------------------------------------------------------------ score2 + traceback2 on the records
+        const bool wantScore = !fillNull && (jb.flags & BBMSA_DO_SCORE);
+        const bool wantTrace = !fillNull && (jb.flags & BBMSA_DO_TRACEBACK) && p.match != nullptr;
+        int sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int scoreLen = 0, matchLen = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        auto nibble = [&](int row, int col) -> unsigned {
+            const int s = (row - 1) / STRIP, lr = (row - 1) - s * STRIP;
+            const int ol = lr / R, ok = lr - ol * R, ot = col + ol;
+            const unsigned dw = load_coherent(dirSlot + (long long)s * p.dir_strip_dwords + ((long long)(ot >> 3) * R + ok) * 64 + ol);
+            return (dw >> ((ot & 7) * 4)) & 15u;
+        };
+        if (wantScore || wantTrace) {
+            int row = rows, col = res1, state = res2, n = 0, gapSyms = 0, stateTime = 0;
+            while (row > 0 && col > 0) {
+                if (state == 0) {
+                    const int rr = row - lane, cq = col - lane;       // diagonal run: lane l looks at cell (row-l, col-l)
+                    const bool inside = rr >= 1 && cq >= 1;
+                    const unsigned nibv = inside ? nibble(rr, cq) : 0u;
+                    const bool brk = !inside || (nibv & 3u) != 0u;
+                    const unsigned long long bal = __ballot(brk);
+                    const int fb = bal ? __builtin_ctzll(bal) : 64;
+                    const int fbInside = __shfl((int)inside, min(fb, 63), 64);
+                    const int fbPrev = __shfl((int)(nibv & 3u), min(fb, 63), 64);
+                    const int consumed = (fb < 64 && fbInside) ? fb + 1 : fb;
+                    if (wantTrace && lane < consumed) {
+                        const int cb = rd[rr - 1], rb = colinfo[cq].y;
+                        tmp[n + lane] = (cb == rb) ? 'm' : ((!fully_defined(cb) || !fully_defined(rb)) ? 'N' : 'S');
+                    }
+                    stateTime += fb;
+                    if (fb < 64 && fbInside) { stateTime = 0; state = fbPrev; }
+                    row -= consumed; col -= consumed; n += consumed;
+                } else {
+                    const unsigned nibv = nibble(row, col);
+                    int prev;
+                    if (state == 1) {
+                        prev = (nibv & 4u) ? 1 : 0;
+                        const int rb = colinfo[col].y;
+                        if (wantTrace && lane == 0) tmp[n] = (rb == '-') ? '-' : 'D';
+                        if (rb == '-') gapSyms++;
+                        col--;
+                    } else {
+                        prev = (nibv & 8u) ? 2 : 0;
+                        if (wantTrace && lane == 0) tmp[n] = (col >= columns) ? 'Y' : 'I';
+                        row--;
+                    }
+                    n++;
+                    if (prev == state) stateTime++; else stateTime = 0;
+                    state = prev;
+                }
+            }
+            int colS = col;
+            if (row > colS) colS -= row;
+            const int bestRefStart = a + colS, bestRefStop = a + res1 - 1;
+            int padLeft = 0, padRight = 0;
+            if (bestRefStart < a) padLeft = max(0, a - bestRefStart);
+            else if (bestRefStart == a && state == 2) padLeft = stateTime;
+            const int bW = (jb.flags & BBMSA_INTERNAL_GAPPED) ? jb.ref_len : b;
+            if (bestRefStop > bW) padRight = max(0, bestRefStop - bW);
+            else if (bestRefStop == bW && res2 == 2) padRight = bPacked & S::TMASK;
+            if (wantScore) {
+                sc[0] = bScore >> S::OFF; sc[1] = bestRefStart; sc[2] = bestRefStop; sc[3] = rows; sc[4] = res1; sc[5] = res2;
+                sc[6] = padLeft; sc[7] = padRight;
+                scoreLen = (padLeft > 0 || padRight > 0) ? 8 : 6;
+                if (scoreLen == 6) { sc[6] = 0; sc[7] = 0; }
+            }
+            if (wantTrace) {
+                const int xs = (col != row) ? row : 0;                // leftover read bases become 'X'
+                for (int i = lane; i < xs; i += 64) tmp[n + i] = 'X';
+                n += xs;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                __builtin_amdgcn_wave_barrier();
+                uint8_t *out = p.match + j * (long long)p.match_stride;
+                const int totalLen = n + gapSyms * (kGapLen - 1);
+                if (totalLen > p.match_stride) matchLen = -1;
+                else if (gapSyms == 0) {
+                    for (int i = lane; i < n; i += 64) out[i] = ld_agent_u8(tmp + n - 1 - i);
+                    matchLen = n;
+                } else {
+                    if (lane == 0) {
+                        int o = 0;
+                        for (int i = n - 1; i >= 0; i--) {
+                            const uint8_t ch = ld_agent_u8(tmp + i);
+                            if (ch != '-') out[o++] = ch;
+                            else for (int q = 0; q < kGapLen; q++) out[o++] = 'D';
+                        }
+                    }
+                    matchLen = totalLen;
+                }
+            }
+        }
+        if (lane == 0) {
+            bbmsa_result r;
+            r.result[0] = rows; r.result[1] = res1; r.result[2] = res2; r.result[3] = res3; r.result[4] = res4;
+            r.status = (fillNull && mode == BBMSA_FILL_LIMITED) ? BBMSA_ST_NULL : BBMSA_ST_OK;
+            r.iterations = iters;
+            for (int i = 0; i < 8; i++) r.score[i] = sc[i];
+            r.score_len = scoreLen; r.match_len = matchLen;
+            r.fill_kind = limited ? 0 : 1; r.columns = columns;
+            p.results[j] = r;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+constexpr int kStripR = 8;           // rows per lane: strips of 512 rows
+template __global__ void msa_fill_strip_kernel<Scheme9PacBio, kStripR>(const StripParams);
+
+int strip_rows_per_lane() { return kStripR; }
+const void *strip_kernel_pacbio() { return (const void *)msa_fill_strip_kernel<Scheme9PacBio, kStripR>; }
+
+}  // namespace bbmsa

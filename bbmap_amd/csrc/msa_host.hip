@@ -14,6 +14,14 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
                      const uint8_t *reads, const uint8_t *refs, bbmsa_result *results, uint8_t *match, int32_t match_stride);
 
 namespace bbmsa {
+struct StripParams {            // msa_fill_strip.hip
+    const bbmsa_job *jobs; const uint8_t *reads; const uint8_t *refs; bbmsa_result *results; uint8_t *match;
+    long long njobs; const unsigned int *njobs_dev; unsigned int *queue; unsigned int *dirbuf;
+    long long dir_slot_dwords, dir_strip_dwords; int *boundary; uint8_t *tmpbuf; int *slow_list; unsigned int *slow_count;
+    int match_stride; int maxRows, maxColumns; int bandwidth; float bandwidthRatio;
+};
+int strip_rows_per_lane();
+const void *strip_kernel_pacbio();
 const void *fast_kernel_for(int R, bool banded);
 template <class S> __global__ void msa_fill_generic_kernel(const GenericParams p);
 __global__ void msa_fill_narrow_kernel(const NarrowParams p);
@@ -90,20 +98,41 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
         return BBMAP_OK;
     }
     if (scheme != BBMSA_SCHEME_11TS) {
-        // 9PacBio: every job runs in the generic kernel (the wavefront and narrow kernels are written for the 11ts constants
-        // and for reads of at most 640 bases)
+        // 9PacBio: the strip-tiled wavefront kernel (msa_fill_strip.hip), one alignment per wavefront; banded fills and windows
+        // narrower than the read are handed to the one-job-per-thread kernel
         HIP_TRY(hipMalloc(&c->d_counters, 64));
         HIP_TRY(hipMemset(c->d_counters, 0, 64));
         const long long planeInts = (long long)(cfg->maxRows + 1) * (cfg->maxColumns + 2);
         const long long perThread = 3 * planeInts * 4;
         long long budget = (long long)env_int("BBMSA_GENERIC_SCRATCH_MB", 40960) << 20;   // 6019 x 7600 (mapPacBio) needs 35 GB for one wavefront of matrices
         long long threads = budget / perThread;
-        if (threads > 16384) threads = 16384;
+        if (threads > 4096) threads = 4096;
         threads = (threads / 64) * 64;
         if (threads < 64) return fail(BBMAP_E_NOMEM, "bbmsa_create: BBMSA_GENERIC_SCRATCH_MB cannot hold one wavefront of scratch matrices for this maxRows x maxColumns");
         c->genThreads = (int)threads;
         HIP_TRY(hipMalloc(&c->d_matrix, (size_t)(threads * perThread)));
         HIP_TRY(hipMalloc(&c->d_limits, (size_t)(threads * (cfg->maxRows + cfg->maxColumns + 4) * 4)));
+        {
+            const int R = bbmsa::strip_rows_per_lane();
+            c->stripLds = (cfg->maxColumns + 2) * 8;
+            const void *kfn = bbmsa::strip_kernel_pacbio();
+            if (c->stripLds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, c->stripLds));
+            int per = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kfn, 64, c->stripLds));
+            if (per < 1) per = 1;
+            if (per > 8) per = 8;
+            c->stripBlocks = c->numCUs * per;
+            const int strips = (cfg->maxRows + 64 * R - 1) / (64 * R);
+            c->stripDwords = (long long)(((cfg->maxColumns + 64) >> 3) + 1) * R * 64;
+            c->stripSlotDwords = c->stripDwords * strips;
+            // traceback records: 4 bits per cell of every resident job (23 MB per 6,000 x 7,600 job)
+            long long dirBudget = (long long)env_int("BBMSA_STRIP_DIR_MB", 32768) << 20;
+            while (c->stripBlocks > c->numCUs && (long long)c->stripBlocks * c->stripSlotDwords * 4 > dirBudget) c->stripBlocks -= c->numCUs;
+            while (c->stripBlocks > 1 && (long long)c->stripBlocks * c->stripSlotDwords * 4 > dirBudget) c->stripBlocks /= 2;
+            HIP_TRY(hipMalloc(&c->d_dir, (size_t)((long long)c->stripBlocks * c->stripSlotDwords * 4)));
+            HIP_TRY(hipMalloc(&c->d_stripBoundary, (size_t)((long long)c->stripBlocks * 6 * (cfg->maxColumns + 2) * 4)));
+            HIP_TRY(hipMalloc(&c->d_stripTmp, (size_t)((long long)c->stripBlocks * (cfg->maxRows + cfg->maxColumns + 8))));
+        }
         for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
         guard.c = nullptr;
         *out = c;
@@ -217,6 +246,8 @@ extern "C" void bbmsa_destroy(bbmsa_ctx *c) {
     if (c->d_gref) (void)hipFree(c->d_gref);
     if (c->d_gaux) (void)hipFree(c->d_gaux);
     if (c->d_gjobs) (void)hipFree(c->d_gjobs);
+    if (c->d_stripBoundary) (void)hipFree(c->d_stripBoundary);
+    if (c->d_stripTmp) (void)hipFree(c->d_stripTmp);
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
@@ -248,13 +279,27 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
     HIP_TRY(hipSetDevice(c->device));
     if (c->legacyOnly) return fail(BBMAP_E_ARG, "bbmsa_align_batch_device: this context was created for bbmsa_fill_packed only (BBMSA_LEGACY_ONLY)");
     if (c->scheme != BBMSA_SCHEME_11TS) {
+        if (n_jobs > c->slowCap) {
+            if (c->d_slowList) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_slowList)); c->d_slowList = nullptr; }
+            HIP_TRY(hipMalloc(&c->d_slowList, (size_t)n_jobs * 4));
+            c->slowCap = n_jobs;
+        }
         HIP_TRY(hipMemsetAsync(c->d_counters, 0, 64, stream));
         HIP_TRY(hipEventRecord(c->ev[0], stream));
         HIP_TRY(hipEventRecord(c->ev[3], stream));
+        bbmsa::StripParams sp;
+        sp.jobs = jobs; sp.reads = reads; sp.refs = refs; sp.results = results; sp.match = match; sp.njobs = n_jobs; sp.njobs_dev = n_jobs_dev;
+        sp.queue = c->d_counters; sp.dirbuf = c->d_dir; sp.dir_slot_dwords = c->stripSlotDwords; sp.dir_strip_dwords = c->stripDwords;
+        sp.boundary = c->d_stripBoundary; sp.tmpbuf = c->d_stripTmp; sp.slow_list = c->d_slowList; sp.slow_count = c->d_counters + 1;
+        sp.match_stride = match_stride; sp.maxRows = c->cfg.maxRows; sp.maxColumns = c->cfg.maxColumns;
+        sp.bandwidth = c->cfg.bandwidth; sp.bandwidthRatio = c->cfg.bandwidthRatio;
+        long long sblocks = n_jobs < c->stripBlocks ? n_jobs : c->stripBlocks;
+        void *sargs[] = {&sp};
+        HIP_TRY(hipLaunchKernel(bbmsa::strip_kernel_pacbio(), dim3((unsigned)sblocks), dim3(64), sargs, (size_t)c->stripLds, stream));
         HIP_TRY(hipEventRecord(c->ev[1], stream));
         bbmsa::GenericParams gp;
         gp.jobs = jobs; gp.reads = reads; gp.refs = refs; gp.results = results; gp.match = match;
-        gp.list = nullptr; gp.list_count = nullptr; gp.njobs = n_jobs; gp.njobs_dev = n_jobs_dev;
+        gp.list = c->d_slowList; gp.list_count = c->d_counters + 1; gp.njobs = n_jobs; gp.njobs_dev = n_jobs_dev;
         gp.matrix = c->d_matrix; gp.limits = c->d_limits; gp.queue = c->d_counters + 2;
         gp.match_stride = match_stride; gp.maxRows = c->cfg.maxRows; gp.maxColumns = c->cfg.maxColumns;
         gp.bandwidth = c->cfg.bandwidth; gp.bandwidthRatio = c->cfg.bandwidthRatio;

@@ -138,3 +138,52 @@ def test_pacbio_gapped_reference_jobs():
             assert g["match"] == tb
     al.ctx.close()
     assert nonnull > 6
+
+
+def _pacbio_read(rng, genome, s, L, err):
+    rd = bytearray(genome[s:s + L])
+    i = 0
+    while i < len(rd):
+        x = rng.random()
+        if x < err * 0.45:
+            rd.insert(i, ord(rng.choice("ACGT"))); i += 2
+        elif x < err * 0.8 and len(rd) > 30:
+            del rd[i]
+        elif x < err:
+            rd[i] = ord(rng.choice("ACGT")); i += 1
+        else:
+            i += 1
+    return bytes(rd)
+
+
+def test_pacbio_full_size_reads_cross_many_strips():
+    """mapPacBio's own limits (ALIGN_ROWS 6020, ALIGN_COLUMNS 7600, current/align2/BBMapThreadPacBio.java:27-28): reads of up to
+    6,019 bases with 13-17 % PacBio errors against windows of up to 7,600 columns -- twelve 512-row strips, the boundary row
+    handed through HBM, the traceback walking back across every strip border -- limited, Java-gated and unlimited fills."""
+    rng = random.Random(17)
+    genome = rand_seq(rng, 9000)
+    probs = []
+    for L, err, pad in ((6019, 0.15, 40), (5200, 0.13, 700), (4097, 0.17, 8), (513, 0.1, 30), (512, 0.0, 4), (1025, 0.15, 300)):
+        s = rng.randint(800, 1200)
+        rd = _pacbio_read(rng, genome, s, L, err)[:6019]
+        a, b = s - pad, min(len(genome) - 1, s + L + pad)
+        if b - a + 1 > 7600:
+            b = a + 7599
+        maxq = 90 + 100 * (len(rd) - 1)
+        probs.append((rd, genome, a, b, int(maxq * 0.3)))
+    check(probs, M.FILL_AND_SCORE_LIMITED | M.DO_TRACEBACK, maxRows=6019, maxColumns=7600)
+    check(probs[:2], M.FILL_LIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK, maxRows=6019, maxColumns=7600)
+    check(probs[2:4], M.FILL_UNLIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK, maxRows=6019, maxColumns=7600)
+
+
+def test_pacbio_fill_dies_inside_a_strip_and_narrow_windows_go_to_the_generic_kernel():
+    rng = random.Random(23)
+    genome = rand_seq(rng, 6000)
+    junk = rand_seq(rng, 1500)                       # unrelated read: the limited fill runs out of good cells early
+    rd = _pacbio_read(rng, genome, 900, 1400, 0.1)
+    maxq = 90 + 100 * 1399
+    probs = [(junk, genome, 100, 1800, int(0.5 * (90 + 100 * 1499))),
+             (rd, genome, 890, 2320, int(maxq * 0.4)),
+             (rd, genome, 890, 2200, int(maxq * 0.2)),          # window narrower than the read by more than two columns
+             (rd[:700], genome, 890, 1630, int(0.99 * (90 + 100 * 699)))]
+    check(probs, M.FILL_LIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK, maxRows=1600, maxColumns=2000)
