@@ -71,7 +71,8 @@ __device__ __forceinline__ uint8_t ld_agent_u8(const uint8_t *p) { return __hip_
 template <class S, int R>
 __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p) {
     extern __shared__ int lds[];
-    int2 *colinfo = reinterpret_cast<int2 *>(lds);                   // [c] = {horizLimit[c] + ONE, ref byte of column c}
+    int *colHl = lds;                                                // [c] = horizLimit[c] + ONE
+    uint8_t *colRef = reinterpret_cast<uint8_t *>(lds + p.maxColumns + 2);   // [c] = reference byte of column c (5 bytes of LDS per column)
     constexpr int ONE = 1 << S::OFF;                                 // one score unit: a packed cell p = score|time satisfies
                                                                      // score <= L  <=>  p < L + ONE for bounds that are multiples of ONE
     constexpr int STRIP = 64 * R;
@@ -143,15 +144,15 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
         const int nstrips = (rows + STRIP - 1) / STRIP;
 
         // column info: reference bytes by the whole wave, horizLimit by lane 0 (jni/...c:427-438)
-        for (int c = lane + 1; c <= columns; c += 64) colinfo[c].y = rf[c - 1];
+        for (int c = lane + 1; c <= columns; c += 64) colRef[c] = rf[c - 1];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             int h = minScoreOff;
             bool prevDef = false;
             for (int i = columns - 1; i >= 0; i--) {
-                colinfo[i + 1].x = (limited ? h : kNegInf) + ONE;
-                const int cb = colinfo[i + 1].y;
+                colHl[i + 1] = (limited ? h : kNegInf) + ONE;
+                const int cb = colRef[i + 1];
                 const bool def = fully_defined(cb);
                 const int cost = def ? (prevDef ? S::MATCH2 : S::MATCH) : ((prevDef && cb == '-') ? S::DEL : 0);
                 h = max(h - cost, floorv);
@@ -244,8 +245,7 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
                 if (c >= 1) {
                     const bool inRange = c <= columns;
                     const int cc = min(c, columns);
-                    const int2 ci = colinfo[cc];
-                    const int hlP = ci.x, ref1 = ci.y;
+                    const int hlP = colHl[cc], ref1 = colRef[cc];
                     const int ref0 = c < 2 ? '!' : lastRef;
                     const bool gap = ref1 == '-', refN = ref1 == 'N';
                     const int refPen = refN ? S::DEL_REF_N : (gap ? S::GAP : 0);
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
                     const int fbPrev = __shfl((int)(nibv & 3u), min(fb, 63), 64);
                     const int consumed = (fb < 64 && fbInside) ? fb + 1 : fb;
                     if (wantTrace && lane < consumed) {
-                        const int cb = rd[rr - 1], rb = colinfo[cq].y;
+                        const int cb = rd[rr - 1], rb = colRef[cq];
                         tmp[n + lane] = (cb == rb) ? 'm' : ((!fully_defined(cb) || !fully_defined(rb)) ? 'N' : 'S');
                     }
                     stateTime += fb;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
                     int prev;
                     if (state == 1) {
                         prev = (nibv & 4u) ? 1 : 0;
-                        const int rb = colinfo[col].y;
+                        const int rb = colRef[col];
                         if (wantTrace && lane == 0) tmp[n] = (rb == '-') ? '-' : 'D';
                         if (rb == '-') gapSyms++;
                         col--;

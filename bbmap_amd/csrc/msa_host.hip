@@ -114,7 +114,7 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
         HIP_TRY(hipMalloc(&c->d_limits, (size_t)(threads * (cfg->maxRows + cfg->maxColumns + 4) * 4)));
         {
             const int R = bbmsa::strip_rows_per_lane();
-            c->stripLds = (cfg->maxColumns + 2) * 8;
+            c->stripLds = (cfg->maxColumns + 2) * 4 + ((cfg->maxColumns + 2 + 7) & ~7);     // horizLimit ints + reference bytes
             const void *kfn = bbmsa::strip_kernel_pacbio();
             if (c->stripLds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, c->stripLds));
             int per = 0;
