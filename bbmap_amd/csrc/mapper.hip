@@ -17,10 +17,13 @@
 // Every function names the reference lines it follows.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "bbmap_amd.h"
@@ -37,6 +40,7 @@ constexpr int TIP_MAX_TIPLEN = 8, OUTER_DIST_MULT = 14, OUTER_DIST_DIV = 32;    
 constexpr int MIN_TRIM_SINGLE = 3, MIN_TRIM_PAIRED = 2;                           // BBMapThread.java:62-63
 constexpr int CLEARZONE1E = 258;                                                  // AbstractMapThread.java:142: 2*100-70+127+1
 constexpr int GAPPED_BIT = 1 << 30;
+constexpr int DEAD_MARK = 0x7fffffff;
 
 struct Settings {
     float minRatio, ratioPaired, ratioPreRescue;
@@ -289,23 +293,31 @@ template <bool BYPOS> __device__ void sort_sites(Site *s, int n) {
         s[j + 1] = t;
     }
 }
-// order-preserving removal of the entries whose bit is set in `dead` (Tools.condenseStrict); lists hold at most 64 sites
-__device__ int condense(Site *s, int n, unsigned long long dead) {
-    if (!dead) return n;
+// Entries marked for removal (Tools.condenseStrict's nulls): the first 64 list positions in a register mask, positions beyond
+// (only the overflow tier has lists that long) as a mark in the record itself (reserved[1], zero in every list entry otherwise).
+struct DeadSet {
+    unsigned long long lo = 0; bool hi = false;
+    __device__ void mark(Site *s, int i) { if (i < 64) lo |= 1ull << i; else { s[i].reserved[1] = DEAD_MARK; hi = true; } }
+    __device__ bool dead(const Site *s, int i) const { return i < 64 ? ((lo >> i) & 1) != 0 : (hi && s[i].reserved[1] == DEAD_MARK); }
+    __device__ bool any() const { return lo != 0 || hi; }
+};
+// order-preserving removal of the marked entries
+__device__ int condense(Site *s, int n, const DeadSet &dead) {
+    if (!dead.any()) return n;
     int m = 0;
-    for (int i = 0; i < n; i++) if (!((dead >> i) & 1)) { if (m != i) s[m] = s[i]; m++; }
+    for (int i = 0; i < n; i++) if (!dead.dead(s, i)) { if (m != i) s[m] = s[i]; m++; }
     return m;
 }
 // Tools.trimSitesBelowCutoff (Tools.java:1113-1161)
 __device__ int trim_below_cutoff(Site *s, int n, int cutoff, bool retainPaired, int minRetain, int maxRetain) {
     if (n <= minRetain) return n;
     if (n > maxRetain) n = maxRetain;
-    unsigned long long dead = 0;
+    DeadSet dead;
     int removed = 0;
     const int maxToRemove = n - minRetain;
     for (int i = n - 1; i >= 0; i--) {
         if (!s[i].semiperfect && s[i].score < cutoff && (!retainPaired || s[i].pairedScore <= 0)) {       // retainSemiperfect is always true here
-            dead |= 1ull << i; removed++;
+            dead.mark(s, i); removed++;
             if (removed >= maxToRemove) break;
         }
     }
@@ -352,7 +364,7 @@ __device__ bool positional_match(const Site &a, const Site &b, bool testGaps) { 
 __device__ int merge_duplicate_sites(Site *s, int n) {
     if (n < 2) return n;
     sort_sites<true>(s, n);
-    unsigned long long dead = 0;
+    DeadSet dead;
     int ai = 0;
     for (int i = 1; i < n; i++) {
         Site &a = s[ai];
@@ -371,7 +383,7 @@ __device__ int merge_duplicate_sites(Site *s, int n) {
             a.perfect = (a.perfect || b.perfect);
             a.semiperfect = (a.semiperfect || b.semiperfect);
             if (takeB) { a.ngaps = b.ngaps; for (int q = 0; q < BBMSA_MAX_GAPS; q++) a.gaps[q] = b.gaps[q]; }
-            dead |= 1ull << i;
+            dead.mark(s, i);
         } else ai = i;
     }
     return condense(s, n, dead);
@@ -381,10 +393,10 @@ __device__ int remove_low_quality_paired(Site *s, int n, int maxSw, float multSi
     if (n == 0) return 0;
     const int thresh = (int)__fmul_rn((float)maxSw, multSingle), threshPaired = (int)__fmul_rn((float)maxSw, multPaired);
     if (s[0].score < threshPaired) return 0;
-    unsigned long long dead = 0;
+    DeadSet dead;
     for (int i = n - 1; i >= 0; i--) {
-        if (s[i].pairedScore > 0) { if (s[i].slowScore < threshPaired) dead |= 1ull << i; }
-        else if (s[i].slowScore < thresh) dead |= 1ull << i;
+        if (s[i].pairedScore > 0) { if (s[i].slowScore < threshPaired) dead.mark(s, i); }
+        else if (s[i].slowScore < thresh) dead.mark(s, i);
     }
     return condense(s, n, dead);
 }
@@ -892,6 +904,31 @@ __global__ __launch_bounds__(128) void rescue_finish_kernel(const Dev D) {
     D.mcount[rl] = merge_duplicate_sites(sl, nl);
 }
 
+// ---------------------------------------------------------------------------------------------- overflow tier
+// units (reads, or pairs in paired mode) whose site list did not fit: appended in any order, sorted on the host
+__global__ __launch_bounds__(128) void collect_overflow_kernel(const int *mcount, long long nunits, int paired, int *ids, unsigned *count) {
+    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nunits) return;
+    const bool over = paired ? (mcount[2 * u] < 0 || mcount[2 * u + 1] < 0) : mcount[u] < 0;
+    if (over) ids[atomicAdd(count, 1u)] = (int)u;
+}
+__global__ __launch_bounds__(128) void gather_reads_kernel(const bbidx_read *reads, const int *ids, int nunits, int paired, bbidx_read *sub, int *readIds) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nunits) return;
+    if (paired) {
+        const int r = 2 * ids[i];
+        sub[2 * i] = reads[r]; sub[2 * i + 1] = reads[r + 1]; readIds[2 * i] = r; readIds[2 * i + 1] = r + 1;
+    } else { sub[i] = reads[ids[i]]; readIds[i] = ids[i]; }
+}
+// a read the tier mapped is marked in the main list (BBMAP_NSITES_IN_TIER); counts the reads that had overflowed and now have a list
+__global__ __launch_bounds__(128) void mark_tier_kernel(int *mcount, const int *tierCount, const int *readIds, int n, unsigned *resolved) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || tierCount[i] < 0) return;
+    const int r = readIds[i];
+    if (mcount[r] == -1) atomicAdd(resolved, 1u);
+    mcount[r] = BBMAP_NSITES_IN_TIER;
+}
+
 }  // namespace bbmapper
 
 // ================================================================================================= host side
@@ -916,10 +953,23 @@ struct bbmap_ctx {
     long long jobCap, gjobCap, rescCap;
     int matchStride, gmatchStride, maxRows, plainColumns;
     unsigned *h_counters;           // pinned
-    hipEvent_t ev[10];
+    hipEvent_t ev[12];
     bbmap_stats stats;
     long long nJobs, nGapped;
     bool ran;
+    // overflow tier: a second, small context with long site lists for the reads whose list did not fit max_sites
+    bbmap_ctx *tier;
+    bool ownsMsa;
+    int *d_tierUnits; bbidx_read *d_tierReads; int *d_tierReadIds;
+    long long tierReads;            // reads the tier mapped in the last batch
+    // The tier's pass runs beside the main pass (its reads are known once begin_kernel has run): its own stream, driven by its
+    // own host thread, joined at the end of the batch.
+    hipStream_t tierStream;
+    std::thread tierThread;
+    bool tierStarted;
+    int tierRc; char tierErr[320];
+    long long overAfterBegin;       // reads flagged by the probe (counters[3] after begin_kernel)
+    struct BatchArgs { int64_t n_reads; const bbidx_read *reads; uint8_t *bases; int64_t minus_delta; const int8_t *baseScores; const int32_t *keyinfo; } batch;
 };
 
 static thread_local char g_merr[320];
@@ -952,9 +1002,12 @@ extern "C" void bbmap_destroy(bbmap_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
-    if (c->msa) bbmsa_destroy(c->msa);
-    if (c->msaGapped) bbmsa_destroy(c->msaGapped);
-    for (int i = 0; i < 10; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->tierThread.joinable()) c->tierThread.join();
+    if (c->tier) bbmap_destroy(c->tier);
+    if (c->tierStream) (void)hipStreamDestroy(c->tierStream);
+    if (c->ownsMsa && c->msa) bbmsa_destroy(c->msa);
+    if (c->ownsMsa && c->msaGapped) bbmsa_destroy(c->msaGapped);
+    for (int i = 0; i < 12; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
 
@@ -969,11 +1022,12 @@ extern "C" int bbidx_get_chrom_table(bbidx_ctx *ix, int32_t *nchroms, const uint
     return BBMAP_OK;
 }
 
-extern "C" int bbmap_create(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx **out) {
+// parent != null: the overflow tier of `parent` (longer job logs per read)
+static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *parent, bbmap_ctx **out) {
     if (!index || !cfg || !out) return mfail(BBMAP_E_ARG, "bbmap_create: null argument");
     *out = nullptr;
     if (cfg->max_reads < 1 || cfg->max_read_len < 1 || cfg->max_read_len > 600) return mfail(BBMAP_E_ARG, "bbmap_create: max_reads >= 1 and max_read_len in 1..600");
-    if (cfg->max_sites < 1 || cfg->max_sites > 64) return mfail(BBMAP_E_ARG, "bbmap_create: max_sites must be 1..64 (a read's site list is handled with 64-bit masks)");
+    if (cfg->max_sites < 1 || cfg->max_sites > BBMAP_MAX_SITES_LIMIT) return mfail(BBMAP_E_ARG, "bbmap_create: max_sites must be 1..4096");
     if (cfg->paired && (cfg->max_reads & 1)) return mfail(BBMAP_E_ARG, "bbmap_create: paired mode takes an even number of reads");
     if (cfg->msaMaxColumns < 64 || cfg->msaMaxColumns > 4096) return mfail(BBMAP_E_ARG, "bbmap_create: msaMaxColumns must be 64..4096");
     if (cfg->device != index->device) return mfail(BBMAP_E_ARG, "bbmap_create: the index lives on another device");
@@ -1009,17 +1063,19 @@ extern "C" int bbmap_create(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx
     mc.maxColumns = cfg->fastCols > 0 ? cfg->fastCols : 256;
     if (mc.maxColumns > cfg->msaMaxColumns) mc.maxColumns = cfg->msaMaxColumns;
     c->plainColumns = mc.maxColumns;
-    if ((rc = bbmsa_create(&mc, &c->msa)) != BBMAP_OK) return bail(rc);
     bbmsa_config gc = mc;
     gc.maxColumns = cfg->msaMaxColumns;
     gc.reserved[0] = 64; gc.reserved[1] = 640 < gc.maxColumns ? 640 : gc.maxColumns;
+    (void)parent;                   // the tier runs beside its parent's pass: DP contexts of its own
+    c->ownsMsa = true;
+    if ((rc = bbmsa_create(&mc, &c->msa)) != BBMAP_OK) return bail(rc);
     if ((rc = bbmsa_create(&gc, &c->msaGapped)) != BBMAP_OK) return bail(rc);
     const long long n = cfg->max_reads;
     const int cap = cfg->max_sites;
     const int jpr = cfg->jobsPerRead > 0 ? cfg->jobsPerRead : 3;
     c->jobCap = n * jpr + 1024;
-    c->gjobCap = n / 8 + 4096;
-    c->rescCap = n * 2 + 1024;
+    c->gjobCap = parent ? n * 16 + 4096 : n / 8 + 4096;
+    c->rescCap = parent ? n * 64 + 1024 : n * 2 + 1024;
     c->matchStride = ((maxRows + c->plainColumns + 15) / 16) * 16;
     // a gapped match string expands every gap symbol to 128 'D's (traceback, MultiStateAligner11tsJNI.java:481-493)
     c->gmatchStride = ((maxRows + gc.maxColumns + 2 + 128 * 8 + 15) / 16) * 16;
@@ -1049,7 +1105,33 @@ extern "C" int bbmap_create(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx
         if (hipMemset(c->d_chromMin, 0, 4 * ((size_t)nch + 1)) != hipSuccess) return bail(mfail(BBMAP_E_HIP, "bbmap_create: memset failed"));
     }
     if (hipHostMalloc((void **)&c->h_counters, 64 * 4) != hipSuccess) return bail(mfail(BBMAP_E_NOMEM, "bbmap_create: pinned allocation failed"));
-    for (int i = 0; i < 10; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) return bail(mfail(BBMAP_E_HIP, "bbmap_create: hipEventCreate failed"));
+    for (int i = 0; i < 12; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) return bail(mfail(BBMAP_E_HIP, "bbmap_create: hipEventCreate failed"));
+    *out = c;
+    return BBMAP_OK;
+}
+
+extern "C" int bbmap_create(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx **out) {
+    bbmap_ctx *c = nullptr;
+    MTRY(create_impl(index, cfg, nullptr, &c));
+    // reserved[1]: reads the overflow tier holds (0 = 4096, < 0 = no tier); reserved[2]: its max_sites (0 = 1024)
+    if (cfg->reserved[1] >= 0) {
+        bbmap_config tc = *cfg;
+        long long tn = cfg->reserved[1] > 0 ? cfg->reserved[1] : 4096;
+        if (tn > cfg->max_reads) tn = cfg->max_reads;
+        if (cfg->paired) tn &= ~1ll;
+        tc.max_reads = (int32_t)tn;
+        tc.max_sites = cfg->reserved[2] > 0 ? cfg->reserved[2] : 1024;
+        tc.jobsPerRead = 128;
+        tc.reserved[1] = -1;
+        if (tn >= (cfg->paired ? 2 : 1) && tc.max_sites > cfg->max_sites) {
+            const int rc = create_impl(index, &tc, c, &c->tier);
+            if (rc != BBMAP_OK) { bbmap_destroy(c); return rc; }
+            const long long units = cfg->paired ? cfg->max_reads / 2 : cfg->max_reads;
+            if (dalloc(c, &c->d_tierUnits, (size_t)units + 1) != BBMAP_OK || dalloc(c, &c->d_tierReads, (size_t)tn) != BBMAP_OK ||
+                dalloc(c, &c->d_tierReadIds, (size_t)tn) != BBMAP_OK) { bbmap_destroy(c); return BBMAP_E_NOMEM; }
+            if (hipStreamCreateWithFlags(&c->tierStream, hipStreamNonBlocking) != hipSuccess) { bbmap_destroy(c); return mfail(BBMAP_E_HIP, "bbmap_create: hipStreamCreate failed"); }
+        }
+    }
     *out = c;
     return BBMAP_OK;
 }
@@ -1077,22 +1159,18 @@ static void add_dp_ms(bbmap_ctx *c, bool plain, bool gapped) {
     if (gapped && bbmsa_last_kernel_ms3(c->msaGapped, k3) == BBMAP_OK) c->stats.ms_dp_gapped += k3[0] + k3[1] + k3[2];
 }
 
-extern "C" int bbmap_map_batch_device(bbmap_ctx *c, void *stream_, int64_t n_reads, const bbidx_read *reads, uint8_t *bases,
-                                      int64_t minus_delta, const int8_t *baseScores, const int32_t *keyinfo) {
-    if (!c) return mfail(BBMAP_E_ARG, "bbmap_map_batch_device: null context");
-    if (n_reads < 0 || n_reads > c->cfg.max_reads) return mfail(BBMAP_E_ARG, "bbmap_map_batch_device: more reads than the context was made for");
-    if (c->cfg.paired && (n_reads & 1)) return mfail(BBMAP_E_ARG, "bbmap_map_batch_device: paired mode takes an even number of reads");
-    if (n_reads == 0) { c->ran = false; return BBMAP_OK; }
-    if (!reads || !bases || !baseScores || !keyinfo) return mfail(BBMAP_E_ARG, "bbmap_map_batch_device: null buffer");
-    hipStream_t stream = (hipStream_t)stream_;
-    MHIP(hipSetDevice(c->cfg.device));
+static void tier_start_async(bbmap_ctx *c, long long found);
+
+// one context's pass over `n_reads` read records
+static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const bbidx_read *reads, uint8_t *bases,
+                       int64_t minus_delta, const int8_t *baseScores, const int32_t *keyinfo, bool writeRc) {
     memset(&c->stats, 0, sizeof c->stats);
     c->stats.reads = n_reads;
     MHIP(hipMemsetAsync(c->d_counters, 0, 64 * 4, stream));
     MHIP(hipEventRecord(c->ev[0], stream));
     // ---- probe (BBIndex.findAdvanced); reverse complements are written on the way
     MTRY(bbidx_find_batch_device_rc(c->index, stream, n_reads, reads, bases, baseScores, keyinfo, c->d_psites, c->cfg.max_sites,
-                                    c->d_pnsites, bases + minus_delta));
+                                    c->d_pnsites, writeRc ? bases + minus_delta : nullptr));
     MHIP(hipEventRecord(c->ev[1], stream));
     bbmapper::Dev D; memset(&D, 0, sizeof D);
     D.S = c->S; D.reads = reads; D.bases = bases; D.minusDelta = minus_delta; D.nreads = n_reads;
@@ -1107,6 +1185,11 @@ extern "C" int bbmap_map_batch_device(bbmap_ctx *c, void *stream_, int64_t n_rea
     const long long units = c->cfg.paired ? n_reads / 2 : n_reads;
     hipLaunchKernelGGL(bbmapper::begin_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, D);
     MHIP(hipGetLastError());
+    if (c->tier) {                       // the units the probe flagged: known now, so the tier can work beside the rest of this pass
+        hipLaunchKernelGGL(bbmapper::collect_overflow_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, c->d_mcount, units, c->cfg.paired,
+                           c->d_tierUnits, c->d_counters + 16);
+        MHIP(hipGetLastError());
+    }
     MHIP(hipEventRecord(c->ev[2], stream));
     hipLaunchKernelGGL(bbmapper::score_kernel, dim3((unsigned)((n_reads + TB - 1) / TB)), dim3(TB), 0, stream, D);
     MHIP(hipGetLastError());
@@ -1121,6 +1204,13 @@ extern "C" int bbmap_map_batch_device(bbmap_ctx *c, void *stream_, int64_t n_rea
         hipLaunchKernelGGL(bbmapper::slow_round_kernel, dim3((unsigned)((nActive + TB - 1) / TB)), dim3(TB), 0, stream, D);
         MHIP(hipGetLastError());
         MTRY(read_counters(c, stream));
+        if (round == 0) {
+            // the probe is over: its statistics are read now (the tier's probe launch reuses the index context's counters)
+            float pms = 0; long long ps[5];       // (not for the tier's own pass: the synchronous copy inside would wait for the main stream)
+            if (writeRc && bbidx_last_stats(c->index, (int64_t *)ps, &pms) == BBMAP_OK) for (int i = 0; i < 5; i++) c->stats.probe_stats[i] = ps[i];
+            c->overAfterBegin = c->h_counters[3];
+            if (c->tier && c->h_counters[16] > 0) tier_start_async(c, c->h_counters[16]);
+        }
         add_dp_ms(c, ranPlainPrev, ranGappedPrev);
         const long long total = c->h_counters[0], gtotal = c->h_counters[1];
         if (total > c->jobCap || gtotal > c->gjobCap) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: job log full (raise bbmap_config.jobsPerRead)");
@@ -1186,9 +1276,119 @@ extern "C" int bbmap_map_batch_device(bbmap_ctx *c, void *stream_, int64_t n_rea
     (void)hipEventElapsedTime(&st.ms_finish, c->ev[4], c->ev[5]);
     (void)hipEventElapsedTime(&st.ms_rescue, c->ev[5], c->ev[6]);
     (void)hipEventElapsedTime(&st.ms_total, c->ev[0], c->ev[6]);
-    { float pms = 0; long long ps[5]; if (bbidx_last_stats(c->index, (int64_t *)ps, &pms) == BBMAP_OK) for (int i = 0; i < 5; i++) st.probe_stats[i] = ps[i]; }
     c->ran = true;
     return BBMAP_OK;
+}
+
+// The reference's ArrayList<SiteScore> has no capacity (BBIndex.java:1537-1604).  Reads whose list did not fit max_sites are
+// mapped again, from the probe on, by the tier context with its long lists (pairs as pairs); a read the tier cannot hold either
+// stays flagged.  The reads the PROBE flagged are known once begin_kernel has run, and the tier maps them on its own stream
+// beside the rest of the main pass.  A list can also outgrow max_sites when rescue appends to it (rare): then the tier runs once
+// more after the main pass, over all flagged reads.
+static int tier_pass(bbmap_ctx *c, hipStream_t s, long long found) {
+    bbmap_ctx *t = c->tier;
+    const bbmap_ctx::BatchArgs &B = c->batch;
+    const int paired = c->cfg.paired;
+    const unsigned TB = 128;
+    c->tierReads = 0; t->ran = false;
+    std::vector<int> ids((size_t)found);
+    MHIP(hipMemcpyAsync(ids.data(), c->d_tierUnits, 4 * (size_t)found, hipMemcpyDeviceToHost, s));
+    MHIP(hipStreamSynchronize(s));
+    std::sort(ids.begin(), ids.end());
+    const long long room = paired ? t->cfg.max_reads / 2 : t->cfg.max_reads;
+    const long long take = found < room ? found : room;           // the first `room` units in read order; the rest stay flagged
+    MHIP(hipMemcpyAsync(c->d_tierUnits, ids.data(), 4 * (size_t)take, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(bbmapper::gather_reads_kernel, dim3((unsigned)((take + TB - 1) / TB)), dim3(TB), 0, s, B.reads, c->d_tierUnits, (int)take, paired,
+                       c->d_tierReads, c->d_tierReadIds);
+    MHIP(hipGetLastError());
+    MHIP(hipStreamSynchronize(s));                                // `ids` is done with
+    const long long tn = paired ? 2 * take : take;
+    // the reverse complements of these reads are in place (the main probe wrote them)
+    MTRY(map_records(t, s, tn, c->d_tierReads, B.bases, B.minus_delta, B.baseScores, B.keyinfo, false));
+    c->tierReads = tn;
+    return BBMAP_OK;
+}
+
+static void tier_start_async(bbmap_ctx *c, long long found) {
+    c->tierStarted = true; c->tierRc = BBMAP_OK; c->tierErr[0] = 0;
+    c->tierThread = std::thread([c, found]() {
+        int rc = hipSetDevice(c->cfg.device) == hipSuccess ? BBMAP_OK : BBMAP_E_HIP;
+        if (rc == BBMAP_OK) rc = tier_pass(c, c->tierStream, found);
+        if (rc != BBMAP_OK) { snprintf(c->tierErr, sizeof c->tierErr, "overflow tier: %s", bbmap_last_error()); }
+        c->tierRc = rc;
+    });
+}
+
+// after the tier's pass: its reads are marked in the main list, its counts join the batch's statistics
+static int tier_finish(bbmap_ctx *c, hipStream_t stream) {
+    bbmap_ctx *t = c->tier;
+    const long long tn = c->tierReads;
+    if (tn == 0) return BBMAP_OK;
+    const unsigned TB = 128;
+    MHIP(hipMemsetAsync(c->d_counters + 17, 0, 4, stream));
+    hipLaunchKernelGGL(bbmapper::mark_tier_kernel, dim3((unsigned)((tn + TB - 1) / TB)), dim3(TB), 0, stream, c->d_mcount, t->d_mcount, c->d_tierReadIds, (int)tn,
+                       c->d_counters + 17);
+    MHIP(hipGetLastError());
+    MTRY(read_counters(c, stream));
+    bbmap_stats &st = c->stats; const bbmap_stats &ts = t->stats;
+    st.reads_reprobed = tn;
+    st.reads_overflowed -= (long long)c->h_counters[17];
+    st.reads_without_site += ts.reads_without_site;
+    st.fills += ts.fills; st.gapped_fills += ts.gapped_fills; st.refills += ts.refills; st.rescue_scans += ts.rescue_scans;
+    st.rescue_fills += ts.rescue_fills; st.fills_dropped += ts.fills_dropped;
+    if (getenv("BBMAP_TIER_DEBUG"))
+        fprintf(stderr, "[bbmap tier] reads %lld: probe %.2f begin %.2f score %.2f slow %.2f (rounds %lld) finish %.2f rescue %.2f total %.2f\n",
+                tn, ts.ms_probe, ts.ms_begin, ts.ms_score, ts.ms_slow, (long long)ts.rounds, ts.ms_finish, ts.ms_rescue, ts.ms_total);
+    return BBMAP_OK;
+}
+
+extern "C" int bbmap_map_batch_device(bbmap_ctx *c, void *stream_, int64_t n_reads, const bbidx_read *reads, uint8_t *bases,
+                                      int64_t minus_delta, const int8_t *baseScores, const int32_t *keyinfo) {
+    if (!c) return mfail(BBMAP_E_ARG, "bbmap_map_batch_device: null context");
+    if (n_reads < 0 || n_reads > c->cfg.max_reads) return mfail(BBMAP_E_ARG, "bbmap_map_batch_device: more reads than the context was made for");
+    if (c->cfg.paired && (n_reads & 1)) return mfail(BBMAP_E_ARG, "bbmap_map_batch_device: paired mode takes an even number of reads");
+    if (n_reads == 0) { c->ran = false; return BBMAP_OK; }
+    if (!reads || !bases || !baseScores || !keyinfo) return mfail(BBMAP_E_ARG, "bbmap_map_batch_device: null buffer");
+    hipStream_t stream = (hipStream_t)stream_;
+    MHIP(hipSetDevice(c->cfg.device));
+    c->batch = {n_reads, reads, bases, minus_delta, baseScores, keyinfo};
+    c->tierStarted = false; c->tierReads = 0;
+    if (c->tier) c->tier->ran = false;
+    const int rc = map_records(c, stream, n_reads, reads, bases, minus_delta, baseScores, keyinfo, true);
+    hipEvent_t e0 = c->ev[10], e1 = c->ev[11];
+    if (rc == BBMAP_OK && c->tier) MHIP(hipEventRecord(e0, stream));
+    if (c->tierStarted) {
+        c->tierThread.join();
+        if (rc == BBMAP_OK && c->tierRc != BBMAP_OK) return mfail(c->tierRc, c->tierErr);
+    }
+    MTRY(rc);
+    if (!c->tier || c->stats.reads_overflowed == 0) return BBMAP_OK;
+    if (c->stats.reads_overflowed > c->overAfterBegin || !c->tierStarted) {
+        // lists that outgrew max_sites in rescue: one more tier pass, over every flagged read
+        const long long units = c->cfg.paired ? n_reads / 2 : n_reads;
+        const unsigned TB = 128;
+        MHIP(hipMemsetAsync(c->d_counters + 16, 0, 4, stream));
+        hipLaunchKernelGGL(bbmapper::collect_overflow_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, c->d_mcount, units, c->cfg.paired,
+                           c->d_tierUnits, c->d_counters + 16);
+        MHIP(hipGetLastError());
+        MTRY(read_counters(c, stream));
+        if (c->h_counters[16] > 0) MTRY(tier_pass(c, stream, c->h_counters[16]));
+    }
+    MTRY(tier_finish(c, stream));
+    MHIP(hipEventRecord(e1, stream));
+    MHIP(hipStreamSynchronize(stream));
+    (void)hipEventElapsedTime(&c->stats.ms_overflow, e0, e1);      // what the tier added to the batch after the main pass
+    c->stats.ms_total += c->stats.ms_overflow;
+    return BBMAP_OK;
+}
+
+extern "C" int bbmap_get_overflow_output(bbmap_ctx *c, bbmap_overflow_output *o) {
+    if (!c || !o) return mfail(BBMAP_E_ARG, "bbmap_get_overflow_output: null argument");
+    if (!c->ran) return mfail(BBMAP_E_ARG, "bbmap_get_overflow_output: no batch has been mapped yet");
+    memset(o, 0, sizeof *o);
+    if (!c->tier || c->tierReads == 0 || !c->tier->ran) return BBMAP_OK;
+    o->n_reads = c->tierReads; o->read_ids = c->d_tierReadIds;
+    return bbmap_get_output(c->tier, &o->out);
 }
 
 extern "C" int bbmap_get_output(bbmap_ctx *c, bbmap_output *o) {

@@ -39,7 +39,14 @@ class bbmap_stats(C.Structure):
                                          "rescue_scans", "rescue_fills", "rounds", "fills_dropped")] + \
                [(n, C.c_float) for n in ("ms_probe", "ms_begin", "ms_score", "ms_slow", "ms_finish", "ms_rescue", "ms_total",
                                          "ms_dp_narrow", "ms_dp_wave", "ms_dp_generic", "ms_dp_gapped", "ms_quick_rescue")] + \
-               [("probe_stats", C.c_int64 * 5)]
+               [("probe_stats", C.c_int64 * 5), ("reads_reprobed", C.c_int64), ("ms_overflow", C.c_float), ("reserved_f", C.c_float)]
+
+
+class bbmap_overflow_output(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("read_ids", C.c_void_p), ("out", bbmap_output)]
+
+
+NSITES_OVERFLOW, NSITES_MATE_OVERFLOW, NSITES_IN_TIER = -1, -2, -3
 
 
 def _bind(L):
@@ -50,7 +57,9 @@ def _bind(L):
     L.bbmap_map_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.bbmap_get_output.argtypes = [C.c_void_p, C.POINTER(bbmap_output)]
     L.bbmap_last_stats.argtypes = [C.c_void_p, C.POINTER(bbmap_stats)]
-    for f in ("bbmap_default_config", "bbmap_create", "bbmap_map_batch_device", "bbmap_get_output", "bbmap_last_stats"):
+    L.bbmap_get_overflow_output.argtypes = [C.c_void_p, C.POINTER(bbmap_overflow_output)]
+    for f in ("bbmap_default_config", "bbmap_create", "bbmap_map_batch_device", "bbmap_get_output", "bbmap_last_stats",
+              "bbmap_get_overflow_output"):
         getattr(L, f).restype = C.c_int
 
 
@@ -120,17 +129,16 @@ class Mapper:
     def stats(self):
         st = bbmap_stats()
         _lib.check(self.L.bbmap_last_stats(self.h, C.byref(st)), "bbmap_last_stats")
-        d = {n: getattr(st, n) for n, _ in bbmap_stats._fields_ if n != "probe_stats"}
+        d = {n: getattr(st, n) for n, _ in bbmap_stats._fields_ if n not in ("probe_stats", "reserved_f")}
         d["probe_stats"] = list(st.probe_stats)
         return d
 
-    def fetch(self, with_match=True):
-        """Host copies of a step's results: sites (n x cap, MSITE_DTYPE), nsites, and the two fill logs."""
-        o = bbmap_output()
-        _lib.check(self.L.bbmap_get_output(self.h, C.byref(o)), "bbmap_get_output")
-        n, cap = self.n, o.cap
+    def _fetch_output(self, o, n, with_match, rows=None):
+        """Host copies of one bbmap_output over n reads (rows: only the site lists of reads [0, rows))."""
+        cap = o.cap
         out = dict(cap=cap)
-        out["sites"] = _copy(o.sites, n * cap * 128, self.dev).view(MSITE_DTYPE).reshape(n, cap)
+        ns = n if rows is None else min(rows, n)
+        out["sites"] = _copy(o.sites, ns * cap * 128, self.dev).view(MSITE_DTYPE).reshape(ns, cap)
         out["nsites"] = _copy(o.nsites, n * 4, self.dev).view(np.int32)
         nj, ng = int(o.n_jobs), int(o.n_gapped_jobs)
         out["jobs"] = _copy(o.jobs, nj * 40, self.dev).view(M.JOB_DTYPE)
@@ -144,4 +152,18 @@ class Mapper:
         if with_match:
             out["match"] = _copy(o.match, nj * o.match_stride, self.dev).reshape(nj, o.match_stride)
             out["gmatch"] = _copy(o.gmatch, ng * o.gmatch_stride, self.dev).reshape(ng, o.gmatch_stride)
+        return out
+
+    def fetch(self, with_match=True, rows=None):
+        """Host copies of a step's results: sites (n x cap, MSITE_DTYPE), nsites, and the two fill logs; out["overflow"] holds
+        the same for the reads the overflow tier mapped (nsites == NSITES_IN_TIER in the main list), plus their read_ids."""
+        o = bbmap_output()
+        _lib.check(self.L.bbmap_get_output(self.h, C.byref(o)), "bbmap_get_output")
+        out = self._fetch_output(o, self.n, with_match, rows)
+        ov = bbmap_overflow_output()
+        _lib.check(self.L.bbmap_get_overflow_output(self.h, C.byref(ov)), "bbmap_get_overflow_output")
+        if ov.n_reads > 0:
+            t = self._fetch_output(ov.out, int(ov.n_reads), with_match)
+            t["read_ids"] = _copy(ov.read_ids, int(ov.n_reads) * 4, self.dev).view(np.int32)
+            out["overflow"] = t
         return out

@@ -173,11 +173,11 @@ def parity_sample(mp, out, oi, reads, L, paired, offsets, key_scores, count):
     r = reads.reshape(-1, L)
     if paired:
         count -= count % 2
-        orc = map_batch(oi, r[0:count:2].copy(), r[1:count:2].copy(), L, offsets, key_scores, cap=64)
+        orc = map_batch(oi, r[0:count:2].copy(), r[1:count:2].copy(), L, offsets, key_scores, cap=1024)
     else:
-        orc = map_batch(oi, r[:count].copy(), None, L, offsets, key_scores, cap=64)
-    over = [i for i in range(count) if out["nsites"][i] < 0]
-    good = [i for i in range(count) if out["nsites"][i] >= 0]
+        orc = map_batch(oi, r[:count].copy(), None, L, offsets, key_scores, cap=1024)
+    over = [i for i in range(count) if out["nsites"][i] in (-1, -2)]        # fitted neither max_sites nor the overflow tier
+    good = [i for i in range(count) if out["nsites"][i] >= 0 or out["nsites"][i] == -3]
     bad = compare(out, orc, count, paired, reads_range=good)
     return {"checked_reads": count, "mismatches": len(bad), "overflowed_in_sample": len(over), "first": bad[:3]}
 
@@ -289,6 +289,10 @@ def main():
     minScore = int(np.float32(0.56) * np.float32(70 + 149 * 100))
     mapped = int(((nsites > 0) & (top["slowScore"] >= minScore)).sum())
     cells = int(out["results"]["iterations"].sum() + out["gresults"]["iterations"].sum())
+    tier = out.get("overflow")
+    if tier is not None:                                    # reads the overflow tier mapped (nsites == -3 in the main list)
+        mapped += int(((tier["nsites"] > 0) & (tier["sites"][:, 0]["slowScore"] >= minScore)).sum())
+        cells += int(tier["results"]["iterations"].sum() + tier["gresults"]["iterations"].sum())
     parity = None
     if rank == 0 and args.parity_sample > 0:
         parity = parity_sample(mp, out, oi, reads, L, paired, offsets, key_scores, min(n, args.parity_sample))
@@ -338,7 +342,7 @@ def main():
                        "fills_per_step": st["fills"] + st["gapped_fills"], "fills_second_context": st["gapped_fills"],
                        "refills_per_step": st["refills"], "scoreslow_rounds": st["rounds"], "fills_ahead_dropped_per_step": st["fills_dropped"],
                        "rescue_scans_per_step": st["rescue_scans"], "rescue_fills_per_step": st["rescue_fills"],
-                       "reads_overflowed_max_sites": st["reads_overflowed"], "reads_without_site": st["reads_without_site"],
+                       "reads_remapped_by_overflow_tier": st["reads_reprobed"], "reads_left_unmapped_by_overflow": st["reads_overflowed"], "reads_without_site": st["reads_without_site"],
                        "mapped_fraction": mapped / n, "dp_cells_per_step": cells,
                        "dp_gcups": (cells / ((ms["ms_dp_wave"] + ms["ms_dp_narrow"] + ms["ms_dp_gapped"]) * 1e-3) / 1e9) if cells else 0.0,
                        "probe_list_entries_per_step": int(ps[0] + ps[1]), "probe_extend_calls_per_step": int(ps[2]),

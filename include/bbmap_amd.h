@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define BBMAP_AMD_ABI_VERSION 3
+#define BBMAP_AMD_ABI_VERSION 4
 
 enum {
     BBMAP_OK = 0,
@@ -402,6 +402,11 @@ typedef struct bbmap_msite {       /* stream.SiteScore, current/stream/SiteScore
     int32_t reserved[2];
 } bbmap_msite;                     /* 128 bytes */
 
+#define BBMAP_NSITES_OVERFLOW (-1)
+#define BBMAP_NSITES_MATE_OVERFLOW (-2)
+#define BBMAP_NSITES_IN_TIER (-3)
+#define BBMAP_MAX_SITES_LIMIT 4096
+
 typedef struct bbmap_jobinfo {     /* one entry per fill, parallel to the job / result arrays */
     int32_t read;                  /* read the fill belongs to */
     int32_t seq;                   /* its position in that read's sequence of fillAndScoreLimited calls; -1 = a fill issued ahead
@@ -415,7 +420,8 @@ typedef struct bbmap_config {
     int32_t paired;                /* 0: processRead per read; 1: processReadPair, reads 2p and 2p+1 are mates */
     int32_t max_reads;             /* capacity in reads (not pairs) */
     int32_t max_read_len;          /* <= 600 */
-    int32_t max_sites;             /* per-read capacity of the probe output and of the mapper's site list */
+    int32_t max_sites;             /* per-read capacity of the probe output and of the mapper's site list (<= 4096); reads that
+                                    * need more go to the overflow tier */
     float   minRatio;              /* MINIMUM_ALIGNMENT_SCORE_RATIO (0.56) */
     int32_t slowAlignPadding;      /* 4 */
     int32_t slowRescuePadding;     /* 8 */
@@ -434,12 +440,17 @@ typedef struct bbmap_config {
     int32_t fastCols;              /* column limit of the first DP context, which takes the ordinary windows (0 = 256); wider
                                     * windows and gapped references go to the second context (the "gapped" log) */
     int32_t jobsPerRead;           /* capacity of the job log = jobsPerRead * max_reads (0 = 3) */
-    int32_t reserved[4];           /* [0] != 0: strictly one fill per read and round (no fills ahead of time; for tests) */
+    int32_t reserved[4];           /* [0] != 0: strictly one fill per read and round (no fills ahead of time; for tests)
+                                    * [1] overflow tier: reads it can hold per batch (0 = 4096, < 0 = no tier)
+                                    * [2] overflow tier: its max_sites (0 = 1024) */
 } bbmap_config;
 
 typedef struct bbmap_output {      /* device pointers, valid until the next bbmap_map_batch_device / bbmap_destroy */
     const bbmap_msite *sites;      /* n_reads x cap */
-    const int32_t *nsites;         /* per read: sites in its list, -1 = the probe overflowed max_sites (list not processed) */
+    const int32_t *nsites;         /* per read: sites in its list, or BBMAP_NSITES_OVERFLOW (-1: the list did not fit max_sites and
+                                    * the overflow tier could not take the read either: not mapped), BBMAP_NSITES_MATE_OVERFLOW
+                                    * (-2: its mate's list did not fit), BBMAP_NSITES_IN_TIER (-3: mapped by the overflow tier, see
+                                    * bbmap_get_overflow_output) */
     int32_t cap;
     int32_t match_stride, gmatch_stride;
     int32_t reserved;
@@ -450,12 +461,16 @@ typedef struct bbmap_output {      /* device pointers, valid until the next bbma
 } bbmap_output;
 
 typedef struct bbmap_stats {
+    /* reads_overflowed: reads whose list fitted neither max_sites nor the overflow tier (left unmapped, flagged) */
     int64_t reads, reads_overflowed, reads_without_site, fills, gapped_fills, refills, rescue_scans, rescue_fills, rounds;
     int64_t fills_dropped;         /* fills issued ahead of time that the reference's sequence turned out not to contain (dropped;
                                     * their log entries keep seq = -1) */
     float ms_probe, ms_begin, ms_score, ms_slow, ms_finish, ms_rescue, ms_total;
     float ms_dp_narrow, ms_dp_wave, ms_dp_generic, ms_dp_gapped, ms_quick_rescue;
     int64_t probe_stats[5];        /* bbidx_last_stats of the probe launch */
+    int64_t reads_reprobed;        /* reads the overflow tier mapped (pairs count both mates); fills etc. above include the tier's */
+    float ms_overflow;             /* the overflow tier's whole pass (included in ms_total) */
+    float reserved_f;
 } bbmap_stats;
 
 typedef struct bbmap_ctx bbmap_ctx;
@@ -470,6 +485,15 @@ void bbmap_destroy(bbmap_ctx *ctx);
 int bbmap_map_batch_device(bbmap_ctx *ctx, void *stream, int64_t n_reads, const bbidx_read *reads, uint8_t *bases,
                            int64_t minus_delta, const int8_t *baseScores, const int32_t *keyinfo);
 int bbmap_get_output(bbmap_ctx *ctx, bbmap_output *out);
+/* The overflow tier's results for the last batch: n_reads = 0 when no read needed it.  Tier read i is read read_ids[i] of the
+ * batch (ascending; pairs keep their two mates adjacent); `out` is laid out like the main output with the tier's own cap, and its
+ * job logs number the reads 0..n_reads-1 in tier order. */
+typedef struct bbmap_overflow_output {
+    int64_t n_reads;
+    const int32_t *read_ids;       /* device pointer */
+    bbmap_output out;
+} bbmap_overflow_output;
+int bbmap_get_overflow_output(bbmap_ctx *ctx, bbmap_overflow_output *out);
 int bbmap_last_stats(bbmap_ctx *ctx, bbmap_stats *out);
 /* synchronous device-to-host copy of (part of) an output array */
 int bbmap_copy_to_host(void *dst, const void *src_device, int64_t bytes);

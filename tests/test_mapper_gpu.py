@@ -31,9 +31,9 @@ def _run(ref, reads, L, k, paired, max_sites=32, cap=64, **cfg):
     if paired:
         oi.s.p.quitAfterTwoPerfects = 0
         r = reads.reshape(-1, L)
-        orc = O.map_batch(oi, r[0::2].copy(), r[1::2].copy(), L, offs, ks, params=params, cap=cap)
+        orc = O.map_batch(oi, r[0::2].copy(), r[1::2].copy(), L, offs, ks, params=params, cap=cap, match_stride=4200)
     else:
-        orc = O.map_batch(oi, reads, None, L, offs, ks, params=params, cap=cap)
+        orc = O.map_batch(oi, reads, None, L, offs, ks, params=params, cap=cap, match_stride=4200)
     mp.close()
     di.close()
     return out, orc, st, n
@@ -78,19 +78,56 @@ def test_paired_without_tip_search_and_trimming():
     assert not bad, "\n".join(bad[:20])
 
 
-def test_overflow_is_reported_not_dropped():
-    """A read with more candidate sites than max_sites is flagged (nsites = -1, counted), never passed off as unmapped."""
+def _repeat_workload(paired):
     L, k = 150, 12
     ref = W.make_reference(200000, seed=11, pad=2000, repeat_frac=0.6, families=3)
-    reads, _, _ = W.make_reads_and_jobs(ref, 1500, read_len=L, seed=2, pad=2000)
-    out, orc, st, n = _run(ref, reads, L, k, paired=False, max_sites=4, cap=256)
+    if paired:
+        reads, _ = W.make_pairs(ref, 700, read_len=L, seed=2, pad=2000, hard_frac=0.05)
+    else:
+        reads, _, _ = W.make_reads_and_jobs(ref, 1500, read_len=L, seed=2, pad=2000)
+    return ref, reads, L, k
+
+
+def test_overflow_is_reported_not_dropped():
+    """Without the overflow tier a read with more candidate sites than max_sites is flagged (nsites = -1, counted), never
+    passed off as unmapped."""
+    ref, reads, L, k = _repeat_workload(False)
+    out, orc, st, n = _run(ref, reads, L, k, paired=False, max_sites=4, cap=256, reserved=(C.c_int32 * 4)(0, -1, 0, 0))
     over = out["nsites"] < 0
-    assert over.sum() == st["reads_overflowed"] and over.sum() > 0
+    assert over.sum() == st["reads_overflowed"] and over.sum() > 0 and st["reads_reprobed"] == 0 and "overflow" not in out
     # every read the device did map is identical to the oracle; the oracle finds sites for the flagged ones
     good = [r for r in range(n) if not over[r]]
     bad = compare(out, orc, n, paired=False, reads_range=good)
     assert not bad, "\n".join(bad[:20])
     assert all(orc["nsites1"][r] != 0 for r in np.nonzero(over)[0])
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_overflow_tier_maps_what_max_sites_cannot_hold(paired):
+    """The reference's site list has no capacity (BBIndex.java:1537-1604): reads whose list does not fit max_sites are mapped
+    again by the overflow tier (long lists), pairs as pairs, and the result is the oracle's for EVERY read."""
+    ref, reads, L, k = _repeat_workload(paired)
+    out, orc, st, n = _run(ref, reads, L, k, paired=paired, max_sites=4, cap=1024)
+    moved = out["nsites"] == -3
+    assert st["reads_overflowed"] == 0 and (out["nsites"] >= -3).all() and not (out["nsites"] == -1).any()
+    assert moved.sum() == st["reads_reprobed"] > (20 if paired else 50)
+    t = out["overflow"]
+    assert sorted(t["read_ids"].tolist()) == np.nonzero(moved)[0].tolist()
+    assert int(t["nsites"].max()) > 4                                    # lists longer than the main capacity exist
+    if paired:                                                           # mates travel together
+        assert (t["read_ids"][0::2] % 2 == 0).all() and (t["read_ids"][1::2] == t["read_ids"][0::2] + 1).all()
+    bad = compare(out, orc, n, paired=paired)
+    assert not bad, "\n".join(bad[:20])
+
+
+def test_overflow_tier_too_small_keeps_the_rest_flagged():
+    ref, reads, L, k = _repeat_workload(False)
+    out, orc, st, n = _run(ref, reads, L, k, paired=False, max_sites=4, cap=1024, reserved=(C.c_int32 * 4)(0, 10, 0, 0))
+    moved, left = out["nsites"] == -3, out["nsites"] == -1
+    assert moved.sum() == 10 == st["reads_reprobed"] and left.sum() == st["reads_overflowed"] > 0
+    assert np.nonzero(moved)[0].max() < np.nonzero(left)[0].min()       # the tier takes the first ones in read order
+    bad = compare(out, orc, n, paired=False, reads_range=[r for r in range(n) if not left[r]])
+    assert not bad, "\n".join(bad[:20])
 
 
 def test_fills_ahead_of_time_do_not_change_anything():
