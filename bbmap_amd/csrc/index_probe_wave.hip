@@ -46,10 +46,27 @@ using namespace wavep;
 #else
 #define CST(u, i, v) do { } while (0)
 #endif
-#ifdef BBIDX_PHASE_TIMERS
-#define PH_MARK(u, i) do { const unsigned long long now_ = __builtin_readcyclecounter(); (u).ph[i] += (unsigned)(now_ - (u).phT); (u).phT = now_; } while (0)
+// debug builds with cycle counters: -DBBIDX_PHASE_TIMERS=1 the read's phases {keys + lookup, trim / setup, prescan, walk, extend};
+// =2 inside the walk {lists + cycle load, candidate stepping, quick scores, extendScore, site bookkeeping}; =3 inside the prescan
+// {lists, cycle gather, candidate filter, candidate loop, sequential fallback}
+#define PH_ADD_(u, i) do { const unsigned long long now_ = __builtin_readcyclecounter(); (u).ph[i] += (unsigned)(now_ - (u).phT); (u).phT = now_; } while (0)
+#define PH_SKIP_(u) do { (u).phT = __builtin_readcyclecounter(); } while (0)
+#if defined(BBIDX_PHASE_TIMERS) && BBIDX_PHASE_TIMERS == 2
+#define PH_MARK(u, i) PH_SKIP_(u)
+#define PH_WALK(u, i) PH_ADD_(u, i)
+#define PH_PRE(u, i) do { } while (0)
+#elif defined(BBIDX_PHASE_TIMERS) && BBIDX_PHASE_TIMERS == 3
+#define PH_MARK(u, i) PH_SKIP_(u)
+#define PH_WALK(u, i) do { } while (0)
+#define PH_PRE(u, i) PH_ADD_(u, i)
+#elif defined(BBIDX_PHASE_TIMERS)
+#define PH_MARK(u, i) PH_ADD_(u, i)
+#define PH_WALK(u, i) do { } while (0)
+#define PH_PRE(u, i) do { } while (0)
 #else
 #define PH_MARK(u, i) do { } while (0)
+#define PH_WALK(u, i) do { } while (0)
+#define PH_PRE(u, i) do { } while (0)
 #endif
 
 constexpr int WAVES_PER_BLOCK = 4;
@@ -115,7 +132,7 @@ struct WL {
     GlobalInts sites;          // uniform
 };
 
-__device__ inline int adjustSite(const U &u, int a, int offset, int baseChrom) {
+__device__ __forceinline__ int adjustSite(const U &u, int a, int offset, int baseChrom) {
     // a site in the first `offset` bases of its chromosome maps to position 0 of that chromosome (branch-free: both forms
     // are a handful of ALU ops, and a per-lane branch here would sit in the innermost loop of the probe)
     const int below = u.c.toNumber(0, u.c.chromOf(a, baseChrom));
@@ -124,7 +141,7 @@ __device__ inline int adjustSite(const U &u, int a, int offset, int baseChrom) {
 
 // BBIndex.maxQuickScore :2473-2487 over lanes 0..n-1 (offsets ascending: the coverage of maxScoreZ :2948-2964 is
 // sum(min(k, next - this)) + k)
-__device__ int maxQuickScoreW(const U &u, int off, int ksc, int n) {
+__device__ __forceinline__ int maxQuickScoreW(const U &u, int off, int ksc, int n) {
     const int nxt = __shfl_down(off, 1);
     int contrib = 0;
     if (u.lane < n) contrib = ksc + Z_MULT * ((u.lane < n - 1) ? min(u.k, nxt - off) : u.k);
@@ -132,7 +149,7 @@ __device__ int maxQuickScoreW(const U &u, int off, int ksc, int n) {
 }
 
 // BBIndex.scoreZ2 :2882-2914
-__device__ int scoreZ2W(const U &u, int value, int offs, int centerVal, int numApproxHits, int numHits) {
+__device__ __forceinline__ int scoreZ2W(const U &u, int value, int offs, int centerVal, int numApproxHits, int numHits) {
     if (numApproxHits == 1) return u.scoreZ1Key;
     const int maxLoc = centerVal + u.ix->p.maxIndel2, minLoc = max(0, centerVal - u.ix->p.maxIndel);
     const bool inr = u.lane < numHits && value >= minLoc && value <= maxLoc;
@@ -147,7 +164,7 @@ __device__ int scoreZ2W(const U &u, int value, int offs, int centerVal, int numA
 // BBIndex.quickScore :2490-2511 with scoreLeft/scoreRight :2967-3035.  The chain "accept a key if it lies within
 // MAX_INDEL of the last accepted one" is sequential; when every key within MAX_INDEL of the centre sits exactly on the
 // centre (no indel between keys) the chain degenerates to a sum, otherwise it is walked with scalar readlanes.
-__device__ int quickScoreW(const U &u, int value, int ksc, int offs, int centerIndex, int centerVal, int numApproxHits, int numHits) {
+__device__ __forceinline__ int quickScoreW(const U &u, int value, int ksc, int offs, int centerIndex, int centerVal, int numApproxHits, int numHits) {
     const int ksC = rl(ksc, centerIndex);
     if (numApproxHits == 1) return ksC;
     const int maxIndel = u.ix->p.maxIndel;
@@ -178,7 +195,7 @@ __device__ int quickScoreW(const U &u, int value, int ksc, int offs, int centerI
 }
 
 // reloads every live list's look-ahead buffer from its cursor
-__device__ inline void refillLists(WL &L) {
+__device__ __forceinline__ void refillLists(WL &L) {
     const bool live = L.hv != INT_MAX;
     const int avail = live ? L.stop - L.row - 1 : 0;
     const int last = live ? L.stop - 1 : 0;                // slots past the list's end re-read its last entry (never used)
@@ -190,7 +207,7 @@ __device__ inline void refillLists(WL &L) {
 // Pops every list whose head equals `site`, in (site, column) order (QuadHeap.poll/add of the reference's inner
 // loop, BBIndex.java:1637-1666 and :2420-2444).  When the caller's loop must end (a list ran out and fewer than
 // `cutoff` lists remain, or perfectOnly) L.nlive is set to 0.
-__device__ inline void popSite(const U &u, WL &L, int site, int cutoff, bool perfectOnly, int baseChrom, unsigned &counter) {
+__device__ __forceinline__ void popSite(const U &u, WL &L, int site, int cutoff, bool perfectOnly, int baseChrom, unsigned &counter) {
     site = uni(site); cutoff = uni(cutoff); perfectOnly = uni(perfectOnly);
     for (;;) {
         L.nlive = uni(L.nlive); counter = uni(counter);
@@ -236,7 +253,7 @@ __device__ inline void popSite(const U &u, WL &L, int site, int cutoff, bool per
 // head is below T therefore moves straight to its first entry >= T (found by galloping, all lists of the wave probing
 // together), except that a list never gives up its last entry here: running out has consequences (the loop's exit rule)
 // that stay with popSite.  The pops are counted as the reference would count them.
-__device__ inline void bulkSkip(const U &u, WL &L, int site, int lo, int cutoff, int baseChrom, unsigned &counter) {
+__device__ __forceinline__ void bulkSkip(const U &u, WL &L, int site, int lo, int cutoff, int baseChrom, unsigned &counter) {
     const bbidx_params &p = u.ix->p;
     const bool live = L.hv != INT_MAX;
     const int e = popc(__ballot(!live && u.lane < L.n && L.value >= site - lo));
@@ -295,7 +312,7 @@ __device__ inline void bulkSkip(const U &u, WL &L, int site, int lo, int cutoff,
 // (keyScore + scoreZ1Key, quickScore/scoreZ2 with one approximate hit) and feeds nothing but the running maximum, so at a
 // cutoff of 1 such sites are folded into `topQscore`/`maxHits` here; anything else at that cutoff ends the batch.
 // Returns the number of entries consumed (0: nothing done).
-__device__ inline int batchPop(const U &u, WL &L, int lo, int hi, int cutoff, bool prescan, int &topQscore, int &maxHits, int mqs,
+__device__ __forceinline__ int batchPop(const U &u, WL &L, int lo, int hi, int cutoff, bool prescan, int &topQscore, int &maxHits, int mqs,
                                int baseChrom, unsigned &counter) {
     const bool live = L.hv != INT_MAX;
     const bool hasNext = live && L.row + 1 < L.stop;
@@ -361,13 +378,13 @@ struct CycleLds {
 };
 struct CycleLanes { int lo, len, last, p, rank; };   // per lane = per list: its slice of ent[], last value, cursor, rank of `last`
 
-__device__ inline unsigned cyc_h1(unsigned b) { return (b * 0x9E3779B1u) >> 21; }
-__device__ inline unsigned cyc_h2(unsigned b) { return ((b ^ (b >> 7)) * 0x85EBCA6Bu) >> 21; }
-__device__ inline bool cyc_bit(const unsigned *m, unsigned sl) { return (m[sl >> 5] >> (sl & 31)) & 1; }
+__device__ __forceinline__ unsigned cyc_h1(unsigned b) { return (b * 0x9E3779B1u) >> 21; }
+__device__ __forceinline__ unsigned cyc_h2(unsigned b) { return ((b ^ (b >> 7)) * 0x85EBCA6Bu) >> 21; }
+__device__ __forceinline__ bool cyc_bit(const unsigned *m, unsigned sl) { return (m[sl >> 5] >> (sl & 31)) & 1; }
 
 // Gathers the cycle's entries.  Returns the number of candidates (their sites in cs[]), or -1 when the cycle does not fit.
 // xrow/xoff/xlo (S.xch) and xksc (S.loc) are scratch of the load phase; cs aliases xrow..xlo afterwards.
-template <int WLEN> __device__ int cycleLoad(const U &u, CycleLds &C, WaveLds<WLEN> &S, const WL &L, int baseChrom, CycleLanes &cl, int &E) {
+template <int WLEN> __device__ __forceinline__ int cycleLoad(U &u, CycleLds &C, WaveLds<WLEN> &S, const WL &L, int baseChrom, CycleLanes &cl, int &E) {
     const int lane = u.lane, n = L.n;
     int *xrow = S.xch[0], *xoff = S.xch[1], *xlo = S.xch[2], *xksc = S.loc, *cs = S.xch[0];
     const int len = lane < n ? L.stop - L.row : 0;
@@ -406,6 +423,7 @@ template <int WLEN> __device__ int cycleLoad(const U &u, CycleLds &C, WaveLds<WL
         }
     }
     wsync();
+    PH_PRE(u, 1);
     cl.last = len > 0 ? C.ent[cl.lo + len - 1] : INT_MAX;
     cl.rank = -2;                                              // ranked on first use (cycleExitSite)
     wsync();                                                   // the load phase's scratch is dead: cs[] may be written
@@ -446,16 +464,17 @@ template <int WLEN> __device__ int cycleLoad(const U &u, CycleLds &C, WaveLds<WL
     wsync();
     for (int i = lane; i < ncand; i += 64) { const int v = xoff[i]; cs[i] = v; }
     wsync();
+    PH_PRE(u, 2);
     return ncand;
 }
 // smallest candidate site above `prev` (INT_MAX: none left)
-__device__ inline int cycleNext(const U &u, const int *cs, int ncand, int prev) {
+__device__ __forceinline__ int cycleNext(const U &u, const int *cs, int ncand, int prev) {
     int m = INT_MAX;
     for (int i = u.lane; i < ncand; i += 64) { const int v = cs[i]; if (v > prev) m = min(m, v); }
     return wmin(m);
 }
 // every list's state when `site` is the heap minimum: head = first entry >= site, value = head or, once exhausted, the last entry
-__device__ inline void cycleSeek(const U &u, const CycleLds &C, CycleLanes &cl, WL &L, int site) {
+__device__ __forceinline__ void cycleSeek(const U &u, const CycleLds &C, CycleLanes &cl, WL &L, int site) {
     const bool mine = u.lane < L.n;
     bool adv = mine && cl.p < cl.len && C.ent[cl.lo + cl.p] < site;
     while (__ballot(adv)) { if (adv) { cl.p++; adv = cl.p < cl.len && C.ent[cl.lo + cl.p] < site; } }
@@ -465,7 +484,7 @@ __device__ inline void cycleSeek(const U &u, const CycleLds &C, CycleLanes &cl, 
 }
 // The pop at which the reference's loop ends after the site `s` has been looked at with hit cutoff c >= 1 (popSite's rule: a
 // list runs out and fewer than c stay alive): INT_MAX if none (cannot happen: the very last entry always ends it).
-__device__ inline int cycleExitSite(const U &u, CycleLanes &cl, int n, int s, int c) {
+__device__ __forceinline__ int cycleExitSite(const U &u, CycleLanes &cl, int n, int s, int c) {
     if (rl(cl.rank, 0) == -2) {                                // rank of every list's last entry (ascending, ties by lane)
         int rk = 0;
         for (int i = 0; i < n; i++) { const int li = rl(cl.last, i); rk += (li < cl.last || (li == cl.last && i < u.lane)) ? 1 : 0; }
@@ -478,7 +497,7 @@ __device__ inline int cycleExitSite(const U &u, CycleLanes &cl, int n, int s, in
 }
 
 // BBIndex.findMaxQscore2 in the whole-cycle form.  Returns false when the cycle was declined (nothing touched).
-template <int WLEN> __device__ bool findMaxQscore2Cycle(U &u, CycleLds &C, WaveLds<WLEN> &S, WL &L, int baseChrom, int prevMaxHits, int numKeys, int mqsAllKeys, int &outQ, int &outHits) {
+template <int WLEN> __device__ __forceinline__ bool findMaxQscore2Cycle(U &u, CycleLds &C, WaveLds<WLEN> &S, WL &L, int baseChrom, int prevMaxHits, int numKeys, int mqsAllKeys, int &outQ, int &outHits) {
     const bbidx_params &p = u.ix->p;
     const int numHits = L.n, lane = u.lane;
     if (wmin(lane < numHits ? L.ksc : INT_MAX) <= 0) return false;       // an isolated site must not be able to reach maxQuickScore
@@ -537,7 +556,7 @@ template <int WLEN> __device__ bool findMaxQscore2Cycle(U &u, CycleLds &C, WaveL
 }
 
 // BBIndex.findMaxQscore2 :2294-2450
-template <bool LONG> __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, bool perfectOnly, int numKeys, int mqsAllKeys,
+template <bool LONG> __device__ __forceinline__ void findMaxQscore2W(U &u, WL &L, int baseChrom, int prevMaxHits, bool perfectOnly, int numKeys, int mqsAllKeys,
                                 int &outQ, int &outHits) {
     const bbidx_params &p = u.ix->p;
     const int numHits = L.n;
@@ -581,7 +600,7 @@ template <bool LONG> __device__ void findMaxQscore2W(U &u, WL &L, int baseChrom,
 //   lastLoc    = the last positive element before p         -> highest set bit of the "positive" ballot below p
 //   timeInMode = length of the run of -1 ending at p        -> distance to the highest "not -1" bit below p
 //   contig     = equal-to-previous streak                   -> popcount of "equal" events since the last reset event
-template <int WLEN> __device__ int calcAffineScoreW(const U &u, const WaveLds<WLEN> &S, int strand, int minContig) {
+template <int WLEN> __device__ __forceinline__ int calcAffineScoreW(const U &u, const WaveLds<WLEN> &S, int strand, int minContig) {
     const int blen = u.blen, lane = u.lane;
     int score = 0, carryLastLoc = -3, carryRun = 0, carryContig = 0, maxContig = 0;
     for (int base = 0; base < blen; base += 64) {
@@ -631,7 +650,7 @@ template <int WLEN> __device__ int calcAffineScoreW(const U &u, const WaveLds<WL
 }
 
 // BBIndex.extendScore :2558-2833
-template <int WLEN> __device__ int extendScoreW(U &u, WaveLds<WLEN> &S, int strand, int value, int offs, int numHits, int chrom, int centerIndex) {
+template <int WLEN> __device__ __forceinline__ int extendScoreW(U &u, WaveLds<WLEN> &S, int strand, int value, int offs, int numHits, int chrom, int centerIndex) {
     const bbidx_params &p = u.ix->p;
     const int blen = u.blen, lane = u.lane, k = u.k;
     const int centerVal = rl(value, centerIndex), centerLoc = u.c.siteOf(centerVal);
@@ -710,8 +729,86 @@ template <int WLEN> __device__ int extendScoreW(U &u, WaveLds<WLEN> &S, int stra
     return uni(calcAffineScoreW(u, S, strand, p.kfilter));
 }
 
+// An upper bound of extendScore for a site with at most three hit keys in range (up to three diagonals), from one pass over the
+// read.  extendScore only ever assigns a base to a diagonal on which it matches the reference, so with m(q) = "base q matches
+// on one of the diagonals": calcAffineScore gives an assigned base at most 100 + baseScore, an unassigned one at most -25
+// (POINTS_SUB_ARRAY's mildest entry) and an N exactly 0.  slowWalk3 uses a site's score only through `score >= cutoff` and
+// `score == maxScore`: when the bound is below both, the site cannot do anything and its extension is not computed.  The reads
+// that need this are the ones with few hit keys (many substitutions): their hit cutoff is 1 or 2, so every chance hit of a
+// single key is a site -- hundreds per read -- and nearly all of them fail here.  Returns INT_MAX when it does not apply.
+#ifndef BBIDX_EXTEND_BOUND
+#define BBIDX_EXTEND_BOUND 1
+#endif
+#ifndef BBIDX_CYCLE_LOW
+#define BBIDX_CYCLE_LOW 1           // 0: walks that start at a hit cutoff of 1 take the sequential heap walk
+#endif
+template <int WLEN> __device__ __forceinline__ int extendBoundW(U &u, const WaveLds<WLEN> &S, int strand, int value, int numHits, int chrom, int centerIndex) {
+    const bbidx_params &p = u.ix->p;
+    const int blen = u.blen, lane = u.lane;
+    const int centerVal = rl(value, centerIndex);
+    const int minVal = centerVal - p.maxIndel, maxVal = centerVal + p.maxIndel2;
+    const u64 R = __ballot(lane < numHits && value >= minVal && value <= maxVal);
+    if (popc(R) > 3) return INT_MAX;
+    int d0 = -1, d1 = -1, d2 = -1, nd = 0;
+    for (u64 m = R; m; m &= m - 1) {
+        const int rbse = u.c.siteOf(rl(value, __builtin_ctzll(m)));
+        if (nd == 0) { d0 = rbse; nd = 1; }
+        else if (rbse != d0 && nd == 1) { d1 = rbse; nd = 2; }
+        else if (rbse != d0 && rbse != d1 && nd == 2) { d2 = rbse; nd = 3; }
+    }
+    const uint8_t *ref = u.ix->chromArr[chrom];
+    const int reflen = u.ix->chromArrLen[chrom];
+    const uint8_t *rb = S.base[strand];
+    int total = 0;
+    for (int base = 0; base < blen; base += 64) {
+        const int q = base + lane;
+        int c = 0;
+        if (q < blen) {
+            const int b = rb[q];
+            bool m = d0 + q < reflen && b == ref[d0 + q];
+            if (nd > 1) m |= d1 + q < reflen && b == ref[d1 + q];
+            if (nd > 2) m |= d2 + q < reflen && b == ref[d2 + q];
+            c = b == 'N' ? 0 : (m ? max(100 + (int)S.bsc[strand ? blen - 1 - q : q], -25) : -25);
+        }
+        total += c;
+    }
+    u.cRefBytes += (unsigned)(blen * nd);
+    return wsum(total);
+}
+
+// extendScore of a site hit by ONE key, one site per lane.  With a single key in range the first-key rule applies to it in both
+// directions -- backward and forward it runs through mismatches and assigns every base that matches on its diagonal (:2598-2700)
+// -- so the location array is the match mask of that diagonal, and calcAffineScore over it is a run-length sum: an assigned base
+// scores 100 + baseScore after an assigned one and 70 + baseScore otherwise, the t-th base of a run of unassigned ones
+// POINTS_SUB_ARRAY[t], an N nothing (and it ends either run).  The caller keeps away the sites this does not hold for: refbase 0
+// (calcAffineScore tests loc > 0), a window that reaches the end of the chromosome array, kfilter > 1.
+template <int WLEN> __device__ __forceinline__ int singleKeyScoreLane(const U &u, const WaveLds<WLEN> &S, int strand, const uint8_t *ref, int refbase, bool active) {
+    const int blen = u.blen;
+    const uint8_t *rb = S.base[strand];
+    const int sh = (int)((unsigned long long)(ref + refbase) & 3ull);
+    const unsigned *rw = (const unsigned *)(ref + refbase - sh);
+    const int nw = (sh + blen + 3) >> 2, nwMax = (blen + 6) >> 2;
+    int score = 0, run = 0; bool prevA = false;
+    unsigned w = active ? rw[0] : 0u;
+    for (int j = 0; j < nwMax; j++) {
+        const unsigned nxt = (active && j + 1 < nw) ? rw[j + 1] : 0u;    // the next word is on its way while this one is used
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int q = 4 * j + t - sh;
+            if (active && q >= 0 && q < blen) {
+                const int b = rb[q], r = (int)((w >> (8 * t)) & 255u);
+                if (b == 'N') { run = 0; prevA = false; }
+                else if (b == r) { score += (prevA ? 100 : 70) + (int)S.bsc[strand ? blen - 1 - q : q]; prevA = true; run = 0; }
+                else { run++; score += subArr(run); prevA = false; }
+            }
+        }
+        w = nxt;
+    }
+    return score;
+}
+
 // BBIndex.makeGapArray :2837-2878 -- rare (a site spanning more than MINGAP + read length); one lane walks LDS
-template <int WLEN> __device__ int makeGapArrayW(const U &u, WaveLds<WLEN> &S, int minLoc, int minGap) {
+template <int WLEN> __device__ __forceinline__ int makeGapArrayW(const U &u, WaveLds<WLEN> &S, int minLoc, int minGap) {
     if (u.lane == 0) {
         int *locArray = S.loc;
         const int n = u.blen;
@@ -741,7 +838,7 @@ template <int WLEN> __device__ int makeGapArrayW(const U &u, WaveLds<WLEN> &S, i
 }
 
 // SiteScore.setPerfect (current/stream/SiteScore.java:239-292): order-independent form
-template <int WLEN> __device__ void setPerfectW(const U &u, const WaveLds<WLEN> &S, int chrom, int strand, int start, int stop, int &perfectOut, int &semiOut) {
+template <int WLEN> __device__ __forceinline__ void setPerfectW(const U &u, const WaveLds<WLEN> &S, int chrom, int strand, int start, int stop, int &perfectOut, int &semiOut) {
     const int blen = u.blen;
     perfectOut = 0; semiOut = 0;
     if (blen != stop - start + 1) return;
@@ -775,13 +872,13 @@ template <int WLEN> __device__ void setPerfectW(const U &u, const WaveLds<WLEN> 
     semiOut = semi ? 1 : 0;
     perfectOut = (perfect && !anyBad && semi && N == 0) ? 1 : 0;
 }
-__device__ inline bool overlap(int a1, int b1, int a2, int b2) { return a2 <= b1 && b2 >= a1; }
+__device__ __forceinline__ bool overlap(int a1, int b1, int a2, int b2) { return a2 <= b1 && b2 >= a1; }
 
 struct SiteOut { bbidx_site *v; int n, cap; bool overflow; };
 struct PrevSite { int idx, chrom, strand, start, stop, score, perfect, semiperfect, ngaps; };
 
 // BBIndex.slowWalk3 :1219-1706
-template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S, CycleLds *C, WL &L, int strand, int numKeys, int mqs, int baseChrom_,
+template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, WaveLds<WLEN> &S, CycleLds *C, WL &L, int strand, int numKeys, int mqs, int baseChrom_,
                            SiteOut &ssl, int *bestScores, bool allBasesCovered, int maxScore, bool fullyDefined) {
     const bbidx_params &p = u.ix->p;
     const int blen = u.blen, lane = u.lane;
@@ -816,6 +913,7 @@ template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S
         const int minsite = site - p.maxIndel, maxsite = site + p.maxIndel2;
         const bool inr = (unsigned)L.value - (unsigned)minsite <= (unsigned)(maxsite - minsite);
         const int approxHits = popc(mask_ule((unsigned)L.value - (unsigned)minsite, (unsigned)(maxsite - minsite)));
+        PH_WALK(u, 1);
         if (approxHits >= approxHitsCutoff) {
             const int centerIndex = __builtin_ctzll(mask_eq(L.hv, site));
             const int maxNearbySite = wmax(inr ? L.value : site);
@@ -829,16 +927,24 @@ template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S
                 const int chrom = u.c.chromOf(site, baseChrom);
                 if (shortCircuit && qscore == mqs) score = maxScore;
                 else {
-                    PH_MARK(u, 3);
-                    score = extendScoreW(u, S, strand, L.value, L.offs, numHits, chrom, centerIndex);
-                    PH_MARK(u, 4);
-                    locArrayValid = true;
-                    int mn = INT_MAX, mx = INT_MIN;
-                    for (int i = lane; i < blen; i += 64) { const int x = S.loc[i]; if (x > -1) { mn = min(mn, x); mx = max(mx, x); } }
-                    mn = wmin(mn); mx = wmax(mx);
-                    if (mn < 0 || mx < 0) score = -99999;
-                    mapStart = u.c.toNumber(mn, chrom);
-                    mapStop = u.c.toNumber(mx, chrom);
+                    PH_MARK(u, 3); PH_WALK(u, 2);
+                    bool hopeless = false;
+                    if (BBIDX_EXTEND_BOUND && approxHits <= 3) {
+                        const int ub = uni(extendBoundW(u, S, strand, L.value, numHits, chrom, centerIndex));
+                        hopeless = ub < cutoff && ub < maxScore;
+                    }
+                    if (hopeless) { score = -1; u.cExtend++; }
+                    else {
+                        score = extendScoreW(u, S, strand, L.value, L.offs, numHits, chrom, centerIndex);
+                        locArrayValid = true;
+                        int mn = INT_MAX, mx = INT_MIN;
+                        for (int i = lane; i < blen; i += 64) { const int x = S.loc[i]; if (x > -1) { mn = min(mn, x); mx = max(mx, x); } }
+                        mn = wmin(mn); mx = wmax(mx);
+                        if (mn < 0 || mx < 0) score = -99999;
+                        mapStart = u.c.toNumber(mn, chrom);
+                        mapStop = u.c.toNumber(mx, chrom);
+                    }
+                    PH_MARK(u, 4); PH_WALK(u, 3);
                 }
                 if (score == maxScore) {
                     qcutoff = max(qcutoff, (int)(mqs * DYN_QSCORE_PERFECT));
@@ -846,6 +952,7 @@ template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S
                 }
                 if (score >= cutoff) { qcutoff = max(qcutoff, (int)(qscore * DYN_QSCORE)); bestqscore = max(qscore, bestqscore); }
             }
+            PH_WALK(u, 2);
             if (score >= cutoff) {
                 if (score > currentTopScore) {
                     maxHits = max(approxHits, maxHits);
@@ -948,32 +1055,69 @@ template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S
                     }
                 }
             }
+            PH_WALK(u, 4);
         }
         return approxHits;
     };
     bool cycled = false;
-    if (LONG && BBIDX_CYCLE && C != nullptr && approxHitsCutoff >= 2 && max(p.maxIndel, p.maxIndel2) <= 32768) {
+    // A walk that starts at a hit cutoff of 1 (reads with few hit keys) looks at EVERY entry: an isolated one is a site with one
+    // hit, whose quick score is the fixed keyScore + scoreZ1Key (isoq) and whose extendScore follows from its diagonal alone.
+    const bool lowCutoff = approxHitsCutoff <= 1;
+    const bool lowOk = BBIDX_CYCLE_LOW && filter_by_qscore && p.kfilter <= 1 && wmin(lane < numHits ? L.ksc : INT_MAX) > 0 &&
+                       wmax(lane < numHits ? L.ksc : 0) + u.scoreZ1Key < 65535;
+    if (LONG && BBIDX_CYCLE && C != nullptr && (!lowCutoff || lowOk) && max(p.maxIndel, p.maxIndel2) <= 32768) {
         // whole-cycle form (see findMaxQscore2Cycle): at a hit cutoff >= 2 an isolated entry can neither be scored nor change
         // any state, so only the candidates are visited, in site order, each followed by popSite's exit rule
         CycleLanes cl; int E;
+        PH_WALK(u, 0);
         const int ncand = cycleLoad(u, *C, S, L, baseChrom, cl, E);
-        if (ncand >= 0) {
+        PH_WALK(u, 0);
+        int npass = 0;
+        int *passv = S.xch[1];                                 // the load phase's scratch rows are free again (cs[] is S.xch[0])
+        if (ncand >= 0 && lowCutoff) {
+            // The isolated entries that pass the quick-score filter are scored exactly, one per lane; the few that reach the score
+            // cutoff (or a case singleKeyScoreLane does not cover) join the candidates and are visited in site order like them.
+            // The thresholds only rise during the walk, so the ones that fail here would fail at their turn too.
+            for (int base = 0; base < E && npass <= 64; base += 64) {
+                const int e = base + lane;
+                const int iq = e < E ? (int)C->isoq[e] : 0;
+                const bool need = iq != 0 && iq >= qcutoff;
+                if (!__ballot(need)) continue;
+                const int v = need ? C->ent[e] : 0;
+                const int chrom = u.c.chromOf(v, baseChrom), refbase = u.c.siteOf(v);
+                const int reflen = need ? u.ix->chromArrLen[chrom] : 0;
+                const bool plain = need && refbase > 0 && refbase + blen + 4 < reflen;
+                const uint8_t *ref = plain ? u.ix->chromArr[chrom] : nullptr;
+                const int sc = singleKeyScoreLane(u, S, strand, ref, refbase, plain);
+                const bool pass = need && (!plain || sc >= cutoff || sc == maxScore);
+                u.cExtend += (unsigned)popc(__ballot(plain && !pass));
+                u.cRefBytes += (unsigned)(blen * popc(__ballot(plain)));
+                const u64 PM = __ballot(pass);
+                if (pass) { const int slot = npass + popc(PM & lt_mask(lane)); if (slot < 64) passv[slot] = v; }
+                npass += popc(PM);
+            }
+            wsync();
+        }
+        if (ncand >= 0 && npass <= 64) {
             cycled = true;
             u.cWalk += (unsigned)E;
             // the candidate sites sit in S.xch, which nothing inside visit() touches (compaction and the greedy trim are over)
             const int *cs = S.xch[0];
-            int site = cycleNext(u, cs, ncand, INT_MIN);
-            // pops in front of the first candidate are isolated: the loop may already end there
-            if (site != INT_MAX && cycleExitSite(u, cl, numHits, INT_MIN, approxHitsCutoff) < site) site = INT_MAX;
-            while (site != INT_MAX) {
-                reuni(); site = uni(site);
+            int prev = INT_MIN;
+            for (;;) {
+                reuni(); prev = uni(prev);
+                const int nextC = cycleNext(u, cs, ncand, prev);
+                const int site = approxHitsCutoff <= 1 ? min(nextC, cycleNext(u, passv, npass, prev)) : nextC;
+                // at a cutoff >= 2 the pops between two candidates are isolated, and the loop may end among them (or at `prev`)
+                if (approxHitsCutoff >= 2) {
+                    const int X = cycleExitSite(u, cl, numHits, prev, approxHitsCutoff);
+                    if (X < site || (X == prev && prev != INT_MIN)) break;
+                }
+                if (site == INT_MAX) break;
                 cycleSeek(u, *C, cl, L, site);
                 visit(site);
                 if (uni(finished)) break;
-                const int X = cycleExitSite(u, cl, numHits, site, approxHitsCutoff);
-                const int next = cycleNext(u, cs, ncand, site);
-                if (X == site || X < next) break;
-                site = next;
+                prev = site;
             }
         }
     }
@@ -993,6 +1137,7 @@ template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S
         BST(u, 4, 1);
         popSite(u, L, site, approxHitsCutoff, false, baseChrom, u.cWalk);
     }
+    PH_WALK(u, 1);
     bestScores[0] = max(bestScores[0], currentTopScore);
     bestScores[1] = max(bestScores[1], maxHits);
     bestScores[2] = max(bestScores[2], qcutoff);
@@ -1002,7 +1147,7 @@ template <bool LONG, int WLEN> __device__ void slowWalk3W(U &u, WaveLds<WLEN> &S
 }
 
 // Solver.valueOfElement (current/align2/Solver.java:97-151)
-__device__ long long valueOfElement(const int *offsets, int noffsets, const int *lengths, float keyWeight, int chunk,
+__device__ __forceinline__ long long valueOfElement(const int *offsets, int noffsets, const int *lengths, float keyWeight, int chunk,
                                     const int *lists, int numlists, int index, long long pointsPerSite) {
     const long long PPL = 30000, PPB1 = 6000, BONUS_END = 40000, WIDTH = 5500, SPACING = -30;
     if (numlists < 1) return 0;
@@ -1030,7 +1175,7 @@ __device__ long long valueOfElement(const int *offsets, int noffsets, const int 
 // BBIndex.trimExcessHitListsByGreedy :266-350 (+ Solver.findWorstGreedy :46-95): lane j evaluates list position j,
 // the "first strict prefix minimum below the early-termination score" rule comes from an exclusive prefix-min scan.
 // x = lengths[lane] (COUNTS of the lane's key), key = keys[lane]; both are updated in place.
-template <int WLEN> __device__ int trimByGreedyW(const U &u, WaveLds<WLEN> &S, int off, int ksc, int n, int maxHitLists, int &key, int &x) {
+template <int WLEN> __device__ __forceinline__ int trimByGreedyW(const U &u, WaveLds<WLEN> &S, int off, int ksc, int n, int maxHitLists, int &key, int &x) {
     const DevIndex &ix = *u.ix;
     const bbidx_params &p = ix.p;
     const int lane = u.lane;
@@ -1081,7 +1226,7 @@ template <int WLEN> __device__ int trimByGreedyW(const U &u, WaveLds<WLEN> &S, i
 
 // Compaction: lanes with keep==true move to lanes 0..count-1.  One LDS round trip publishes, for every destination
 // lane, the lane it takes its values from; the values themselves then move with ds_bpermute (no LDS storage).
-template <int WLEN> __device__ inline int compactSrc(WaveLds<WLEN> &S, int lane, bool keep, int &count) {
+template <int WLEN> __device__ __forceinline__ int compactSrc(WaveLds<WLEN> &S, int lane, bool keep, int &count) {
     const u64 M = __ballot(keep);
     wsync();
     if (keep) S.xch[0][popc(M & lt_mask(lane))] = lane;
@@ -1097,7 +1242,7 @@ template <int WLEN> __device__ inline int compactSrc(WaveLds<WLEN> &S, int lane,
 struct KeyHit { int cnt, start, len, first; };
 
 // the minus-strand view of lane i is the reverse-complement half of the record held by lane n-1-i
-__device__ inline KeyHit minusView(int lane, int n, int cntRC, int startR, int lenR, int firstR) {
+__device__ __forceinline__ KeyHit minusView(int lane, int n, int cntRC, int startR, int lenR, int firstR) {
     const int src = (lane < n) ? n - 1 - lane : lane;
     KeyHit h;
     h.cnt = __shfl(cntRC, src); h.start = __shfl(startR, src); h.len = __shfl(lenR, src); h.first = __shfl(firstR, src);
@@ -1105,7 +1250,7 @@ __device__ inline KeyHit minusView(int lane, int n, int cntRC, int startR, int l
 }
 
 // BBIndex.getHits (:354-391) + the heap fill at the top of slowWalk3/findMaxQscore2: builds the compacted lists
-template <bool LONG, int WLEN> __device__ int makeListsW(const U &u, WaveLds<WLEN> &S, WL &L, int block, int baseChrom, const KeyHit &h, int off, int ksc, int n, int minHits, bool refill = true) {
+template <bool LONG, int WLEN> __device__ __forceinline__ int makeListsW(const U &u, WaveLds<WLEN> &S, WL &L, int block, int baseChrom, const KeyHit &h, int off, int ksc, int n, int minHits, bool refill = true) {
     const bool hit = u.lane < n && h.cnt > 0 && h.len > 0 && h.first != -1;
     const u64 M = __ballot(hit);
     const int nh = popc(M);
@@ -1310,15 +1455,19 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
                 const int baseChrom = u.c.baseChrom(chrom);
                 const int block = baseChrom >> p.chromBits;
                 for (int pmi = 0; pmi < 2 && !earlyOut; pmi++, cycle++) {
+                    PH_PRE(u, 3);
                     const int nh = makeListsW<LONG>(u, S, L, block, baseChrom, keyHits(block, pmi), pmi ? offM : off, pmi ? kscM : ksc, n, minHitsToScore,
                                                     !(LONG && BBIDX_CYCLE));
+                    PH_PRE(u, 0);
                     if (nh < minHitsToScore) { if (lane == cycle) { prescore = -9999; precount = 0; } }
                     else {
                         int tq, th;
                         const bool perfectOnly = bestqscore >= mqs && pretend;
                         if (!(LONG && BBIDX_CYCLE && !perfectOnly && findMaxQscore2Cycle(u, cyc[LONG ? wave : 0], S, L, baseChrom, minHitsToScore, n, mqs, tq, th))) {
+                            PH_PRE(u, 3);
                             if (LONG && BBIDX_CYCLE) refillLists(L);
                             findMaxQscore2W<LONG>(u, L, baseChrom, minHitsToScore, perfectOnly, n, mqs, tq, th);
+                            PH_PRE(u, 4);
                         }
                         if (lane == cycle) { prescore = tq; precount = th; }
                         bestqscore = max(tq, bestqscore); maxHits = max(maxHits, th);
@@ -1338,7 +1487,7 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
                 qscoreCutoff = max(qscoreCutoff, (int)(bestScores[3] * PRESCAN_QSCORE_THRESH));
             }
         }
-        PH_MARK(u, 2);
+        PH_PRE(u, 3); PH_MARK(u, 2);
         if (uni(dead)) { result = 0; break; }
         hitsCutoff = uni(hitsCutoff); qscoreCutoff = uni(qscoreCutoff); n = uni(n);
 
@@ -1352,6 +1501,7 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
                 for (int j = 0; j < 6; j++) bestScores[j] = uni(bestScores[j]);
                 ssl.n = uni(ssl.n); ssl.overflow = uni(ssl.overflow); cycle = uni(cycle); quit = uni(quit);
                 if (!prescan || rl(precount, cycle) >= hitsCutoff || rl(prescore, cycle) >= qscoreCutoff) {
+                    PH_WALK(u, 1);
                     const int nh = makeListsW<LONG>(u, S, L, block, baseChrom, keyHits(block, strand), strand ? offM : off, strand ? kscM : ksc, n, p.minApproxHitsToKeep,
                                                     !(LONG && BBIDX_CYCLE));
                     if (nh >= p.minApproxHitsToKeep)

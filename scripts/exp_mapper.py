@@ -1,4 +1,5 @@
-"""Stage timings of the device mapper on one of bench.py's workloads: python scripts/exp_mapper.py [hg38|chr21|ecoli] [n_reads] [max_sites]"""
+"""Stage timings of the device mapper on one of bench.py's workloads:
+python scripts/exp_mapper.py [hg38|chr21|ecoli] [n_reads] [max_sites] [repeat_frac (default: the workload's)]"""
 import json
 import sys
 import time
@@ -13,7 +14,11 @@ name = sys.argv[1] if len(sys.argv) > 1 else "hg38"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2000000
 max_sites = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 lens, paired, _ = B.WORKLOADS[name]
-chroms, _ = B.shared_reference(name, lens, 0.0 if name == "ecoli" else 0.1, 0, 1)
+rf = float(sys.argv[4]) if len(sys.argv) > 4 else (0.0 if name == "ecoli" else 0.1)
+chroms, _ = B.shared_reference(name, lens, rf, 0, 1)
+if len(sys.argv) > 5:                      # hard_frac override (share of the mates riddled with substitutions)
+    import functools
+    W.make_pairs = functools.partial(W.make_pairs, hard_frac=float(sys.argv[5]))
 reads = B.make_batch(chroms, n, paired, 4)
 t = time.time()
 di = DeviceIndex.build(chroms, k=13)

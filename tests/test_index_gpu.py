@@ -133,3 +133,54 @@ def test_long_lists_small_k_two_blocks():
     reads = make_reads(21, genomes, 120, k=9)
     tweak = {"maxUsableLength": 400, "maxUsableLength2": 800}      # keep the long lists (analyzeIndex would drop most of them)
     assert run_case(genomes, 9, 1, reads, tweak=tweak, cap=64) > 40
+
+
+def _hard_reads(seed, genomes, n, k, read_len=150, sub=(0.08, 0.16)):
+    """Reads riddled with substitutions (a few keys hit, so the walk starts at a hit cutoff of 1 and every list entry is a
+    site), some with Ns, some hanging over either end of their chromosome, with and without base / key scores."""
+    import random
+    from oracle.oracle import make_offsets
+    from tests.index_problems import revcomp
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        ci = rng.randrange(len(genomes))
+        G = genomes[ci]
+        L = read_len
+        where = rng.random()
+        if where < 0.1:
+            st = rng.randrange(380, 420)                       # around the first defined base
+        elif where < 0.2:
+            st = len(G) - L - rng.randrange(380, 420)          # around the last one
+        else:
+            st = rng.randrange(400, len(G) - L - 400)
+        rd = bytearray(G[st:st + L])
+        for p in range(L):
+            if rng.random() < rng.uniform(*sub):
+                rd[p] = rng.choice(b"ACGT")
+        if rng.random() < 0.2:
+            rd[rng.randrange(L)] = ord("N")
+        rd = bytes(rd)
+        if b"N" * 20 in rd:
+            continue
+        strand = 1 if rng.random() < 0.5 else 0
+        bp = revcomp(rd) if strand else rd
+        offs = make_offsets(L, k, 1.9)
+        if rng.random() < 0.5:
+            ks, bs = [100 * k] * len(offs), [0] * L
+        else:
+            ks, bs = [rng.randint(100 * k // 8, 100 * k) for _ in offs], [rng.randint(0, 30) for _ in range(L)]
+        out.append((bp, revcomp(bp), bs, ks, offs, (ci + 1, strand, st)))
+    return out
+
+
+def test_few_hit_keys_walk_at_cutoff_one():
+    # reads with 8-16 % substitutions: a handful of keys hit, the hit cutoff is 1, so the walk treats every list entry as a site
+    # (quick-score filter, then extendScore from that one key).  Long lists (k=9, two blocks) and ordinary ones (k=13).
+    import random
+    rng = random.Random(5)
+    genomes = [b"N" * 400 + bytes(rng.choice(b"ACGT") for _ in range(1200000)) + b"N" * 400 for _ in range(3)]
+    tweak = {"maxUsableLength": 400, "maxUsableLength2": 800}
+    assert run_case(genomes, 9, 1, _hard_reads(31, genomes, 90, 9), tweak=tweak, cap=64) > 20
+    g13 = [make_genome(9, 300000), make_genome(10, 200000)]
+    assert run_case(g13, 13, 1, _hard_reads(32, g13, 200, 13, sub=(0.05, 0.14)), cap=64) > 60
