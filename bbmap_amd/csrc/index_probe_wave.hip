@@ -47,25 +47,30 @@ using namespace wavep;
 #define CST(u, i, v) do { } while (0)
 #endif
 // debug builds with cycle counters: -DBBIDX_PHASE_TIMERS=1 the read's phases {keys + lookup, trim / setup, prescan, walk, extend};
-// =2 inside the walk {lists + cycle load, candidate stepping, quick scores, extendScore, site bookkeeping}; =3 inside the prescan
+// =2 inside the walk, extendScore left out {lists + cycle load, candidate stepping, quick scores + site bookkeeping,
+// single-key batch of a walk at cutoff 1, sequential heap walk}; =3 inside the prescan
 // {lists, cycle gather, candidate filter, candidate loop, sequential fallback}
 #define PH_ADD_(u, i) do { const unsigned long long now_ = __builtin_readcyclecounter(); (u).ph[i] += (unsigned)(now_ - (u).phT); (u).phT = now_; } while (0)
 #define PH_SKIP_(u) do { (u).phT = __builtin_readcyclecounter(); } while (0)
 #if defined(BBIDX_PHASE_TIMERS) && BBIDX_PHASE_TIMERS == 2
 #define PH_MARK(u, i) PH_SKIP_(u)
 #define PH_WALK(u, i) PH_ADD_(u, i)
+#define PH_SKIPW(u) PH_SKIP_(u)
 #define PH_PRE(u, i) do { } while (0)
 #elif defined(BBIDX_PHASE_TIMERS) && BBIDX_PHASE_TIMERS == 3
 #define PH_MARK(u, i) PH_SKIP_(u)
 #define PH_WALK(u, i) do { } while (0)
+#define PH_SKIPW(u) do { } while (0)
 #define PH_PRE(u, i) PH_ADD_(u, i)
 #elif defined(BBIDX_PHASE_TIMERS)
 #define PH_MARK(u, i) PH_ADD_(u, i)
 #define PH_WALK(u, i) do { } while (0)
+#define PH_SKIPW(u) do { } while (0)
 #define PH_PRE(u, i) do { } while (0)
 #else
 #define PH_MARK(u, i) do { } while (0)
 #define PH_WALK(u, i) do { } while (0)
+#define PH_SKIPW(u) do { } while (0)
 #define PH_PRE(u, i) do { } while (0)
 #endif
 
@@ -909,11 +914,12 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
         ssl.n = uni(ssl.n); ssl.overflow = uni(ssl.overflow); finished = uni(finished); u.cWalk = uni(u.cWalk); u.cExtend = uni(u.cExtend); u.cRefBytes = uni(u.cRefBytes);
     };
     // one site of the merged lists with every list's head / value in L (the reference's loop body between two polls)
+    bool seqMode = false;                                      // (phase timers: the sequential walk is accounted separately)
     auto visit = [&](const int site) -> int {
         const int minsite = site - p.maxIndel, maxsite = site + p.maxIndel2;
         const bool inr = (unsigned)L.value - (unsigned)minsite <= (unsigned)(maxsite - minsite);
         const int approxHits = popc(mask_ule((unsigned)L.value - (unsigned)minsite, (unsigned)(maxsite - minsite)));
-        PH_WALK(u, 1);
+        PH_WALK(u, seqMode ? 4 : 1);
         if (approxHits >= approxHitsCutoff) {
             const int centerIndex = __builtin_ctzll(mask_eq(L.hv, site));
             const int maxNearbySite = wmax(inr ? L.value : site);
@@ -927,7 +933,7 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
                 const int chrom = u.c.chromOf(site, baseChrom);
                 if (shortCircuit && qscore == mqs) score = maxScore;
                 else {
-                    PH_MARK(u, 3); PH_WALK(u, 2);
+                    PH_MARK(u, 3); PH_WALK(u, seqMode ? 4 : 2);
                     bool hopeless = false;
                     if (BBIDX_EXTEND_BOUND && approxHits <= 3) {
                         const int ub = uni(extendBoundW(u, S, strand, L.value, numHits, chrom, centerIndex));
@@ -944,7 +950,7 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
                         mapStart = u.c.toNumber(mn, chrom);
                         mapStop = u.c.toNumber(mx, chrom);
                     }
-                    PH_MARK(u, 4); PH_WALK(u, 3);
+                    PH_MARK(u, 4); PH_SKIPW(u);
                 }
                 if (score == maxScore) {
                     qcutoff = max(qcutoff, (int)(mqs * DYN_QSCORE_PERFECT));
@@ -952,7 +958,7 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
                 }
                 if (score >= cutoff) { qcutoff = max(qcutoff, (int)(qscore * DYN_QSCORE)); bestqscore = max(qscore, bestqscore); }
             }
-            PH_WALK(u, 2);
+            PH_WALK(u, seqMode ? 4 : 2);
             if (score >= cutoff) {
                 if (score > currentTopScore) {
                     maxHits = max(approxHits, maxHits);
@@ -1055,7 +1061,7 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
                     }
                 }
             }
-            PH_WALK(u, 4);
+            PH_WALK(u, seqMode ? 4 : 2);
         }
         return approxHits;
     };
@@ -1097,6 +1103,7 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
                 npass += popc(PM);
             }
             wsync();
+            PH_WALK(u, 3);
         }
         if (ncand >= 0 && npass <= 64) {
             cycled = true;
@@ -1121,6 +1128,8 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
             }
         }
     }
+    PH_WALK(u, 1);
+    seqMode = !cycled;
     if (LONG && BBIDX_CYCLE && !cycled) refillLists(L);          // makeListsW left the look-ahead buffers to this path
     while (!cycled && L.nlive > 0 && !finished) {
         reuni();
@@ -1137,7 +1146,7 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
         BST(u, 4, 1);
         popSite(u, L, site, approxHitsCutoff, false, baseChrom, u.cWalk);
     }
-    PH_WALK(u, 1);
+    PH_WALK(u, seqMode ? 4 : 1);
     bestScores[0] = max(bestScores[0], currentTopScore);
     bestScores[1] = max(bestScores[1], maxHits);
     bestScores[2] = max(bestScores[2], qcutoff);

@@ -965,6 +965,8 @@ struct bbmap_ctx {
     // The tier's pass runs beside the main pass (its reads are known once begin_kernel has run): its own stream, driven by its
     // own host thread, joined at the end of the batch.
     hipStream_t tierStream;
+    // second-context fills (few jobs, wide windows: a handful of waves per CU) run on a stream of their own beside the plain ones
+    hipStream_t dpStream; hipEvent_t evFork, evJoin;
     std::thread tierThread;
     bool tierStarted;
     int tierRc; char tierErr[320];
@@ -1005,6 +1007,9 @@ extern "C" void bbmap_destroy(bbmap_ctx *c) {
     if (c->tierThread.joinable()) c->tierThread.join();
     if (c->tier) bbmap_destroy(c->tier);
     if (c->tierStream) (void)hipStreamDestroy(c->tierStream);
+    if (c->dpStream) (void)hipStreamDestroy(c->dpStream);
+    if (c->evFork) (void)hipEventDestroy(c->evFork);
+    if (c->evJoin) (void)hipEventDestroy(c->evJoin);
     if (c->ownsMsa && c->msa) bbmsa_destroy(c->msa);
     if (c->ownsMsa && c->msaGapped) bbmsa_destroy(c->msaGapped);
     for (int i = 0; i < 12; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1106,6 +1111,10 @@ static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *par
     }
     if (hipHostMalloc((void **)&c->h_counters, 64 * 4) != hipSuccess) return bail(mfail(BBMAP_E_NOMEM, "bbmap_create: pinned allocation failed"));
     for (int i = 0; i < 12; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) return bail(mfail(BBMAP_E_HIP, "bbmap_create: hipEventCreate failed"));
+    if (!getenv("BBMAP_SERIAL_DP")) {
+        if (hipStreamCreateWithFlags(&c->dpStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess) return bail(mfail(BBMAP_E_HIP, "bbmap_create: stream / event creation failed"));
+    }
     *out = c;
     return BBMAP_OK;
 }
@@ -1144,12 +1153,19 @@ static int read_counters(bbmap_ctx *c, hipStream_t stream) {
 
 // launches the DP over the fills appended since (jobBase, gjobBase)
 static int run_fills(bbmap_ctx *c, hipStream_t stream, const uint8_t *bases, long long jobBase, long long nNew, long long gBase, long long gNew) {
+    // the second context's launches first, on their own stream: its blocks take their share of the CUs and the plain context's
+    // persistent blocks fill the rest (and the slots the others free)
+    hipStream_t gs = (c->dpStream && nNew > 0) ? c->dpStream : stream;
+    if (gNew > 0) {
+        if (gs != stream) { MHIP(hipEventRecord(c->evFork, stream)); MHIP(hipStreamWaitEvent(gs, c->evFork, 0)); }
+        MTRY(bbmsa_align_gapped_batch_device(c->msaGapped, gs, gNew, c->d_gjobs + gBase, c->d_ggaps + gBase, bases, c->refsBase,
+                                             c->d_gresults + gBase, c->d_gmatch + gBase * c->gmatchStride, c->gmatchStride));
+        if (gs != stream) MHIP(hipEventRecord(c->evJoin, gs));
+    }
     if (nNew > 0)
         MTRY(bbmsa_align_batch_device(c->msa, stream, nNew, c->d_jobs + jobBase, bases, c->refsBase, c->d_results + jobBase,
                                       c->d_match + jobBase * c->matchStride, c->matchStride));
-    if (gNew > 0)
-        MTRY(bbmsa_align_gapped_batch_device(c->msaGapped, stream, gNew, c->d_gjobs + gBase, c->d_ggaps + gBase, bases, c->refsBase,
-                                             c->d_gresults + gBase, c->d_gmatch + gBase * c->gmatchStride, c->gmatchStride));
+    if (gNew > 0 && gs != stream) MHIP(hipStreamWaitEvent(stream, c->evJoin, 0));
     return BBMAP_OK;
 }
 
