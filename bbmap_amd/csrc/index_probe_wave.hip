@@ -490,14 +490,16 @@ __device__ __forceinline__ void cycleSeek(const U &u, const CycleLds &C, CycleLa
 // The pop at which the reference's loop ends after the site `s` has been looked at with hit cutoff c >= 1 (popSite's rule: a
 // list runs out and fewer than c stay alive): INT_MAX if none (cannot happen: the very last entry always ends it).
 __device__ __forceinline__ int cycleExitSite(const U &u, CycleLanes &cl, int n, int s, int c) {
+    const int firstDeath = wmin((u.lane < n && cl.last >= s) ? cl.last : INT_MAX);
+    if (n - c < 0) return firstDeath;
+    if (n - c == 0) return max(firstDeath, wmin(u.lane < n ? cl.last : INT_MAX));    // every list has to be alive: the smallest last entry
     if (rl(cl.rank, 0) == -2) {                                // rank of every list's last entry (ascending, ties by lane)
         int rk = 0;
         for (int i = 0; i < n; i++) { const int li = rl(cl.last, i); rk += (li < cl.last || (li == cl.last && i < u.lane)) ? 1 : 0; }
         cl.rank = u.lane < n ? rk : -1;
     }
-    const int firstDeath = wmin((u.lane < n && cl.last >= s) ? cl.last : INT_MAX);
     int dstar = INT_MIN;
-    if (n - c >= 0) { const u64 K = __ballot(cl.rank == n - c); if (K) dstar = rl(cl.last, __builtin_ctzll(K)); }
+    { const u64 K = __ballot(cl.rank == n - c); if (K) dstar = rl(cl.last, __builtin_ctzll(K)); }
     return max(firstDeath, dstar);
 }
 
@@ -521,10 +523,16 @@ template <int WLEN> __device__ __forceinline__ bool findMaxQscore2Cycle(U &u, Cy
     int prev = INT_MIN;
     // at a cutoff >= 2 the pops in front of the first candidate are isolated and the loop may already end among them
     bool ended = approxHitsCutoff >= 2 && cycleExitSite(u, cl, numHits, INT_MIN, approxHitsCutoff) < cycleNext(u, cs, ncand, INT_MIN);
+    // the best quick score any isolated entry of the cycle has: once the running maximum is there, folding more of them is a no-op
+    int isoBest = 0;
+    if (!ended && approxHitsCutoff <= 1) {
+        for (int base = 0; base < E; base += 64) { const int e = base + lane; if (e < E) isoBest = max(isoBest, (int)C.isoq[e]); }
+        isoBest = wmax(isoBest);
+    }
     while (!ended) {
         approxHitsCutoff = uni(approxHitsCutoff); topQscore = uni(topQscore); maxHits = uni(maxHits); prev = uni(prev);
         const int site = cycleNext(u, cs, ncand, prev);
-        if (approxHitsCutoff <= 1) {
+        if (approxHitsCutoff <= 1 && isoBest > topQscore) {
             // isolated entries below this candidate (all remaining ones after the last candidate): each is a site with one hit
             int m = 0;
             for (int base = 0; base < E; base += 64) {
