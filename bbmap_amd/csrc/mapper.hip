@@ -159,18 +159,45 @@ __device__ int calc_gref_len(const Site &ss) {                                  
 }
 
 // ---------------------------------------------------------------------------------------------- byte scans (one thread)
+// A thread's consecutive bytes through aligned 32-bit loads: one thread per read means 64 lanes in 64 different cache lines, and a
+// byte load costs the L1 as much as a dword load -- four bytes per access instead of one.  Only words that hold a byte below `n`
+// are touched.
+struct Words {
+    const unsigned *w; unsigned lo; int sh, n, k;
+    __device__ void init(const uint8_t *p, int n_) {
+        sh = (int)((unsigned long long)p & 3ull); w = (const unsigned *)(p - sh); n = n_; k = 0;
+        lo = n > 0 ? w[0] : 0u;
+    }
+    __device__ unsigned next() {                       // bytes p[4k .. 4k+3] of the k-th call
+        k++;
+        const unsigned hi = (4 * k - sh < n) ? w[k] : 0u;
+        const unsigned x = sh ? __builtin_amdgcn_alignbyte(hi, lo, (unsigned)sh) : lo;
+        lo = hi;
+        return x;
+    }
+};
 // MSA.scoreNoIndels(read, ref, refStart) (MultiStateAligner11tsJNI.java:1034-1089)
 __device__ int score_no_indels(const uint8_t *read, int len, const uint8_t *ref, int reflen, int refStart) {
     int readStart = 0, readStop = len;
     if (refStart < 0) readStart = -refStart;
     if (refStart + len > reflen) readStop -= (refStart + len - reflen);
     int score = 0, mode = -1, t = 0;                  // mode 0 = match streak, 1 = substitution streak
-    for (int i = readStart; i < readStop; i++) {
-        const int c = read[i], r = ref[refStart + i];
-        if (c == r && c != 'N') { if (mode == 0) { t++; score += 100; } else { t = 0; score += 70; } mode = 0; }
-        else if (c >= 128 || c == 'N') { }
-        else if (r >= 128 || r == 'N') { }
-        else { if (mode == 1) t++; else t = 0; score += (t + 1 > 5 ? -25 : (t + 1 > 1 ? -51 : -127)); mode = 1; }
+    const int n = readStop - readStart;
+    if (n <= 0) return 0;
+    Words A, B;
+    A.init(read + readStart, n); B.init(ref + refStart + readStart, n);
+    for (int i = 0; i < n; i += 4) {
+        const unsigned c4 = A.next(), r4 = B.next();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (i + q < n) {
+                const int c = (int)((c4 >> (8 * q)) & 255u), r = (int)((r4 >> (8 * q)) & 255u);
+                if (c == r && c != 'N') { if (mode == 0) { t++; score += 100; } else { t = 0; score += 70; } mode = 0; }
+                else if (c >= 128 || c == 'N') { }
+                else if (r >= 128 || r == 'N') { }
+                else { if (mode == 1) t++; else t = 0; score += (t + 1 > 5 ? -25 : (t + 1 > 1 ? -51 : -127)); mode = 1; }
+            }
+        }
     }
     return score;
 }
@@ -184,12 +211,24 @@ __device__ void set_perfect(Site &ss, const uint8_t *bases, int len, const uint8
     if (ss.start < 0) { N -= ss.start; readloc -= ss.start; refloc -= ss.start; perfect = false; }
     if (ss.stop >= reflen) { N += (ss.stop - reflen + 1); perfect = false; }
     if (N > nlimit) return;
-    for (; refloc <= mx; refloc++, readloc++) {
-        const int c = bases[readloc], r = ref[refloc];
-        if (c != r || c == 'N') {
-            perfect = false;
-            if (c == 'N') semi = false;
-            if (r != 'N' || (N = N + 1) > nlimit) return;
+    const int n = mx - refloc + 1;
+    if (n > 0) {
+        Words A, B;
+        A.init(bases + readloc, n); B.init(ref + refloc, n);
+        for (int i = 0; i < n; i += 4) {
+            const unsigned c4 = A.next(), r4 = B.next();
+            if (c4 == r4 && !(((c4 ^ 0x4E4E4E4Eu) - 0x01010101u) & ~(c4 ^ 0x4E4E4E4Eu) & 0x80808080u) && i + 4 <= n) continue;   // four equal bases, none of them 'N'
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (i + q < n) {
+                    const int c = (int)((c4 >> (8 * q)) & 255u), r = (int)((r4 >> (8 * q)) & 255u);
+                    if (c != r || c == 'N') {
+                        perfect = false;
+                        if (c == 'N') semi = false;
+                        if (r != 'N' || (N = N + 1) > nlimit) return;
+                    }
+                }
+            }
         }
     }
     semi = semi && N <= nlimit;
