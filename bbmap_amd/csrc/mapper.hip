@@ -26,6 +26,8 @@
 #include <thread>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "bbmap_amd.h"
 #include "index_ctx.h"
 
@@ -968,6 +970,22 @@ __global__ __launch_bounds__(128) void mark_tier_kernel(int *mcount, const int *
     mcount[r] = BBMAP_NSITES_IN_TIER;
 }
 
+// ---------------------------------------------------------------------------------------------- packed output
+__global__ __launch_bounds__(256) void pack_counts_kernel(const int *mcount, long long n, int *counts) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) { const int m = mcount[r]; counts[r] = m > 0 ? m : 0; }
+}
+// one 16-byte piece of a 128-byte site record per thread: eight consecutive lanes move one record
+__global__ __launch_bounds__(256) void pack_sites_kernel(const Site *ms, const int *mcount, const long long *offsets, long long n, int cap, long long packedCap, Site *packed) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long slot = t >> 3; const int piece = (int)(t & 7);
+    const long long r = slot / cap; const int j = (int)(slot - r * cap);
+    if (r >= n || j >= mcount[r]) return;
+    const long long dst = offsets[r] + j;
+    if (dst >= packedCap) return;
+    ((uint4 *)(packed + dst))[piece] = ((const uint4 *)(ms + r * cap + j))[piece];
+}
+
 }  // namespace bbmapper
 
 // ================================================================================================= host side
@@ -997,6 +1015,7 @@ struct bbmap_ctx {
     long long nJobs, nGapped;
     bool ran;
     // overflow tier: a second, small context with long site lists for the reads whose list did not fit max_sites
+    void *d_packTmp; size_t packTmpBytes;     // bbmap_pack_sites_device's scan scratch (allocated on first use)
     bbmap_ctx *tier;
     bool ownsMsa;
     int *d_tierUnits; bbidx_read *d_tierReads; int *d_tierReadIds;
@@ -1045,6 +1064,7 @@ extern "C" void bbmap_destroy(bbmap_ctx *c) {
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->tierThread.joinable()) c->tierThread.join();
     if (c->tier) bbmap_destroy(c->tier);
+    if (c->d_packTmp) (void)hipFree(c->d_packTmp);
     if (c->tierStream) (void)hipStreamDestroy(c->tierStream);
     if (c->dpStream) (void)hipStreamDestroy(c->dpStream);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
@@ -1434,6 +1454,34 @@ extern "C" int bbmap_map_batch_device(bbmap_ctx *c, void *stream_, int64_t n_rea
     MHIP(hipStreamSynchronize(stream));
     (void)hipEventElapsedTime(&c->stats.ms_overflow, e0, e1);      // what the tier added to the batch after the main pass
     c->stats.ms_total += c->stats.ms_overflow;
+    return BBMAP_OK;
+}
+
+// The batch's site lists without the empty slots: counts[r] sites of read r (0 for a read without a list: no site, flagged, or
+// mapped by the overflow tier) at packed[offsets[r] ...], offsets = exclusive prefix sums of counts (offsets[n] = their total).
+extern "C" int bbmap_pack_sites_device(bbmap_ctx *c, void *stream_, int64_t n_reads, int32_t *counts, int64_t *offsets, bbmap_msite *packed,
+                                       int64_t packed_cap) {
+    if (!c || !counts || !offsets || !packed) return mfail(BBMAP_E_ARG, "bbmap_pack_sites_device: null argument");
+    if (!c->ran || n_reads != c->stats.reads) return mfail(BBMAP_E_ARG, "bbmap_pack_sites_device: n_reads is not the last batch's");
+    hipStream_t stream = (hipStream_t)stream_;
+    MHIP(hipSetDevice(c->cfg.device));
+    const long long n = n_reads;
+    size_t need = 0;
+    MHIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, (const int *)counts, (long long *)offsets, (int)(n + 1), stream));
+    if (need > c->packTmpBytes) {
+        if (c->d_packTmp) { MHIP(hipStreamSynchronize(stream)); (void)hipFree(c->d_packTmp); c->d_packTmp = nullptr; c->packTmpBytes = 0; }
+        MHIP(hipMalloc(&c->d_packTmp, need));
+        c->packTmpBytes = need;
+    }
+    // counts has n + 1 entries for the scan (the last one a zero), so that offsets[n] is the total
+    hipLaunchKernelGGL(bbmapper::pack_counts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c->d_mcount, n, counts);
+    MHIP(hipGetLastError());
+    MHIP(hipMemsetAsync(counts + n, 0, 4, stream));
+    MHIP(hipcub::DeviceScan::ExclusiveSum(c->d_packTmp, need, (const int *)counts, (long long *)offsets, (int)(n + 1), stream));
+    const long long threads = n * c->cfg.max_sites * 8;
+    hipLaunchKernelGGL(bbmapper::pack_sites_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, c->d_ms, c->d_mcount, (const long long *)offsets, n,
+                       c->cfg.max_sites, (long long)packed_cap, packed);
+    MHIP(hipGetLastError());
     return BBMAP_OK;
 }
 

@@ -58,6 +58,8 @@ def _bind(L):
     L.bbmap_get_output.argtypes = [C.c_void_p, C.POINTER(bbmap_output)]
     L.bbmap_last_stats.argtypes = [C.c_void_p, C.POINTER(bbmap_stats)]
     L.bbmap_get_overflow_output.argtypes = [C.c_void_p, C.POINTER(bbmap_overflow_output)]
+    L.bbmap_pack_sites_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.bbmap_pack_sites_device.restype = C.c_int
     for f in ("bbmap_default_config", "bbmap_create", "bbmap_map_batch_device", "bbmap_get_output", "bbmap_last_stats",
               "bbmap_get_overflow_output"):
         getattr(L, f).restype = C.c_int
@@ -119,12 +121,30 @@ class Mapper:
         assert reads_u8.size == self.total_bytes
         self.bases[: self.total_bytes].copy_(torch.from_numpy(np.ascontiguousarray(reads_u8).reshape(-1)))
 
-    def step(self):
-        """Maps the resident batch; returns when it is done (bbmap_map_batch_device waits for its stream)."""
+    def step(self, bases=None):
+        """Maps the resident batch; returns when it is done (bbmap_map_batch_device waits for its stream).  bases: another
+        device buffer of 2 * n_reads * read_len bytes holding the batch's plus strands in its first half (a host that streams
+        batches uploads the next one while this one is mapped)."""
         stream = torch.cuda.current_stream().cuda_stream
-        _lib.check(self.L.bbmap_map_batch_device(self.h, C.c_void_p(stream), self.n, self.reads.data_ptr(), self.bases.data_ptr(),
+        b = self.bases if bases is None else bases
+        assert b.numel() == 2 * self.total_bytes and b.dtype == torch.uint8
+        _lib.check(self.L.bbmap_map_batch_device(self.h, C.c_void_p(stream), self.n, self.reads.data_ptr(), b.data_ptr(),
                                                  self.total_bytes, self.base_scores.data_ptr(), self.keyinfo.data_ptr()),
                    "bbmap_map_batch_device")
+
+    def pack_sites(self, counts, offsets, packed):
+        """The last step's site lists without their empty slots (bbmap_pack_sites_device), enqueued on the current stream:
+        counts int32[n+1], offsets int64[n+1], packed uint8[cap_records * 128] -- device tensors of the caller's."""
+        stream = torch.cuda.current_stream().cuda_stream
+        assert counts.numel() == self.n + 1 and offsets.numel() == self.n + 1 and packed.numel() % 128 == 0
+        _lib.check(self.L.bbmap_pack_sites_device(self.h, C.c_void_p(stream), self.n, counts.data_ptr(), offsets.data_ptr(),
+                                                  packed.data_ptr(), packed.numel() // 128), "bbmap_pack_sites_device")
+
+    def output_pointers(self):
+        """(bbmap_output of the last step) -- device pointers and counts, for callers that move the logs themselves."""
+        o = bbmap_output()
+        _lib.check(self.L.bbmap_get_output(self.h, C.byref(o)), "bbmap_get_output")
+        return o
 
     def stats(self):
         st = bbmap_stats()

@@ -182,6 +182,93 @@ def parity_sample(mp, out, oi, reads, L, paired, offsets, key_scores, count):
     return {"checked_reads": count, "mismatches": len(bad), "overflowed_in_sample": len(over), "first": bad[:3]}
 
 
+_HIP = None
+
+
+def _hip_copy(dst, src, nbytes, kind, stream):
+    """hipMemcpyAsync on raw pointers (kind 1 = host to device, 2 = device to host, 3 = device to device)."""
+    global _HIP
+    import ctypes as C
+    if _HIP is None:
+        _HIP = C.CDLL("libamdhip64.so")
+        _HIP.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        _HIP.hipMemcpyAsync.restype = C.c_int
+    if nbytes > 0:
+        rc = _HIP.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), nbytes, kind, C.c_void_p(stream))
+        if rc != 0:
+            raise SystemExit("hipMemcpyAsync failed (%d)" % rc)
+
+
+def streaming_region(mp, batches, steps, warmup):
+    """The same step with a DIFFERENT batch every time and the PCIe traffic a host would have inside the timed region: batch
+    i + 1 is uploaded (pinned host memory, second stream) while batch i is mapped, and batch i's results -- the site lists without
+    their empty slots (bbmap_pack_sites_device), the per-read counts and both fill logs with their traceback strings -- are copied
+    to pinned host memory while batch i + 1 is mapped.  Returns (seconds for `steps` steps, bytes up per step, bytes down per step)."""
+    import torch
+    dev, n, total = mp.dev, mp.n, mp.total_bytes
+    pin_in = [torch.from_numpy(np.ascontiguousarray(b).reshape(-1)).pin_memory() for b in batches]
+    dev_in = [torch.zeros(2 * total, dtype=torch.uint8, device=dev) for _ in range(2)]
+    cap_rec = int(n * 5)
+    counts = [torch.zeros(n + 1, dtype=torch.int32, device=dev) for _ in range(2)]
+    offsets = [torch.zeros(n + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+    packed = [torch.zeros(cap_rec * 128, dtype=torch.uint8, device=dev) for _ in range(2)]
+    o = None
+    mp.step()                                                     # sizes of the log staging buffers
+    o = mp.output_pointers()
+    job_cap, gjob_cap = int(o.n_jobs * 1.3) + 4096, int(o.n_gapped_jobs * 1.5) + 4096
+    per_job, per_gjob = 40 + 80 + 16 + o.match_stride, 40 + 80 + 16 + 68 + o.gmatch_stride
+    stage = [torch.zeros(job_cap * per_job + gjob_cap * per_gjob, dtype=torch.uint8, device=dev) for _ in range(2)]
+    host_out = [torch.zeros(4 * (n + 1) + cap_rec * 128 + stage[0].numel(), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    main = torch.cuda.current_stream()
+    copy = torch.cuda.Stream(device=dev)
+    h2d_done = [torch.cuda.Event() for _ in range(2)]
+    out_ready = [torch.cuda.Event() for _ in range(2)]
+    up = down = 0
+
+    def upload(slot, b):
+        _hip_copy(dev_in[slot].data_ptr(), pin_in[b % len(pin_in)].data_ptr(), total, 1, copy.cuda_stream)
+        h2d_done[slot].record(copy)
+
+    upload(0, 0)
+    upload(1, 1)
+    t0 = None
+    for i in range(warmup + steps):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            up = down = 0
+        s = i % 2
+        main.wait_event(h2d_done[s])
+        mp.step(bases=dev_in[s])
+        mp.pack_sites(counts[s], offsets[s], packed[s])
+        o = mp.output_pointers()
+        nj, ng = int(o.n_jobs), int(o.n_gapped_jobs)
+        if nj > job_cap or ng > gjob_cap:
+            raise SystemExit("streaming_region: log staging buffers too small")
+        # the logs live in the mapper's buffers, which the next step overwrites: staged device to device, then sent from the stage
+        pieces = [(o.jobs, nj * 40), (o.results, nj * 80), (o.jobinfo, nj * 16), (o.match, nj * o.match_stride),
+                  (o.gjobs, ng * 40), (o.gresults, ng * 80), (o.gjobinfo, ng * 16), (o.ggaps, ng * 68), (o.gmatch, ng * o.gmatch_stride)]
+        off = 0
+        for ptr, nb in pieces:
+            _hip_copy(stage[s].data_ptr() + off, ptr, nb, 3, main.cuda_stream)
+            off += nb
+        total_sites = int(offsets[s][n].item())                    # (waits for the pack; the step itself is over)
+        if total_sites > cap_rec:
+            raise SystemExit("streaming_region: packed site buffer too small")
+        out_ready[s].record(main)
+        copy.wait_event(out_ready[s])
+        h = host_out[s].data_ptr()
+        _hip_copy(h, counts[s].data_ptr(), 4 * n, 2, copy.cuda_stream)
+        _hip_copy(h + 4 * (n + 1), packed[s].data_ptr(), total_sites * 128, 2, copy.cuda_stream)
+        _hip_copy(h + 4 * (n + 1) + cap_rec * 128, stage[s].data_ptr(), off, 2, copy.cuda_stream)
+        down += 4 * n + total_sites * 128 + off
+        upload(s, i + 2)                                           # the batch after next goes into the buffer this step has freed
+        up += total
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    return elapsed, up // max(1, steps), down // max(1, steps)
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) before anything here touches the GPU."""
     s = socket.socket()
@@ -204,6 +291,7 @@ def main():
     ap.add_argument("--max-sites", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=600)
+    ap.add_argument("--stream-steps", type=int, default=3, help="steps of the PCIe-inclusive streaming region (0 = skip it)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -283,6 +371,18 @@ def main():
     # ---- outside the timed region: checks and bookkeeping
     st = mp.stats()
     ms = {key: v / max(1, args.steps) for key, v in acc.items()}
+    stream_res = None
+    if args.stream_steps > 0:
+        # the PCIe-inclusive rate: distinct batches, uploads and downloads inside the timed region (reported beside `value`)
+        reads_b = make_batch(chroms, n, paired, D.shard_seed(5, rank))
+        if dist is not None:
+            dist.barrier()
+        s_el, s_up, s_down = streaming_region(mp, [reads, reads_b], args.stream_steps, 1)
+        if dist is not None:
+            s_el = D.max_over_ranks(s_el, dist, mp.dev)
+        stream_res = (s_el, s_up, s_down)
+        mp.step()                                                # the parity sample below looks at batch `reads` again
+        log("streaming region done")
     out = mp.fetch(with_match=args.parity_sample > 0 and rank == 0)
     nsites = out["nsites"]
     top = out["sites"][:, 0]
@@ -344,10 +444,18 @@ def main():
                        "rescue_scans_per_step": st["rescue_scans"], "rescue_fills_per_step": st["rescue_fills"],
                        "reads_remapped_by_overflow_tier": st["reads_reprobed"], "reads_left_unmapped_by_overflow": st["reads_overflowed"], "reads_without_site": st["reads_without_site"],
                        "mapped_fraction": mapped / n, "dp_cells_per_step": cells,
-                       "dp_gcups": (cells / ((ms["ms_dp_wave"] + ms["ms_dp_narrow"] + ms["ms_dp_gapped"]) * 1e-3) / 1e9) if cells else 0.0,
+                       # (the two DP contexts run side by side, so their kernel times overlap: the rate is over the two stages' wall time)
+                       "dp_gcups_over_scoreslow_and_rescue_stages": (cells / ((ms["ms_slow"] + ms["ms_rescue"]) * 1e-3) / 1e9) if cells else 0.0,
                        "probe_list_entries_per_step": int(ps[0] + ps[1]), "probe_extend_calls_per_step": int(ps[2]),
                        "stage_ms": {key[3:]: round(v, 3) for key, v in ms.items()},
                        "index_build_s_gpu": t_ix, "parity": parity},
+            "pcie_inclusive": None if stream_res is None else {
+                "value": n * world * args.stream_steps / stream_res[0], "unit": "reads/s", "steps": args.stream_steps,
+                "ms_per_step": 1e3 * stream_res[0] / args.stream_steps, "host_to_device_bytes_per_step": int(stream_res[1]),
+                "device_to_host_bytes_per_step": int(stream_res[2]),
+                "what": "two distinct batches alternating; batch i+1 uploaded from pinned host memory and batch i's results (packed site "
+                        "lists, per-read counts, both fill logs with traceback strings) downloaded to pinned host memory on a second "
+                        "stream while a batch is mapped; per GPU bytes"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": dom, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(dom_bytes), "kernels": kern},

@@ -495,6 +495,12 @@ typedef struct bbmap_overflow_output {
 } bbmap_overflow_output;
 int bbmap_get_overflow_output(bbmap_ctx *ctx, bbmap_overflow_output *out);
 int bbmap_last_stats(bbmap_ctx *ctx, bbmap_stats *out);
+/* The last batch's site lists without their empty slots, for a host that copies them back: counts (n_reads + 1 ints), offsets
+ * (n_reads + 1 int64: exclusive prefix sums, offsets[n_reads] = total) and packed (packed_cap records) are device buffers of the
+ * caller's; read r's counts[r] sites are packed[offsets[r] ...] (0 for a read without a list, a flagged one, or one the overflow
+ * tier mapped).  Enqueues on `stream`; records beyond packed_cap are not written (compare offsets[n_reads] with packed_cap). */
+int bbmap_pack_sites_device(bbmap_ctx *ctx, void *stream, int64_t n_reads, int32_t *counts, int64_t *offsets, bbmap_msite *packed,
+                            int64_t packed_cap);
 /* synchronous device-to-host copy of (part of) an output array */
 int bbmap_copy_to_host(void *dst, const void *src_device, int64_t bytes);
 

@@ -158,3 +158,37 @@ def test_fills_ahead_of_time_do_not_change_anything():
     for key in fa:
         for f in ("kind", "refStartLoc", "refEndLoc", "minScore", "score", "iterations", "match"):
             assert fa[key][f] == fb[key][f], (key, f)
+
+
+def test_packed_site_lists_equal_the_padded_ones():
+    """bbmap_pack_sites_device: the site lists without their empty slots, as a host would copy them back."""
+    import torch
+    ref, reads, L, k = _repeat_workload(True)                 # lists of every length, reads without a list, reads in the tier
+    di = DeviceIndex.build([ref], k=k)
+    offs = O.make_offsets(L, k, 1.9)
+    n = reads.size // L
+    mp = Mapper(di, n, L, offs, [100 * k] * len(offs), paired=True, max_sites=16)
+    mp.load_reads(reads)
+    mp.step()
+    out = mp.fetch(with_match=False)
+    dev = mp.dev
+    counts = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    packed = torch.zeros(n * 16 * 128, dtype=torch.uint8, device=dev)
+    mp.pack_sites(counts, offsets, packed)
+    torch.cuda.synchronize()
+    c, o = counts.cpu().numpy(), offsets.cpu().numpy()
+    ns = np.maximum(out["nsites"], 0)
+    assert (c[:n] == ns).all() and c[n] == 0
+    assert (o == np.concatenate([[0], np.cumsum(ns)])).all() and o[n] > n // 2 and ns.max() > 4 and (out["nsites"] < 0).any()
+    from bbmap_amd.mapper import MSITE_DTYPE
+    recs = packed.cpu().numpy()[: int(o[n]) * 128].view(MSITE_DTYPE)
+    want = np.concatenate([out["sites"][r, : ns[r]] for r in range(n)])
+    assert recs.tobytes() == want.tobytes()
+    # a destination that is too small is never written past its end (the caller compares offsets[n] with its capacity)
+    small = torch.zeros(100 * 128 + 256, dtype=torch.uint8, device=dev)
+    mp.pack_sites(counts, offsets, small[: 100 * 128])
+    torch.cuda.synchronize()
+    assert int(small[100 * 128:].sum()) == 0 and small.cpu().numpy()[: 100 * 128].tobytes() == want[:100].tobytes()
+    mp.close()
+    di.close()
