@@ -16,7 +16,8 @@ res = {}
 for short, pat in (("probe_wave_kernel", "probe_wave_kernel"), ("msa_fill_fast_kernel", "msa_fill_fast_kernel<5")):
     for name, v in vals.items():
         if pat in name and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            steps = 3 if short == "msa_fill_fast_kernel" else v["FETCH_SIZE"][1]     # the DP kernel runs several times per step: per step
+            steps = 3          # the profiled command runs 1 warm-up + 2 timed steps; per step = per main launch of the probe (the
+                               # overflow tier's own small probe launch, a few hundred reads, is counted in) and all DP launches of a step
             fetch = v["FETCH_SIZE"][0] * 1024 / steps
             write = v["WRITE_SIZE"][0] * 1024 / steps
             res[short] = {"reads_per_step": reads, "fetch_bytes_raw": int(fetch), "write_bytes": int(write),
