@@ -323,13 +323,20 @@ def main():
     offsets = W.make_offsets(L, k, 1.9)
     key_scores = [100 * k] * len(offsets)          # GENERATE_KEY_SCORES_FROM_QUALITY needs qualities; synthetic reads have none
 
-    torch.cuda.set_device(local_rank)
+    # BBMAP_BENCH_REHEARSE=1: every rank on GPU 0 and gloo instead of RCCL -- a way to run the N > 1 code path on a one-GPU box
+    rehearse = os.environ.get("BBMAP_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    red_dev = None if rehearse else torch.device("cuda", dev_index)
     t_ix = time.perf_counter()
-    di = DeviceIndex.build(chroms, k=k, device=local_rank)          # IndexMaker4 + analyzeIndex on the device (bbidx_build)
+    di = DeviceIndex.build(chroms, k=k, device=dev_index)          # IndexMaker4 + analyzeIndex on the device (bbidx_build)
     torch.cuda.synchronize()
     t_ix = time.perf_counter() - t_ix
     log("index built")
@@ -343,7 +350,7 @@ def main():
         cpu = cpu_baseline(oi, reads, L, paired, offsets, key_scores)
         log("cpu baseline done")
 
-    mp = Mapper(di, n, L, offsets, key_scores, paired=paired, device=local_rank, max_sites=args.max_sites)
+    mp = Mapper(di, n, L, offsets, key_scores, paired=paired, device=dev_index, max_sites=args.max_sites)
     mp.load_reads(reads)
     for _ in range(args.warmup):
         mp.step()
@@ -365,7 +372,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        elapsed = D.max_over_ranks(elapsed, dist, mp.dev)
+        elapsed = D.max_over_ranks(elapsed, dist, red_dev)
     log("timed region done")
 
     # ---- outside the timed region: checks and bookkeeping
@@ -377,10 +384,14 @@ def main():
         reads_b = make_batch(chroms, n, paired, D.shard_seed(5, rank))
         if dist is not None:
             dist.barrier()
-        s_el, s_up, s_down = streaming_region(mp, [reads, reads_b], args.stream_steps, 1)
+        try:
+            s_el, s_up, s_down = streaming_region(mp, [reads, reads_b], args.stream_steps, 1)
+        except (RuntimeError, MemoryError) as e:                 # e.g. the host refuses that much pinned memory: the line goes out without it
+            log("streaming region failed: %s" % e)
+            s_el, s_up, s_down = float("inf"), 0, 0
         if dist is not None:
-            s_el = D.max_over_ranks(s_el, dist, mp.dev)
-        stream_res = (s_el, s_up, s_down)
+            s_el = D.max_over_ranks(s_el, dist, red_dev)
+        stream_res = (s_el, s_up, s_down) if s_el != float("inf") else None
         mp.step()                                                # the parity sample below looks at batch `reads` again
         log("streaming region done")
     out = mp.fetch(with_match=args.parity_sample > 0 and rank == 0)
