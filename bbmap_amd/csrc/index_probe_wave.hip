@@ -88,8 +88,6 @@ struct WaveLds {
     uint8_t base[2][WLEN + 8];    // [0] the read as given, [1] its reverse complement
     int8_t bsc[WLEN + 8];         // base scores of the plus strand
     int8_t code[WLEN + 8];        // AminoAcid.baseToNumber of the plus strand (-1 = undefined)
-    int hits[8][64];              // block 0's list heads per key lane, plus then minus strand {cnt, start, len, first}:
-                                  // long-lived, rarely read -> parked here instead of 8 VGPRs (which the compiler spilled)
 };
 
 // wave-uniform state of one read
@@ -376,15 +374,20 @@ __device__ __forceinline__ int batchPop(const U &u, WL &L, int lo, int hi, int c
 #define BBIDX_CYCLE 1               // 0: always the sequential heap walk (for A/B measurements)
 #endif
 constexpr int CYC_EMAX = 384, CYC_CMAX = 64;
+constexpr int CYC_MAPW = 192;        // words per presence map (6,144 slots)
 struct CycleLds {
     int ent[CYC_EMAX];               // adjusted sites, list after list
     unsigned short isoq[CYC_EMAX];   // 0 for a candidate, else the entry's prescan quick score keyScore + scoreZ1Key
-    unsigned once[2][64], twice[2][64];   // presence maps over hashed 32 kbp buckets: seen, seen more than once
+    // Presence maps over hashed 64 kbp buckets of two grids, the second shifted by half a bucket: two entries no farther apart than
+    // 32,768 share a bucket in at least one of them.  once = a slot that was hit, twice = hit more than once.
+    unsigned once[2][CYC_MAPW], twice[2][CYC_MAPW];
 };
 struct CycleLanes { int lo, len, last, p, rank; };   // per lane = per list: its slice of ent[], last value, cursor, rank of `last`
 
-__device__ __forceinline__ unsigned cyc_h1(unsigned b) { return (b * 0x9E3779B1u) >> 21; }
-__device__ __forceinline__ unsigned cyc_h2(unsigned b) { return ((b ^ (b >> 7)) * 0x85EBCA6Bu) >> 21; }
+__device__ __forceinline__ unsigned cyc_slot(unsigned v, int grid) {
+    const unsigned b = (v + (grid ? 32768u : 0u)) >> 16;
+    return __umulhi(b * (grid ? 0x85EBCA6Bu : 0x9E3779B1u), (unsigned)(32 * CYC_MAPW));
+}
 __device__ __forceinline__ bool cyc_bit(const unsigned *m, unsigned sl) { return (m[sl >> 5] >> (sl & 31)) & 1; }
 
 // Gathers the cycle's entries.  Returns the number of candidates (their sites in cs[]), or -1 when the cycle does not fit.
@@ -392,6 +395,8 @@ __device__ __forceinline__ bool cyc_bit(const unsigned *m, unsigned sl) { return
 template <int WLEN> __device__ __forceinline__ int cycleLoad(U &u, CycleLds &C, WaveLds<WLEN> &S, const WL &L, int baseChrom, CycleLanes &cl, int &E) {
     const int lane = u.lane, n = L.n;
     int *xrow = S.xch[0], *xoff = S.xch[1], *xlo = S.xch[2], *xksc = S.loc, *cs = S.xch[0];
+    unsigned *startBits = (unsigned *)(S.loc + 64);           // one bit per entry index: a list starts here (12 words)
+    int *startPre = S.loc + 80;                                //   and the number of starts in the words before each of them
     const int len = lane < n ? L.stop - L.row : 0;
     int inc = len;
 #pragma unroll
@@ -400,30 +405,47 @@ template <int WLEN> __device__ __forceinline__ int cycleLoad(U &u, CycleLds &C, 
     if (E > CYC_EMAX || n < 2) return -1;
     cl.lo = inc - len; cl.len = len; cl.p = 0;
     wsync();
-    xlo[lane] = cl.lo; xksc[lane] = L.ksc; xrow[lane] = L.row; xoff[lane] = L.offs;
-    C.once[0][lane] = 0; C.once[1][lane] = 0; C.twice[0][lane] = 0; C.twice[1][lane] = 0;
+    xlo[lane] = cl.lo; xksc[lane] = L.ksc; xrow[lane] = L.row; xoff[lane] = L.offs;      // (lanes past the last list: lo = E)
+    for (int i = lane; i < CYC_MAPW; i += 64) { C.once[0][i] = 0; C.once[1][i] = 0; C.twice[0][i] = 0; C.twice[1][i] = 0; }
+    if (lane < 12) startBits[lane] = 0;
     wsync();
+    if (lane < n) atomicOr(&startBits[cl.lo >> 5], 1u << (cl.lo & 31));
+    wsync();
+    {
+        const int c = lane < 12 ? __builtin_popcount(startBits[lane]) : 0;
+        int ps = c;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { const int t = __shfl_up(ps, d); if (lane >= d) ps += t; }
+        if (lane < 12) startPre[lane] = ps - c;
+    }
+    wsync();
+    // Every lane takes four CONSECUTIVE entries: the list of the first one from the start bits (a rank), the others follow by
+    // stepping over at most one list border each.
     for (int base = 0; base < E; base += 256) {
+        const int e0 = base + 4 * lane;
+        int a = 0;
+        if (e0 < E) { const int w = e0 >> 5; a = startPre[w] + __builtin_popcount(startBits[w] & (0xFFFFFFFFu >> (31 - (e0 & 31)))) - 1; }
         int raw[4], qs[4], oj[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int e = base + q * 64 + lane;
+            const int e = e0 + q;
             const bool in = e < E;
-            int a = 0, b = n;                                  // largest j with lo[j] <= e
-            while (b - a > 1) { const int m = (a + b) >> 1; if (xlo[m] <= (in ? e : 0)) a = m; else b = m; }
+            if (q > 0 && in && a + 1 < n && e >= xlo[a + 1]) a++;
             oj[q] = xoff[a]; qs[q] = xksc[a] + u.scoreZ1Key;
             raw[q] = in ? L.sites[xrow[a] + (e - xlo[a])] : 0;
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int e = base + q * 64 + lane;
+            const int e = e0 + q;
             if (e < E) {
                 const int v = adjustSite(u, raw[q], oj[q], baseChrom);
                 C.ent[e] = v; C.isoq[e] = (unsigned short)min(qs[q], 65535);
-                const unsigned b = (unsigned)v >> 15;
-                const unsigned s1 = cyc_h1(b), s2 = cyc_h2(b), b1 = 1u << (s1 & 31), b2 = 1u << (s2 & 31);
-                if (atomicOr(&C.once[0][s1 >> 5], b1) & b1) atomicOr(&C.twice[0][s1 >> 5], b1);
-                if (atomicOr(&C.once[1][s2 >> 5], b2) & b2) atomicOr(&C.twice[1][s2 >> 5], b2);
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const unsigned sl = cyc_slot((unsigned)v, g), bit = 1u << (sl & 31);
+                    const unsigned old = atomicOr(&C.once[g][sl >> 5], bit);
+                    atomicOr(&C.twice[g][sl >> 5], old & bit);
+                }
             }
         }
     }
@@ -432,7 +454,8 @@ template <int WLEN> __device__ __forceinline__ int cycleLoad(U &u, CycleLds &C, 
     cl.last = len > 0 ? C.ent[cl.lo + len - 1] : INT_MAX;
     cl.rank = -2;                                              // ranked on first use (cycleExitSite)
     wsync();                                                   // the load phase's scratch is dead: cs[] may be written
-    // pass 1: entries with company at bucket granularity (a superset); pass 2: the exact window among those
+    // pass 1: entries that share a bucket with another one in either grid (a superset of the entries with company: a shared
+    // bucket can be wider than the window, a slot can be shared by two buckets); pass 2: the exact window among those
     const int lo = min(u.ix->p.maxIndel, u.ix->p.maxIndel2), hi = u.ix->p.maxIndel2;
     int nflag = 0;
     for (int base = 0; base < E; base += 64) {
@@ -440,10 +463,7 @@ template <int WLEN> __device__ __forceinline__ int cycleLoad(U &u, CycleLds &C, 
         bool flag = false; int v = 0;
         if (e < E) {
             v = C.ent[e];
-            const unsigned b = (unsigned)v >> 15;
-            flag = (cyc_bit(C.twice[0], cyc_h1(b)) && cyc_bit(C.twice[1], cyc_h2(b)))
-                || (cyc_bit(C.once[0], cyc_h1(b - 1u)) && cyc_bit(C.once[1], cyc_h2(b - 1u)))
-                || (cyc_bit(C.once[0], cyc_h1(b + 1u)) && cyc_bit(C.once[1], cyc_h2(b + 1u)));
+            flag = cyc_bit(C.twice[0], cyc_slot((unsigned)v, 0)) || cyc_bit(C.twice[1], cyc_slot((unsigned)v, 1));
         }
         const u64 M = __ballot(flag);
         if (nflag + popc(M) > CYC_CMAX) return -1;
@@ -1425,19 +1445,9 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
             const int so = __shfl(off, src), sk = __shfl(key, src), ss = __shfl(ksc, src);
             if (lane < n) { offM = blen - (so + p.k); keyM = rc_key(sk, p.k); kscM = ss; }
         }
-        // block 0's list heads for both strands come from the records already in registers; further blocks reload
-        {
-            const KeyHit hm = minusView(lane, n, e.cntRC, e.startR, e.lenR, e.firstR);
-            S.hits[0][lane] = cnt; S.hits[1][lane] = e.startF; S.hits[2][lane] = e.lenF; S.hits[3][lane] = e.firstF;
-            S.hits[4][lane] = hm.cnt; S.hits[5][lane] = hm.start; S.hits[6][lane] = hm.len; S.hits[7][lane] = hm.first;
-            wsync();
-        }
+        // every (block, strand) cycle reloads the fused records of its keys: 32 bytes per key lane, two vector loads.  (Parking block
+        // 0's records in LDS saved the reload but cost 2 KB per wave, which the cycle's presence maps make better use of.)
         auto keyHits = [&](int block, int strand) -> KeyHit {
-            if (block == 0) {
-                KeyHit h; const int o = strand ? 4 : 0;
-                h.cnt = S.hits[o][lane]; h.start = S.hits[o + 1][lane]; h.len = S.hits[o + 2][lane]; h.first = S.hits[o + 3][lane];
-                return h;
-            }
             KeyEntry eb; eb.cnt = eb.cntRC = eb.startF = eb.lenF = eb.firstF = eb.startR = eb.lenR = eb.firstR = 0;
             if (lane < n && key >= 0) eb = ix.fused[block][key];
             if (strand) return minusView(lane, n, eb.cntRC, eb.startR, eb.lenR, eb.firstR);
