@@ -392,9 +392,10 @@ __device__ __forceinline__ bool cyc_bit(const unsigned *m, unsigned sl) { return
 
 // Gathers the cycle's entries.  Returns the number of candidates (their sites in cs[]), or -1 when the cycle does not fit.
 // xrow/xoff/xlo (S.xch) and xksc (S.loc) are scratch of the load phase; cs aliases xrow..xlo afterwards.
-template <int WLEN> __device__ __forceinline__ int cycleLoad(U &u, CycleLds &C, WaveLds<WLEN> &S, const WL &L, int baseChrom, CycleLanes &cl, int &E) {
+// cycleGather: the entries into C.ent / C.isoq (and, with MAPS, into the presence maps); false when the cycle does not fit.
+template <bool MAPS, int WLEN> __device__ __forceinline__ bool cycleGather(U &u, CycleLds &C, WaveLds<WLEN> &S, const WL &L, int baseChrom, CycleLanes &cl, int &E) {
     const int lane = u.lane, n = L.n;
-    int *xrow = S.xch[0], *xoff = S.xch[1], *xlo = S.xch[2], *xksc = S.loc, *cs = S.xch[0];
+    int *xrow = S.xch[0], *xoff = S.xch[1], *xlo = S.xch[2], *xksc = S.loc;
     unsigned *startBits = (unsigned *)(S.loc + 64);           // one bit per entry index: a list starts here (12 words)
     int *startPre = S.loc + 80;                                //   and the number of starts in the words before each of them
     const int len = lane < n ? L.stop - L.row : 0;
@@ -402,11 +403,11 @@ template <int WLEN> __device__ __forceinline__ int cycleLoad(U &u, CycleLds &C, 
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
     E = rl(inc, 63);
-    if (E > CYC_EMAX || n < 2) return -1;
+    if (E > CYC_EMAX || n < 2) return false;
     cl.lo = inc - len; cl.len = len; cl.p = 0;
     wsync();
     xlo[lane] = cl.lo; xksc[lane] = L.ksc; xrow[lane] = L.row; xoff[lane] = L.offs;      // (lanes past the last list: lo = E)
-    for (int i = lane; i < CYC_MAPW; i += 64) { C.once[0][i] = 0; C.once[1][i] = 0; C.twice[0][i] = 0; C.twice[1][i] = 0; }
+    if (MAPS) for (int i = lane; i < CYC_MAPW; i += 64) { C.once[0][i] = 0; C.once[1][i] = 0; C.twice[0][i] = 0; C.twice[1][i] = 0; }
     if (lane < 12) startBits[lane] = 0;
     wsync();
     if (lane < n) atomicOr(&startBits[cl.lo >> 5], 1u << (cl.lo & 31));
@@ -441,7 +442,7 @@ template <int WLEN> __device__ __forceinline__ int cycleLoad(U &u, CycleLds &C, 
                 const int v = adjustSite(u, raw[q], oj[q], baseChrom);
                 C.ent[e] = v; C.isoq[e] = (unsigned short)min(qs[q], 65535);
 #pragma unroll
-                for (int g = 0; g < 2; g++) {
+                for (int g = 0; MAPS && g < 2; g++) {
                     const unsigned sl = cyc_slot((unsigned)v, g), bit = 1u << (sl & 31);
                     const unsigned old = atomicOr(&C.once[g][sl >> 5], bit);
                     atomicOr(&C.twice[g][sl >> 5], old & bit);
@@ -454,6 +455,12 @@ template <int WLEN> __device__ __forceinline__ int cycleLoad(U &u, CycleLds &C, 
     cl.last = len > 0 ? C.ent[cl.lo + len - 1] : INT_MAX;
     cl.rank = -2;                                              // ranked on first use (cycleExitSite)
     wsync();                                                   // the load phase's scratch is dead: cs[] may be written
+    return true;
+}
+template <int WLEN> __device__ __forceinline__ int cycleLoad(U &u, CycleLds &C, WaveLds<WLEN> &S, const WL &L, int baseChrom, CycleLanes &cl, int &E) {
+    if (!cycleGather<true>(u, C, S, L, baseChrom, cl, E)) return -1;
+    const int lane = u.lane;
+    int *xoff = S.xch[1], *xlo = S.xch[2], *cs = S.xch[0];
     // pass 1: entries that share a bucket with another one in either grid (a superset of the entries with company: a shared
     // bucket can be wider than the window, a slot can be shared by two buckets); pass 2: the exact window among those
     const int lo = min(u.ix->p.maxIndel, u.ix->p.maxIndel2), hi = u.ix->p.maxIndel2;
@@ -771,6 +778,9 @@ template <int WLEN> __device__ __forceinline__ int extendScoreW(U &u, WaveLds<WL
 // single key is a site -- hundreds per read -- and nearly all of them fail here.  Returns INT_MAX when it does not apply.
 #ifndef BBIDX_EXTEND_BOUND
 #define BBIDX_EXTEND_BOUND 1
+#endif
+#ifndef BBIDX_ALL_LISTS
+#define BBIDX_ALL_LISTS 1           // 0: no shortcut for walks in which every list has to hit
 #endif
 #ifndef BBIDX_CYCLE_LOW
 #define BBIDX_CYCLE_LOW 1           // 0: walks that start at a hit cutoff of 1 take the sequential heap walk
@@ -1094,12 +1104,41 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
         return approxHits;
     };
     bool cycled = false;
+    // A walk in which EVERY list has to hit (after a perfect site the hit cutoff is the number of lists; in a read with a perfect
+    // site in an early cycle that is every later cycle, none of which the prescan has seen): a site needs an entry of the
+    // shortest list with an entry of every other list no farther from it than MAX_INDEL + MAX_INDEL2.  If no entry of the
+    // shortest list has that, the cycle holds no site and the walk has nothing to do -- found from the gathered entries alone,
+    // without presence maps, candidates or a single visit.
+    if (LONG && BBIDX_CYCLE && BBIDX_ALL_LISTS && C != nullptr && approxHitsCutoff >= numHits && numHits >= 2 && max(p.maxIndel, p.maxIndel2) <= 32768) {
+        CycleLanes cl; int E;
+        PH_WALK(u, 0);
+        if (cycleGather<false>(u, *C, S, L, baseChrom, cl, E)) {
+            const int mylen = lane < numHits ? cl.len : INT_MAX;
+            const int minLen = wmin(mylen);
+            if (minLen <= 8) {
+                const int lo0 = rl(cl.lo, __builtin_ctzll(__ballot(mylen == minLen)));
+                const int W = p.maxIndel + p.maxIndel2;
+                bool possible = false;
+                for (int t = 0; t < minLen && !possible; t++) {
+                    const int w = C->ent[lo0 + t];
+                    int a = 0, b = lane < numHits ? cl.len : 0;                  // first entry of this lane's list >= w - W
+                    while (__ballot(b > a)) {
+                        if (b > a) { const int m = (a + b) >> 1; if (C->ent[cl.lo + m] < w - W) a = m + 1; else b = m; }
+                    }
+                    const bool ok = lane >= numHits || (a < cl.len && C->ent[cl.lo + a] <= w + W);
+                    possible = __ballot(ok) == ~0ull;
+                }
+                if (!possible) { cycled = true; u.cWalk += (unsigned)E; }
+            }
+        }
+        PH_WALK(u, 0);
+    }
     // A walk that starts at a hit cutoff of 1 (reads with few hit keys) looks at EVERY entry: an isolated one is a site with one
     // hit, whose quick score is the fixed keyScore + scoreZ1Key (isoq) and whose extendScore follows from its diagonal alone.
     const bool lowCutoff = approxHitsCutoff <= 1;
     const bool lowOk = BBIDX_CYCLE_LOW && filter_by_qscore && p.kfilter <= 1 && wmin(lane < numHits ? L.ksc : INT_MAX) > 0 &&
                        wmax(lane < numHits ? L.ksc : 0) + u.scoreZ1Key < 65535;
-    if (LONG && BBIDX_CYCLE && C != nullptr && (!lowCutoff || lowOk) && max(p.maxIndel, p.maxIndel2) <= 32768) {
+    if (!cycled && LONG && BBIDX_CYCLE && C != nullptr && (!lowCutoff || lowOk) && max(p.maxIndel, p.maxIndel2) <= 32768) {
         // whole-cycle form (see findMaxQscore2Cycle): at a hit cutoff >= 2 an isolated entry can neither be scored nor change
         // any state, so only the candidates are visited, in site order, each followed by popSite's exit rule
         CycleLanes cl; int E;
