@@ -1390,11 +1390,25 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
 
     // persistent waves: a read costs anything from a few microseconds to milliseconds (repeats), and a wave that is done
     // would otherwise idle until the slowest of its block's four reads finishes
+    // (The plain variant takes eight reads per pull: same-address atomics come back one every few nanoseconds, which is the whole
+    // kernel on a small genome.  With long lists a read costs 0.1 - 10 ms of wave time: one per pull.)
+    unsigned rNext = 0, rEnd = 0;
     for (;;) {
     long long r = 0;
-    if (lane == 0) r = (long long)atomicAdd(&P.queue[2], 1u);
-    r = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)r);
-    if (r >= P.nreads) break;
+    if (LONG) {
+        if (lane == 0) r = (long long)atomicAdd(&P.queue[2], 1u);
+        r = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)r);
+        if (r >= P.nreads) break;
+    } else {
+        if (rNext >= rEnd) {
+            unsigned r0 = 0;
+            if (lane == 0) r0 = atomicAdd(&P.queue[2], 8u);
+            rNext = (unsigned)__builtin_amdgcn_readfirstlane((int)r0);
+            if ((long long)rNext >= P.nreads) break;
+            rEnd = (long long)rNext + 8 < P.nreads ? rNext + 8u : (unsigned)P.nreads;
+        }
+        r = (long long)rNext++;
+    }
     int result = 0;                      // what goes to nsites[r]
     bool done = false;
     bbidx_read rr; rr.len = 0; rr.nkeys = 0; rr.bases_off = 0; rr.keys_off = 0;
