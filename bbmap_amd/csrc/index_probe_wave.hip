@@ -41,6 +41,11 @@ using namespace wavep;
 #else
 #define BST(u, i, v) do { } while (0)
 #endif
+#ifdef BBIDX_NO_WORK_COUNTERS       // experiment: what the four work counters (list entries, extensions, reference bytes) cost
+#define WORK(c, v) do { } while (0)
+#else
+#define WORK(c, v) ((c) += (v))
+#endif
 #ifdef BBIDX_CYC_STATS              // debug build: {cycles offered to the whole-cycle walk, declined, entries, candidates, candidates visited}
 #define CST(u, i, v) ((u).ph[i] += (unsigned)(v))
 #else
@@ -226,13 +231,13 @@ __device__ __forceinline__ void popSite(const U &u, WL &L, int site, int cutoff,
                 u64 m = D;
                 for (int j = 1; j < jexit; j++) m &= m - 1;
                 const int d = __builtin_ctzll(m);
-                counter += (unsigned)popc(Pm & (lt_mask(d) | (1ull << d)));
+                WORK(counter, (unsigned)popc(Pm & (lt_mask(d) | (1ull << d))));
                 L.nlive = 0;
                 return;
             }
             L.nlive -= nd;
         }
-        counter += (unsigned)popc(Pm);
+        WORK(counter, (unsigned)popc(Pm));
         const bool dies = hit && row >= L.stop;
         if (__ballot(hit && !dies && L.nbuf == 0)) refillLists(L);
         // per-lane cursor update as selects: no EXEC juggling in the innermost loop
@@ -295,7 +300,7 @@ __device__ __forceinline__ void bulkSkip(const U &u, WL &L, int site, int lo, in
     const bool moved = live && L.hv < T && L.row < last;
     const int np = moved ? b : L.row;
     const int total = wsum(np - L.row);
-    counter += (unsigned)total;
+    WORK(counter, (unsigned)total);
     if (moved) {
         L.row = np;
         L.value = adjustSite(u, L.sites[np], L.offs, baseChrom);
@@ -342,7 +347,7 @@ __device__ __forceinline__ int batchPop(const U &u, WL &L, int lo, int hi, int c
         if (q >= mqs) return 0;                                           // the reference's loop would end there
         if (q > topQscore) { maxHits = max(maxHits, 1); topQscore = q; }
     }
-    counter += (unsigned)np;
+    WORK(counter, (unsigned)np);
     L.row += pop ? 1 : 0;
     L.value = pop ? nx : L.value; L.hv = pop ? nx : L.hv;
 #pragma unroll
@@ -542,7 +547,7 @@ template <int WLEN> __device__ __forceinline__ bool findMaxQscore2Cycle(U &u, Cy
     if (ncand < 0) { CST(u, 1, 1); return false; }
     CST(u, 2, E); CST(u, 3, ncand);
     const int *cs = S.xch[0];
-    u.cPrescan += (unsigned)E;
+    WORK(u.cPrescan, (unsigned)E);
     const int mqs = numHits == numKeys ? mqsAllKeys : maxQuickScoreW(u, L.offs, L.ksc, numHits);
     int topQscore = -999999999, maxHits = 0;
     int approxHitsCutoff = max(prevMaxHits, min(p.minApproxHitsToKeep, numHits - 1));
@@ -698,7 +703,7 @@ template <int WLEN> __device__ __forceinline__ int extendScoreW(U &u, WaveLds<WL
     const uint8_t *ref = u.ix->chromArr[chrom];
     const int reflen = u.ix->chromArrLen[chrom];
     const uint8_t *rb = S.base[strand];
-    u.cExtend++;
+    WORK(u.cExtend, 1u);
     for (int i = lane; i < blen; i += 64) S.loc[i] = -1;
     wsync();
     const u64 R = __ballot(lane < numHits && value >= minVal && value <= maxVal);
@@ -714,7 +719,7 @@ template <int WLEN> __device__ __forceinline__ int extendScoreW(U &u, WaveLds<WL
                 const int q = base + lane;
                 if (q <= c0 && rb[q] == ref[refbase + q]) S.loc[q] = refbase;
             }
-            u.cRefBytes += (unsigned)(c0 + 1);
+            WORK(u.cRefBytes, (unsigned)(c0 + 1));
         } else {
             for (int top = c0; top >= 0; top -= 64) {
                 const int q = top - lane;
@@ -726,7 +731,7 @@ template <int WLEN> __device__ __forceinline__ int extendScoreW(U &u, WaveLds<WL
                 const u64 stopM = Em | __ballot(mm);
                 const int s = stopM ? __builtin_ctzll(stopM) : 64;
                 if (valid && lane < s && (old < 0 || refbase == centerLoc)) S.loc[q] = refbase;
-                u.cRefBytes += (unsigned)(min(s, min(64, top + 1)) + ((s < 64 && !((Em >> s) & 1)) ? 1 : 0));
+                WORK(u.cRefBytes, (unsigned)(min(s, min(64, top + 1)) + ((s < 64 && !((Em >> s) & 1)) ? 1 : 0)));
                 if (s < 64) break;
             }
         }
@@ -758,7 +763,7 @@ template <int WLEN> __device__ __forceinline__ int extendScoreW(U &u, WaveLds<WL
                 const bool mmBeforeS = mmprev || (mmM & lt_mask(s)) != 0;
                 if (!Es && !(mmBeforeS && As)) cnt++;
             }
-            u.cRefBytes += cnt;
+            WORK(u.cRefBytes, cnt);
             if (s < 64) break;
             mmprev = mmprev || mmM != 0;
         }
@@ -815,7 +820,7 @@ template <int WLEN> __device__ __forceinline__ int extendBoundW(U &u, const Wave
         }
         total += c;
     }
-    u.cRefBytes += (unsigned)(blen * nd);
+    WORK(u.cRefBytes, (unsigned)(blen * nd));
     return wsum(total);
 }
 
@@ -977,7 +982,7 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
                         const int ub = uni(extendBoundW(u, S, strand, L.value, numHits, chrom, centerIndex));
                         hopeless = ub < cutoff && ub < maxScore;
                     }
-                    if (hopeless) { score = -1; u.cExtend++; }
+                    if (hopeless) { score = -1; WORK(u.cExtend, 1u); }
                     else {
                         score = extendScoreW(u, S, strand, L.value, L.offs, numHits, chrom, centerIndex);
                         locArrayValid = true;
@@ -1128,7 +1133,7 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
                     const bool ok = lane >= numHits || (a < cl.len && C->ent[cl.lo + a] <= w + W);
                     possible = __ballot(ok) == ~0ull;
                 }
-                if (!possible) { cycled = true; u.cWalk += (unsigned)E; }
+                if (!possible) { cycled = true; WORK(u.cWalk, (unsigned)E); }
             }
         }
         PH_WALK(u, 0);
@@ -1163,8 +1168,8 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
                 const uint8_t *ref = plain ? u.ix->chromArr[chrom] : nullptr;
                 const int sc = singleKeyScoreLane(u, S, strand, ref, refbase, plain);
                 const bool pass = need && (!plain || sc >= cutoff || sc == maxScore);
-                u.cExtend += (unsigned)popc(__ballot(plain && !pass));
-                u.cRefBytes += (unsigned)(blen * popc(__ballot(plain)));
+                WORK(u.cExtend, (unsigned)popc(__ballot(plain && !pass)));
+                WORK(u.cRefBytes, (unsigned)(blen * popc(__ballot(plain))));
                 const u64 PM = __ballot(pass);
                 if (pass) { const int slot = npass + popc(PM & lt_mask(lane)); if (slot < 64) passv[slot] = v; }
                 npass += popc(PM);
@@ -1174,7 +1179,7 @@ template <bool LONG, int WLEN> __device__ __forceinline__ void slowWalk3W(U &u, 
         }
         if (ncand >= 0 && npass <= 64) {
             cycled = true;
-            u.cWalk += (unsigned)E;
+            WORK(u.cWalk, (unsigned)E);
             // the candidate sites sit in S.xch, which nothing inside visit() touches (compaction and the greedy trim are over)
             const int *cs = S.xch[0];
             int prev = INT_MIN;
