@@ -1,5 +1,5 @@
-"""configs[2] and configs[3] at their real reference sizes (chr21-sized, 46.7 Mbp; hg38-shaped, 24 chromosomes, 3.09 Gbp, four index
-blocks; 10 % repeat families, k=13; 2 x 150 paired reads), checked through properties that do not need the oracle on the whole batch: a batch mapped twice gives the same bytes; a batch mapped
+"""configs[1], configs[2] and configs[3] at their real reference sizes (E. coli-sized, 4.6 Mbp, single-ended; chr21-sized, 46.7 Mbp;
+hg38-shaped, 24 chromosomes, 3.09 Gbp, four index blocks, 10 % repeat families; k=13; 150-bp reads, paired in the last two), checked through properties that do not need the oracle on the whole batch: a batch mapped twice gives the same bytes; a batch mapped
 in two halves gives the lists the whole batch gives (pairs are independent, which is what lets reads shard across GPUs); the
 planted pairs come back where they were drawn from; and a sample of the batch is identical to the CPU oracle, site by site and
 fill by fill (the oracle probes the device-built index arrays, exported block by block, as bench.py does)."""
@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 L, K, N = 150, 13, 120000            # reads (60,000 pairs)
 
 
-def _map(di, reads, offs):
+def _map(di, reads, offs, paired=True):
     n = reads.size // L
-    mp = Mapper(di, n, L, offs, [100 * K] * len(offs), paired=True, max_sites=32)
+    mp = Mapper(di, n, L, offs, [100 * K] * len(offs), paired=paired, max_sites=32)
     mp.load_reads(reads)
     mp.step()
     out, st = mp.fetch(), mp.stats()
@@ -30,18 +30,17 @@ def _map(di, reads, offs):
     return out, st, again
 
 
-@pytest.mark.parametrize("name", ["chr21", "hg38"])
-def test_full_size_reference_paired_workload(name):
+@pytest.mark.parametrize("name", ["ecoli", "chr21", "hg38"])
+def test_full_size_reference_workload(name):
     lens, paired, _ = B.WORKLOADS[name]
-    assert paired
-    chroms, _ = B.shared_reference(name, lens, 0.1, 0, 1)
-    if len(chroms) == 1:
+    chroms, _ = B.shared_reference(name, lens, 0.0 if name == "ecoli" else 0.1, 0, 1)
+    if paired and len(chroms) == 1:
         pairs, truth = W.make_pairs(chroms[0], N // 2, read_len=L, seed=3)
     else:
-        pairs, truth = B.make_batch(chroms, N, True, 3), None          # pairs from all 24 chromosomes, mixed
+        pairs, truth = B.make_batch(chroms, N, paired, 3), None        # single-ended reads / pairs from all 24 chromosomes, mixed
     di = DeviceIndex.build(chroms, k=K)
     offs = W.make_offsets(L, K, 1.9)
-    out, st, again = _map(di, pairs, offs)
+    out, st, again = _map(di, pairs, offs, paired)
     ns = out["nsites"]
     assert st["reads_overflowed"] == 0 and (ns != -1).all()
 
@@ -64,7 +63,7 @@ def test_full_size_reference_paired_workload(name):
         return o["sites"][r, : max(0, o["nsites"][r])]
     half = (N // 4) * 2
     for lo, hi in ((0, half), (half, N)):
-        part, _, _ = _map(di, pairs.reshape(-1, L)[lo:hi].reshape(-1), offs)
+        part, _, _ = _map(di, pairs.reshape(-1, L)[lo:hi].reshape(-1), offs, paired)
         step = max(1, (hi - lo) // 4000)
         for r in list(range(0, hi - lo, step)) + [int(x) for x in np.nonzero(part["nsites"] == -3)[0][:50]]:
             a, b = lists(part, r), lists(out, lo + r)
@@ -80,17 +79,22 @@ def test_full_size_reference_paired_workload(name):
     assert ((ns > 0) & (top["slowScore"] >= minScore)).mean() > 0.99
     if truth is None:
         truth = {"start1": top["start"][0::2], "start2": top["start"][1::2], "strand1": top["strand"][0::2], "strand2": top["strand"][1::2]}
+    if not paired:
+        truth = {"start1": top["start"][0::2], "start2": top["start"][1::2], "strand1": top["strand"][0::2], "strand2": top["strand"][1::2]}
     ok1 = (ns[0::2] > 0) & (np.abs(top["start"][0::2] - truth["start1"]) <= 40) & (top["strand"][0::2] == truth["strand1"])
     ok2 = (ns[1::2] > 0) & (np.abs(top["start"][1::2] - truth["start2"]) <= 40) & (top["strand"][1::2] == truth["strand2"])
     assert ok1.mean() > 0.97 and ok2.mean() > 0.97
 
     # 4. a sample against the oracle
     oi = B.oracle_index(di, chroms, K)
-    oi.s.p.quitAfterTwoPerfects = 0
     cnt = 400
     r = pairs.reshape(-1, L)
-    orc = map_batch(oi, r[0:cnt:2].copy(), r[1:cnt:2].copy(), L, offs, [100 * K] * len(offs), cap=1024, match_stride=4200)
+    if paired:
+        oi.s.p.quitAfterTwoPerfects = 0
+        orc = map_batch(oi, r[0:cnt:2].copy(), r[1:cnt:2].copy(), L, offs, [100 * K] * len(offs), cap=1024, match_stride=4200)
+    else:
+        orc = map_batch(oi, r[:cnt].copy(), None, L, offs, [100 * K] * len(offs), cap=1024, match_stride=4200)
     good = [i for i in range(cnt) if ns[i] >= 0 or ns[i] == -3]
-    bad = compare(out, orc, cnt, True, reads_range=good)
+    bad = compare(out, orc, cnt, paired, reads_range=good)
     assert not bad, "\n".join(bad[:10])
     di.close()
