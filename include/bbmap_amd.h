@@ -475,8 +475,11 @@ typedef struct bbmap_stats {
 
 typedef struct bbmap_ctx bbmap_ctx;
 int bbmap_default_config(bbmap_config *cfg);
-/* The context borrows `index` (which must outlive it) and owns two DP contexts (plain and gapped-reference) and every
- * intermediate buffer. */
+/* The context borrows `index` (which must outlive it) and owns two DP contexts (plain and gapped-reference), the overflow tier
+ * (a second, small set of the same) and every intermediate buffer.  One batch at a time per context, from one thread at a time; the
+ * call itself uses two internal streams and a helper thread (the overflow tier's pass runs beside the main one) and has joined
+ * them when it returns.  Two contexts over the same index must not map at the same time (the probe keeps its queue and counters
+ * in the index context). */
 int bbmap_create(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx **out);
 void bbmap_destroy(bbmap_ctx *ctx);
 /* Maps a batch that is resident on the device.  reads[i].bases_off addresses the plus strand inside `bases`; the call writes
