@@ -269,6 +269,98 @@ def streaming_region(mp, batches, steps, warmup):
     return elapsed, up // max(1, steps), down // max(1, steps)
 
 
+def pacbio_dp_main(args):
+    """--workload pacbio_dp: the DP half of BASELINE.json configs[4] (mapPacBio: 10 kb reads pre-split into <= 6,000-base pieces,
+    fastareadlen=6000, current/align2/BBMapPacBio.java:47-69).  A step = every piece of the batch aligned with the
+    MultiStateAligner9PacBio scheme against its window +- padding (fillAndScoreLimited + traceback) by the strip-tiled wavefront
+    kernel.  The PacBio INDEX probe (BBIndexPacBio's constants, 6,000-base reads) is not built, so this is not that configuration
+    end to end and its metric is its own (pieces per second), never the headline's."""
+    import threading
+    import torch
+    from bbmap_amd import msa as M
+    n = args.reads if args.reads != 2000000 else 2000
+    Lp = 6000
+    rng = np.random.Generator(np.random.PCG64(5))
+    BASES = np.frombuffer(b"ACGT", np.uint8)
+    genome = BASES[rng.integers(0, 4, size=4_000_000, dtype=np.uint8)]
+    reads, jobs, off = [], np.zeros(n, M.JOB_DTYPE), 0
+    for i in range(n):
+        s_ = int(rng.integers(1000, len(genome) - Lp - 2000))
+        err = rng.uniform(0.13, 0.17)                                          # pbmin / pbmax (RandomReads3.java:1714-1715)
+        x = rng.random(Lp)
+        keep = x >= err * 0.35
+        sub = (x >= err * 0.35) & (x < err * 0.55)
+        piece = genome[s_:s_ + Lp].copy()
+        piece[sub] = BASES[rng.integers(0, 4, size=int(sub.sum()), dtype=np.uint8)]
+        piece = piece[keep]
+        ins_at = np.nonzero(rng.random(len(piece)) < err * 0.45)[0]
+        piece = np.insert(piece, ins_at, BASES[rng.integers(0, 4, size=len(ins_at), dtype=np.uint8)])[:6019]
+        reads.append(piece)
+        jobs[i] = (off, 0, len(piece), len(genome), s_ - 40, s_ + Lp + 40, int(0.3 * (90 + 100 * (len(piece) - 1))),
+                   M.FILL_AND_SCORE_LIMITED | M.DO_TRACEBACK)
+        off += len(piece)
+    blob = np.concatenate(reads)
+    log("pieces ready")
+    # CPU baseline: the oracle's restatement of the same scheme, one MSA per thread (549 MB matrix each), on a bounded sample
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle.oracle import OracleMSA
+        cores = min(usable_cores(), 16)
+        sample = min(n, 3 * cores)
+        done = [0] * cores
+
+        def work(t):
+            om = OracleMSA(maxRows=6019, maxColumns=7600, scheme="9pacbio")
+            for i in range(t, sample, cores):
+                j = jobs[i]
+                rd = blob[j["read_off"]: j["read_off"] + j["read_len"]].tobytes()
+                r4 = om.fillLimited(rd, genome.tobytes(), int(j["refStartLoc"]), int(j["refEndLoc"]), int(j["minScore"]))
+                if r4 is not None:
+                    om.traceback(rd, genome.tobytes(), int(j["refStartLoc"]), int(j["refEndLoc"]), r4[0], r4[1], r4[2])
+                    done[t] += 1
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        dt = time.perf_counter() - t0
+        cpu = {"value": sample / dt, "unit": "pieces/s", "cores": cores, "kind": "port",
+               "sample": "first %d pieces of the same batch, fillLimited + traceback on the CPU oracle (9PacBio constants), %d threads, %.1f s; %d aligned" % (sample, cores, dt, sum(done))}
+        log("cpu baseline done")
+    torch.cuda.set_device(0)
+    ctx = M.MSAContext(maxRows=6019, maxColumns=7600, scheme=M.SCHEME_9PACBIO)
+    stride = 6019 + 7600 + 64
+    for _ in range(max(1, args.warmup)):
+        res, match = ctx.align_batch(jobs, blob, genome, match_stride=stride)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kms = 0.0
+    for _ in range(args.steps):
+        res, match = ctx.align_batch(jobs, blob, genome, match_stride=stride)
+        kms += ctx.last_kernel_ms3()[1]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    cells = int(res["iterations"].sum())
+    swept = float((jobs["read_len"].astype(np.int64) * (jobs["refEndLoc"] - jobs["refStartLoc"] + 1)).sum())
+    kms /= args.steps
+    algo = int((2 * (jobs["read_len"].astype(np.int64) + (jobs["refEndLoc"] - jobs["refStartLoc"] + 1)) + 59).sum())      # SURVEY 8(d)
+    out = {"metric": "pacbio_dp_pieces_per_sec", "value": n * args.steps / elapsed, "unit": "pieces/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "int32", "data": "synthetic",
+           "config": {"workload": "DP stage of configs[4] only (the PacBio index probe is not built): %d pieces of <= 6,000 bases with 13-17 %% PacBio errors, "
+                                  "each aligned against its window of 6,080 columns with the MultiStateAligner9PacBio scheme (fillAndScoreLimited + "
+                                  "traceback); the timed region includes the host-to-device and device-to-host copies of the batch" % n,
+                      "pieces_per_step": n, "aligned": int((res["score_len"] > 0).sum()), "visited_cells_per_step": cells,
+                      "gcups_visited": cells / (kms * 1e-3) / 1e9, "gcups_swept": swept / (kms * 1e-3) / 1e9, "strip_kernel_ms": kms,
+                      "handed_to_generic_kernel_ms": ctx.last_kernel_ms3()[2]},
+           "roofline": {"bound": "hbm", "achieved": algo / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "msa_fill_strip_kernel",
+                        "kernel_ms": kms, "algorithmic_bytes_per_launch": algo,
+                        "note": "integer-VALU-bound (about 180 VALU instructions per cell): the HBM fraction is reported as the contract asks, the rate that says something is gcups"}}
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    print(json.dumps(out))
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) before anything here touches the GPU."""
     s = socket.socket()
@@ -285,7 +377,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="hg38")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["pacbio_dp"], default="hg38")
     ap.add_argument("--reads", type=int, default=2000000, help="reads per GPU per step (pairs x 2 in the paired workloads)")
     ap.add_argument("--k", type=int, default=13)
     ap.add_argument("--max-sites", type=int, default=32)
@@ -294,6 +386,10 @@ def main():
     ap.add_argument("--stream-steps", type=int, default=3, help="steps of the PCIe-inclusive streaming region (0 = skip it)")
     args = ap.parse_args()
 
+    if args.workload == "pacbio_dp":
+        if args.gpus != 1 or "WORLD_SIZE" in os.environ:
+            raise SystemExit("--workload pacbio_dp is a one-GPU DP benchmark")
+        return pacbio_dp_main(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
