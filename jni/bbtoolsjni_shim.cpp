@@ -122,19 +122,26 @@ void throw_runtime(JNIEnv *env, const char *what) {
 void fill_common(JNIEnv *env, bool limited, jbyteArray read, jbyteArray ref, jint refStartLoc, jint refEndLoc, jint minScore,
                  jintArray result, jlongArray iterations, jintArray packed, jint maxRows, jint maxColumns, jint bandwidth, jfloat ratio) {
     const jsize readLen = env->GetArrayLength(read), refLen = env->GetArrayLength(ref);
-    // the window the fill reads is all of `ref` it needs: copy [0, refEndLoc] (bases past the window are never touched)
-    const jsize refNeed = refEndLoc + 1 < refLen ? refEndLoc + 1 : refLen;
-    std::vector<jbyte> rd((size_t)readLen + 1), rf((size_t)(refNeed > 0 ? refNeed : 0) + 1);
+    // `ref` is the whole chromosome array; the fill reads ref[refStartLoc + col - 1] for col 1..columns only
+    // (jni/MultiStateAligner11tsJNI.c:137-139, :427-438), so only that window leaves the JVM: the job is rebased to offset 0.
+    // result[] holds row / column / state indices, never absolute coordinates, so nothing else changes.
+    if (refStartLoc < 0 || refEndLoc >= refLen || refEndLoc < refStartLoc) {
+        snprintf(t_err, sizeof t_err, "bbtoolsjni: window [%d, %d] outside ref[%d]", (int)refStartLoc, (int)refEndLoc, (int)refLen);
+        throw_runtime(env, t_err);
+        return;
+    }
+    const jsize cols = refEndLoc - refStartLoc + 1;
+    std::vector<jbyte> rd((size_t)readLen + 1), rf((size_t)cols + 1);
     env->GetByteArrayRegion(read, 0, readLen, rd.data());
-    if (refNeed > 0) env->GetByteArrayRegion(ref, 0, refNeed, rf.data());
+    env->GetByteArrayRegion(ref, refStartLoc, cols, rf.data());
     jlong it = 0;
     env->GetLongArrayRegion(iterations, 0, 1, &it);
     const size_t plane = (size_t)(maxRows + 1) * (size_t)(maxColumns + 1);
     if (t_stage.size() < 3 * plane) t_stage.resize(3 * plane);
     int32_t r5[5] = {0, 0, 0, 0, 0};
     int64_t it64 = it;
-    const int rc = bbjni_fill(limited ? 1 : 0, (const uint8_t *)rd.data(), readLen, (const uint8_t *)rf.data(), refNeed, refStartLoc,
-                              refEndLoc, minScore, r5, &it64, t_stage.data(), maxRows, maxColumns, bandwidth, ratio);
+    const int rc = bbjni_fill(limited ? 1 : 0, (const uint8_t *)rd.data(), readLen, (const uint8_t *)rf.data(), cols, 0, cols - 1,
+                              minScore, r5, &it64, t_stage.data(), maxRows, maxColumns, bandwidth, ratio);
     if (rc != BBMAP_OK) {                                          // the reference calls exit(0) here (jni/...c:130-132)
         snprintf(t_err, sizeof t_err, "bbtoolsjni: fill failed (%d): %s", rc, bbmap_last_error());
         throw_runtime(env, t_err);

@@ -12,12 +12,13 @@
 
 struct _jobject { void *data; int len; int elem; };
 static int g_critical = 0, g_violations = 0, g_thrown = 0;
+static size_t g_maxRegionBytes = 0;      // largest Get<Type>ArrayRegion copy seen
 static void touch() { if (g_critical) g_violations++; }
 
 static jclass mFindClass(JNIEnv *, const char *) { touch(); static _jobject cls = {nullptr, 0, 0}; return &cls; }
 static jint mThrowNew(JNIEnv *, jclass, const char *msg) { touch(); g_thrown++; fprintf(stderr, "thrown: %s\n", msg); return 0; }
 static jsize mGetArrayLength(JNIEnv *, jarray a) { touch(); return a->len; }
-template <class T> static void getRegion(jarray a, jsize s, jsize l, T *b) { touch(); memcpy(b, (T *)a->data + s, sizeof(T) * (size_t)l); }
+template <class T> static void getRegion(jarray a, jsize s, jsize l, T *b) { touch(); if (sizeof(T) * (size_t)l > g_maxRegionBytes) g_maxRegionBytes = sizeof(T) * (size_t)l; memcpy(b, (T *)a->data + s, sizeof(T) * (size_t)l); }
 template <class T> static void setRegion(jarray a, jsize s, jsize l, const T *b) { touch(); memcpy((T *)a->data + s, b, sizeof(T) * (size_t)l); }
 static void mGetByte(JNIEnv *, jbyteArray a, jsize s, jsize l, jbyte *b) { getRegion(a, s, l, b); }
 static void mGetInt(JNIEnv *, jintArray a, jsize s, jsize l, jint *b) { getRegion(a, s, l, b); }
@@ -103,6 +104,28 @@ static int test_gpu(JNIEnv *env) {
         CHECK(it[0] == it2 && it2 > 1000);
         for (int s = 0; s < 3; s++) CHECK(memcmp(packed.data() + s * plane, packed2.data() + s * plane, (size_t)(rlen + 1) * (maxColumns + 1) * 4) == 0);
         CHECK(res[0] == rlen);
+    }
+    {   // `ref` is a whole chromosome in BBMap: a 120 MB array with the window at its far end must cost what a small one costs
+        // (only [refStartLoc, refEndLoc] may leave the JVM) and give the planes of the same window in a small array
+        const size_t big = (size_t)120 << 20;
+        std::vector<jbyte> chrom(big, (jbyte)'N');
+        const size_t base = big - ref.size();
+        memcpy(chrom.data() + base, ref.data(), ref.size());
+        const int st = 700, len = 140;
+        std::vector<jbyte> rd(ref.begin() + st, ref.begin() + st + len);
+        rd[60] = (rd[60] == 'A') ? 'C' : 'A';
+        const int a = st - 4, b = st + len + 3, minScore = (int)(0.56f * (70 + 100 * (len - 1)));
+        jint res[5] = {0, 0, 0, 0, 0}; jlong it[1] = {0};
+        _jobject jrd{rd.data(), len, 1}, jrf{chrom.data(), (int)big, 1}, jres{res, 5, 4}, jit{it, 1, 8}, jpk{packed.data(), (int)packed.size(), 4};
+        Java_align2_MultiStateAligner11tsJNI_fillLimitedXJNI(env, nullptr, &jrd, &jrf, (jint)(base + a), (jint)(base + b), minScore, &jres, &jit, &jpk,
+                                                             nullptr, nullptr, maxRows, maxColumns, 0, 0.0f, nullptr, nullptr, nullptr, nullptr);
+        CHECK(g_thrown == 0 && g_violations == 0 && g_critical == 0);
+        int32_t r2[5] = {0, 0, 0, 0, 0}; int64_t it2 = 0;
+        CHECK(bbjni_fill(1, (const uint8_t *)rd.data(), len, (const uint8_t *)ref.data(), (int)ref.size(), a, b, minScore, r2, &it2, packed2.data(), maxRows, maxColumns, 0, 0.0f) == 0);
+        for (int i = 0; i < 5; i++) CHECK(res[i] == r2[i]);
+        CHECK(it[0] == it2 && it2 > 0);
+        for (int s = 0; s < 3; s++) CHECK(memcmp(packed.data() + s * plane, packed2.data() + s * plane, (size_t)(len + 1) * (maxColumns + 1) * 4) == 0);
+        CHECK(g_maxRegionBytes <= 4096);                       // no JNI region copy anywhere near the chromosome's size
     }
     {   // BandedAligner symbol: the survey's known answer (edits 2, {19,18,19,2,1})
         jbyte q[] = "ACGTTGCAAGCTTAGGCTTA", r[] = "ACGTTGCAGCTTAGGCTTAC";
