@@ -21,6 +21,7 @@ EXPORTS = [
     "bbmap_default_config", "bbmap_create", "bbmap_destroy", "bbmap_map_batch_device", "bbmap_get_output", "bbmap_get_overflow_output", "bbmap_last_stats", "bbmap_pack_sites_device",
     "bbmap_copy_to_host", "bbidx_get_chrom_table",
     "bbpipe_revcomp_device", "bbpipe_quick_rescue_device",
+    "bbidx_build_profile", "bbkeys_default_config", "bbkeys_make", "bbkeys_make_batch", "bbmap_default_config_profile",
 ]
 
 

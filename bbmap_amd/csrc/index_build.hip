@@ -89,13 +89,13 @@ __global__ void combine_counts(const unsigned long long *total, int *counts, int
     if (rc != (int)key) v += total[rc];
     counts[key] = v > 0x7fffffffull ? 0x7fffffff : (int)v;
 }
-__global__ void zero_clumpy(const unsigned *clump, const int *countsIn, int *countsOut, int k, long long nkeys) {
+__global__ void zero_clumpy(const unsigned *clump, const int *countsIn, int *countsOut, int k, long long nkeys, int clumpyMinLen, float clumpyFraction) {
     const long long key = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
     const unsigned cc = clump[key];
     if (!cc) return;
     const int ln = countsIn[key];
-    if (ln > 2000 && (float)cc > __fmul_rn(0.75f, (float)ln)) { countsOut[key] = 0; countsOut[rc_key((int)key, k)] = 0; }
+    if (ln > clumpyMinLen && (float)cc > __fmul_rn(clumpyFraction, (float)ln)) { countsOut[key] = 0; countsOut[rc_key((int)key, k)] = 0; }
 }
 // grid-stride: one atomic per wave at the very end
 __global__ void max_kernel(const int *v, long long n, int *out) {
@@ -144,10 +144,12 @@ static void length_histogram(const std::vector<unsigned long long> &cnt, int mx,
 }
 
 // BBMap.loadIndex genome-size adjustments + analyzeIndex thresholds, as bbmap_amd/index.py:_set_params states them
+// (the same arithmetic for mapPacBio with BBIndexPacBio's statics, BBMapPacBio.java:351-365, BBIndexPacBio.java:2462-2560)
 static void derive_params(bbidx_params &p, long long definedBases, const int *h) {
-    float f = 0.03f;
-    p.maxIndel = 16000; p.maxIndel2 = 32000; p.minApproxHitsToKeep = 1; p.kfilter = 0;
-    p.maxHitsReduction2 = 2; p.maximumMaxHitsReduction = 3; p.hitReductionDiv = 5;
+    const bool pb = p.profile == BBIDX_PROFILE_PACBIO;
+    float f = pb ? 0.005f : 0.03f;                                    // FRACTION_GENOME_TO_EXCLUDE
+    p.maxIndel = pb ? 100 : 16000; p.maxIndel2 = pb ? 800 : 32000; p.minApproxHitsToKeep = 1; p.kfilter = 0;
+    p.maxHitsReduction2 = pb ? 3 : 2; p.maximumMaxHitsReduction = pb ? 6 : 3; p.hitReductionDiv = pb ? 4 : 5;
     p.quitAfterTwoPerfects = 1; p.prescanQscore = 1; p.trimByGreedy = 1; p.slow = 0;
     if (definedBases < 300000000LL) {
         p.maxHitsReduction2 += 1; p.maximumMaxHitsReduction += 1;
@@ -163,7 +165,7 @@ static void derive_params(bbidx_params &p, long long definedBases, const int *h)
     p.maxShortestListToSearch = (int)(1000 * (1 - 2.8 * fd));
     const int i1 = (int)((1.0f - f) * 1000.0f);
     const int i2 = (int)((1.0f - f * 0.25f) * 1000.0f);
-    const int SMALL = 20;
+    const int SMALL = pb ? 80 : 20;                                   // SMALL_GENOME_LIST
     p.maxUsableLength = h[i1] > 2 * SMALL ? h[i1] : 2 * SMALL;
     p.maxUsableLength2 = h[i2] > 6 * SMALL ? h[i2] : 6 * SMALL;
     const int denom = h[p.maxAverageListToSearch] > 2 * SMALL ? h[p.maxAverageListToSearch] : 2 * SMALL;
@@ -174,8 +176,15 @@ static void derive_params(bbidx_params &p, long long definedBases, const int *h)
 
 extern "C" int bbidx_build(int32_t device, int32_t k, int32_t chromBits, int32_t nchroms,
                            const uint8_t *const *chromArr, const int32_t *chromArrLen, bbidx_ctx **out) {
+    return bbidx_build_profile(device, BBIDX_PROFILE_BBMAP, k, chromBits, nchroms, chromArr, chromArrLen, out);
+}
+
+extern "C" int bbidx_build_profile(int32_t device, int32_t profile, int32_t k, int32_t chromBits, int32_t nchroms,
+                                   const uint8_t *const *chromArr, const int32_t *chromArrLen, bbidx_ctx **out) {
     if (!out || !chromArr || !chromArrLen) { bbmap_set_error("bbidx_build: null argument"); return BBMAP_E_ARG; }
     *out = nullptr;
+    if (profile != BBIDX_PROFILE_BBMAP && profile != BBIDX_PROFILE_PACBIO) { bbmap_set_error("bbidx_build: unknown profile"); return BBMAP_E_ARG; }
+    if (k <= 0) k = profile == BBIDX_PROFILE_PACBIO ? 12 : 13;            // BBMapPacBio.java:51 / BBMap.java:48
     if (k < 8 || k > 15 || nchroms < 1 || chromBits > 16) { bbmap_set_error("bbidx_build: bad geometry (k must be 8..15)"); return BBMAP_E_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { bbmap_set_error("bbidx_build: no HIP device (no CPU path)"); return BBMAP_E_NODEVICE; }
@@ -208,7 +217,7 @@ extern "C" int bbidx_build(int32_t device, int32_t k, int32_t chromBits, int32_t
         const int cpb = 1 << chromBits, shift = 31 - chromBits, lowMask = cpb - 1;
         const long long nkeys = 1LL << (2 * k);
         const unsigned kb = (unsigned)((nkeys + 255) / 256);
-        c->dev.p.k = k; c->dev.p.chromBits = chromBits; c->dev.p.minChrom = 1; c->dev.p.maxChrom = nchroms;
+        c->dev.p.k = k; c->dev.p.chromBits = chromBits; c->dev.p.minChrom = 1; c->dev.p.maxChrom = nchroms; c->dev.p.profile = profile; c->dev.p.reserved = 0;
         c->dev.nblocks = nblocks; c->dev.nchroms = nchroms;
 
         std::vector<const uint8_t *> hc((size_t)nchroms + 1, nullptr);
@@ -286,7 +295,8 @@ extern "C" int bbidx_build(int32_t device, int32_t k, int32_t chromBits, int32_t
         BHIP(hipMalloc(&d_countsRaw, (size_t)nkeys * 4));
         hipLaunchKernelGGL(bbidxb::combine_counts, dim3(kb), dim3(256), 0, nullptr, d_total, d_countsRaw, k, nkeys);
         BHIP(hipMemcpy(d_counts, d_countsRaw, (size_t)nkeys * 4, hipMemcpyDeviceToDevice));
-        hipLaunchKernelGGL(bbidxb::zero_clumpy, dim3(kb), dim3(256), 0, nullptr, d_clump, d_countsRaw, d_counts, k, nkeys);
+        hipLaunchKernelGGL(bbidxb::zero_clumpy, dim3(kb), dim3(256), 0, nullptr, d_clump, d_countsRaw, d_counts, k, nkeys,
+                           profile == BBIDX_PROFILE_PACBIO ? 2800 : 2000, profile == BBIDX_PROFILE_PACBIO ? 0.8f : 0.75f);   // CLUMPY_MIN_LENGTH_INDEX, CLUMPY_FRACTION
         hipLaunchKernelGGL(bbidxb::max_kernel, dim3(2048), dim3(256), 0, nullptr, d_counts, nkeys, d_max);
         BHIP(hipGetLastError());
         int mx = 0;

@@ -752,6 +752,7 @@ extern "C" int bbidx_create(int32_t device, const bbidx_index_desc *d, bbidx_ctx
     const bbidx_params &p = d->params;
     if (p.k < 8 || p.k > 15 || p.chromBits < 0 || p.chromBits > 16 || d->nblocks < 1 || d->nchroms < 1)
         return ifail(BBMAP_E_ARG, "bbidx_create: bad index geometry (k must be 8..15)");
+    if (p.profile != BBIDX_PROFILE_BBMAP && p.profile != BBIDX_PROFILE_PACBIO) return ifail(BBMAP_E_ARG, "bbidx_create: unknown profile");
     for (int b = 0; b < d->nblocks; b++)
         if (d->numSites[b] < 0 || (long long)d->numSites[b] > 0x7fffffffLL - 64)
             return ifail(BBMAP_E_ARG, "bbidx_create: a block holds more than 2^31 - 64 sites");
@@ -798,6 +799,7 @@ extern "C" void bbidx_destroy(bbidx_ctx *c) {
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_longWs) (void)hipFree(c->d_longWs);
     for (int i = 0; i < 2; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
@@ -828,6 +830,20 @@ extern "C" int bbidx_find_batch_device_rc(bbidx_ctx *c, void *stream_, int64_t n
     long long blocks = (n + 63) / 64;
     if (blocks > c->blocks) blocks = c->blocks;
     IHIP(hipEventRecord(c->ev[0], stream));
+    if (c->dev.p.profile == BBIDX_PROFILE_PACBIO || c->kernelKind == BBIDX_KERNEL_LONG) {
+        // mapPacBio's reads (thousands of bases, hundreds of keys), or the long-read kernel asked for by name
+        if (!c->dev.fused) return ifail(BBMAP_E_NOMEM, "bbidx_find_batch_device: the long-read kernel needs the fused key table, which could not be allocated");
+        if (!c->d_longWs) {
+            c->longBlocks = bbidx_long_blocks(c->dev.p.profile == BBIDX_PROFILE_PACBIO ? 1 : 0);
+            if (c->longBlocks < 1) return ifail(BBMAP_E_HIP, "bbidx_find_batch_device: the long-read kernel does not fit this device");
+            IHIP(hipMalloc(&c->d_longWs, (size_t)c->longBlocks * (size_t)bbidx_long_workspace_ints_per_block() * 4));
+        }
+        const int rc = bbidx_launch_long(P, stream, c->dev.p.profile == BBIDX_PROFILE_PACBIO ? 1 : 0, c->d_longWs, c->longBlocks);
+        if (rc != BBMAP_OK) return rc;
+        IHIP(hipEventRecord(c->ev[1], stream));
+        c->timed = true;
+        return BBMAP_OK;
+    }
     if (c->kernelKind == BBIDX_KERNEL_AUTO) {
         // one read per wavefront; reads it cannot take (more than 64 keys) are marked and picked up by the per-lane kernel
         // average list length >= 1/2: the variant with batched pops / bulk skips (it gates them per strand by list size);
@@ -857,7 +873,7 @@ extern "C" int bbidx_find_batch(bbidx_ctx *c, int64_t n, const bbidx_read *reads
         if (r.len < 0 || r.nkeys < 0 || r.bases_off < 0 || r.keys_off < 0 || r.bases_off + r.len > bases_bytes ||
             r.keys_off + 2LL * r.nkeys > keyinfo_ints)
             return ifail(BBMAP_E_ARG, "bbidx_find_batch: a read lies outside its buffers");
-        for (int q = 0; q < r.nkeys && q < BBIDX_MAX_KEYS; q++) {
+        for (int q = 0; q < r.nkeys && q < BBIDX_PACBIO_MAX_KEYS; q++) {
             const int o = keyinfo[r.keys_off + q];
             if (o < 0 || o + c->dev.p.k > r.len) return ifail(BBMAP_E_ARG, "bbidx_find_batch: a key offset lies outside its read");
         }
@@ -916,8 +932,10 @@ extern "C" int bbidx_set_max_read_len(bbidx_ctx *c, int32_t max_len) {
 }
 
 extern "C" int bbidx_set_kernel(bbidx_ctx *c, int32_t kind) {
-    if (!c || (kind != BBIDX_KERNEL_AUTO && kind != BBIDX_KERNEL_LANE)) return ifail(BBMAP_E_ARG, "bbidx_set_kernel: bad argument");
-    if (kind == BBIDX_KERNEL_AUTO && !c->dev.fused) return ifail(BBMAP_E_NOMEM, "bbidx_set_kernel: the fused key table could not be allocated");
+    if (!c || (kind != BBIDX_KERNEL_AUTO && kind != BBIDX_KERNEL_LANE && kind != BBIDX_KERNEL_LONG)) return ifail(BBMAP_E_ARG, "bbidx_set_kernel: bad argument");
+    if (c->dev.p.profile == BBIDX_PROFILE_PACBIO && kind != BBIDX_KERNEL_LONG && kind != BBIDX_KERNEL_AUTO)
+        return ifail(BBMAP_E_ARG, "bbidx_set_kernel: a BBIDX_PROFILE_PACBIO context only has the long-read kernel");
+    if (kind != BBIDX_KERNEL_LANE && !c->dev.fused) return ifail(BBMAP_E_NOMEM, "bbidx_set_kernel: the fused key table could not be allocated");
     c->kernelKind = kind;
     return BBMAP_OK;
 }

@@ -263,7 +263,11 @@ class bbidx_params(C.Structure):
         "k", "chromBits", "minChrom", "maxChrom", "maxIndel", "maxIndel2", "minApproxHitsToKeep", "kfilter",
         "maxUsableLength", "maxUsableLength2", "maxHitsReduction2", "maximumMaxHitsReduction", "hitReductionDiv",
         "quitAfterTwoPerfects", "prescanQscore", "trimByGreedy", "slow",
-        "maxAverageListToSearch", "maxAverageListToSearch2", "maxShortestListToSearch")] + [("pointsPerSite", C.c_int64)]
+        "maxAverageListToSearch", "maxAverageListToSearch2", "maxShortestListToSearch")] + [("pointsPerSite", C.c_int64),
+                                                                                             ("profile", C.c_int32), ("reserved", C.c_int32)]
+
+
+PROFILE_BBMAP, PROFILE_PACBIO = 0, 1        # BBIDX_PROFILE_*
 
 
 class bbidx_index_desc(C.Structure):
@@ -277,7 +281,7 @@ READ_DTYPE = np.dtype([("bases_off", "<i8"), ("keys_off", "<i8"), ("len", "<i4")
 SITE_DTYPE = np.dtype([("chrom", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("stop", "<i4"), ("hits", "<i4"),
                        ("score", "<i4"), ("perfect", "<i4"), ("semiperfect", "<i4"), ("ngaps", "<i4"),
                        ("gaps", "<i4", (16,))])
-assert C.sizeof(bbidx_params) == 88 and READ_DTYPE.itemsize == 24 and SITE_DTYPE.itemsize == 100
+assert C.sizeof(bbidx_params) == 96 and READ_DTYPE.itemsize == 24 and SITE_DTYPE.itemsize == 100
 
 
 class BuiltIndexInfo:
@@ -295,8 +299,11 @@ class DeviceIndex:
     batched probes."""
 
     @classmethod
-    def build(cls, chroms, k=13, chromBits=None, device=0):
-        """IndexMaker4 + analyzeIndex on the device (bbidx_build); returns a DeviceIndex whose .host is a BuiltIndexInfo."""
+    def build(cls, chroms, k=None, chromBits=None, device=0, profile=PROFILE_BBMAP):
+        """IndexMaker4 + analyzeIndex on the device (bbidx_build_profile); returns a DeviceIndex whose .host is a BuiltIndexInfo.
+        profile: PROFILE_BBMAP (BBIndex, k 13) or PROFILE_PACBIO (BBIndexPacBio, k 12)."""
+        if k is None:
+            k = 12 if profile == PROFILE_PACBIO else 13
         self = cls.__new__(cls)
         self.L = _lib.load()
         arrs = [np.ascontiguousarray(np.frombuffer(bytes(c), np.uint8)) if not isinstance(c, np.ndarray)
@@ -304,11 +311,11 @@ class DeviceIndex:
         ptrs = (C.c_void_p * (len(arrs) + 1))(*([0] + [a.ctypes.data for a in arrs]))
         lens = np.array([0] + [len(a) for a in arrs], np.int32)
         h = C.c_void_p()
-        self.L.bbidx_build.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p,
-                                       C.POINTER(C.c_void_p)]
-        self.L.bbidx_build.restype = C.c_int
-        _lib.check(self.L.bbidx_build(device, k, -1 if chromBits is None else chromBits, len(arrs), ptrs, lens.ctypes.data,
-                                      C.byref(h)), "bbidx_build")
+        self.L.bbidx_build_profile.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p,
+                                               C.POINTER(C.c_void_p)]
+        self.L.bbidx_build_profile.restype = C.c_int
+        _lib.check(self.L.bbidx_build_profile(device, profile, k, -1 if chromBits is None else chromBits, len(arrs), ptrs,
+                                              lens.ctypes.data, C.byref(h)), "bbidx_build_profile")
         self.h = h
         self._bind()
         p = bbidx_params()
@@ -381,8 +388,9 @@ class DeviceIndex:
         self._bind()
 
     def set_kernel(self, kind):
-        """kind: "auto" (one read per wavefront, per-lane kernel for the reads that do not fit) or "lane"."""
-        _lib.check(self.L.bbidx_set_kernel(self.h, {"auto": 0, "lane": 1}[kind]), "bbidx_set_kernel")
+        """kind: "auto" (one read per wavefront, per-lane kernel for the reads that do not fit), "lane", or "long" (the
+        long-read kernel: up to 6016 bases and 2047 keys per read; what a PROFILE_PACBIO index always runs)."""
+        _lib.check(self.L.bbidx_set_kernel(self.h, {"auto": 0, "lane": 1, "long": 2}[kind]), "bbidx_set_kernel")
 
     def set_max_read_len(self, max_len):
         """Sizing hint for the wavefront kernel (reads of at most 160 bases: 8 waves per SIMD instead of 6)."""

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define BBMAP_AMD_ABI_VERSION 4
+#define BBMAP_AMD_ABI_VERSION 5
 
 enum {
     BBMAP_OK = 0,
@@ -254,6 +254,15 @@ int bbband_align_double_batch(bbband_ctx *ctx, int64_t n_pairs, const bbband_pai
  *   (Block.sites/starts, current/align2/Block.java:162-165; AbstractIndex.COUNTS; the chromosome byte
  *   arrays) is uploaded once and stays resident in HBM.
  * ===================================================================================== */
+/* Which of the reference's two index / mapper class families a context follows.  BBMAP: align2.BBIndex + BBMapThread + BBMap.setDefaults
+ * + MultiStateAligner11ts (bbmap.sh).  PACBIO: align2.BBIndexPacBio + BBMapThreadPacBio + BBMapPacBio.setDefaults +
+ * MultiStateAligner9PacBio (mapPacBio.sh).  BBIndexPacBio is BBIndex with other constants (current/align2/BBIndexPacBio.java:2461-2596:
+ * k 12, MAX_INDEL 100 / MAX_INDEL2 800, Z_SCORE_MULT 25, INDEL_PENALTY KEY/8-1 and x25, HIT_FRACTION_TO_RETAIN .97, MIN_HIT_LISTS_TO_RETAIN
+ * 12, SMALL_GENOME_LIST 80, MIN_SCORE_MULT .02, MIN_QSCORE_MULT(2) .005, DYNAMIC_SCORE_THRESH .64, MAX_HITS_REDUCTION_PERFECT 2,
+ * clumpy-key constants 2800 / .8, FRACTION_GENOME_TO_EXCLUDE .005, the retry thresholds of find() 20/18/16/14 (:409-421)), reads of
+ * up to 6000 bases and up to 2047 keys (:2394-2396), and its location-array score is MultiStateAligner9PacBio.calcAffineScore. */
+enum { BBIDX_PROFILE_BBMAP = 0, BBIDX_PROFILE_PACBIO = 1 };
+
 typedef struct bbidx_params {   /* the reference's mutable statics, BBIndex.java:3168-3305, AbstractIndex.java:100-160 */
     int32_t k, chromBits, minChrom, maxChrom;
     int32_t maxIndel, maxIndel2, minApproxHitsToKeep, kfilter;
@@ -262,7 +271,9 @@ typedef struct bbidx_params {   /* the reference's mutable statics, BBIndex.java
     int32_t quitAfterTwoPerfects, prescanQscore, trimByGreedy, slow;
     int32_t maxAverageListToSearch, maxAverageListToSearch2, maxShortestListToSearch;
     int64_t pointsPerSite;      /* Solver.POINTS_PER_SITE after analyzeIndex */
-} bbidx_params;                 /* 88 bytes */
+    int32_t profile;            /* BBIDX_PROFILE_*: the constants that are `static final` in the reference */
+    int32_t reserved;
+} bbidx_params;                 /* 96 bytes */
 
 typedef struct bbidx_index_desc {   /* host pointers; everything is copied to the device by bbidx_create */
     bbidx_params params;
@@ -292,7 +303,8 @@ typedef struct bbidx_site { /* stream.SiteScore as the probe emits it (current/s
     int32_t gaps[BBIDX_MAX_GAPS];
 } bbidx_site;               /* 100 bytes */
 
-enum { BBIDX_MAX_KEYS = 128, BBIDX_MAX_READ_LEN = 600 };
+enum { BBIDX_MAX_KEYS = 128, BBIDX_MAX_READ_LEN = 600 };          /* BBIDX_PROFILE_BBMAP (BBIndex keeps 256 keys, 600 bases) */
+enum { BBIDX_PACBIO_MAX_KEYS = 2047, BBIDX_PACBIO_MAX_READ_LEN = 6016 };   /* BBIDX_PROFILE_PACBIO: HEAP_LENGTH 2047; reads are split at 6000 */
 
 typedef struct bbidx_ctx bbidx_ctx;
 int bbidx_create(int32_t device, const bbidx_index_desc *desc, bbidx_ctx **out);
@@ -327,6 +339,9 @@ int bbidx_last_stats(bbidx_ctx *ctx, int64_t *stats5, float *kernel_ms);
  * host. */
 int bbidx_build(int32_t device, int32_t k, int32_t chromBits, int32_t nchroms,
                 const uint8_t *const *chromArr, const int32_t *chromArrLen, bbidx_ctx **out);
+/* The same for either profile (bbidx_build = BBIDX_PROFILE_BBMAP); k <= 0 takes the profile's default (13 / 12). */
+int bbidx_build_profile(int32_t device, int32_t profile, int32_t k, int32_t chromBits, int32_t nchroms,
+                        const uint8_t *const *chromArr, const int32_t *chromArrLen, bbidx_ctx **out);
 /* The tunables a context works with (derived by bbidx_build, or as given to bbidx_create). */
 int bbidx_get_params(bbidx_ctx *ctx, bbidx_params *out);
 /* Copies one block's arrays back to the host (any pointer may be NULL): starts 4^k+1 ints, sites starts[4^k] ints
@@ -337,13 +352,42 @@ int bbidx_export_block(bbidx_ctx *ctx, int32_t block, int32_t *starts, int32_t *
 /* Which probe kernel a context launches.  AUTO (default): one read per wavefront (registers + LDS), with the
  * one-read-per-lane kernel taking the reads that do not fit it (more than 64 keys).  LANE: the per-lane kernel
  * for every read (any shape up to BBIDX_MAX_KEYS / BBIDX_MAX_READ_LEN; kept as the cross-check). */
-enum { BBIDX_KERNEL_AUTO = 0, BBIDX_KERNEL_LANE = 1 };
+enum { BBIDX_KERNEL_AUTO = 0, BBIDX_KERNEL_LANE = 1,
+       BBIDX_KERNEL_LONG = 2 };   /* the long-read kernel (up to 6016 bases, 2047 keys) for every read: what a BBIDX_PROFILE_PACBIO
+                                   * context always runs; selectable on a BBMAP context as a third cross-check */
 int bbidx_set_kernel(bbidx_ctx *ctx, int32_t kind);
 
 /* Longest read of the batches to come (default BBIDX_MAX_READ_LEN).  Sizing hint, not a limit: the wavefront kernel keeps a
  * read's per-base arrays in LDS, and with reads of at most 160 bases it needs a third less of it and runs 8 waves per SIMD
  * instead of 6; reads longer than announced are still answered (by the per-lane kernel). */
 int bbidx_set_max_read_len(bbidx_ctx *ctx, int32_t max_len);
+
+/* =====================================================================================
+ * The probe's per-read inputs, host side: AbstractMapThread.quickMap up to its findAdvanced call
+ *   (current/align2/AbstractMapThread.java:642-728): key error probabilities from the qualities (QualityTools.makeKeyProbs,
+ *   current/align2/QualityTools.java:188-279), key placement (KeyRing.makeOffsets3, current/align2/KeyRing.java:396-506, with the
+ *   density window of :663-676), key scores (QualityTools.makeKeyScores :125-133) and base scores (makeByteScoreArray :145-181).
+ *   Float code on the mapping thread in the reference, host code here; its integer outputs are the probe's inputs.
+ * ===================================================================================== */
+typedef struct bbkeys_config {
+    int32_t k;                      /* KEYLEN */
+    float keyDensity, maxKeyDensity, minKeyDensity;   /* BBMap.java:52-54 (1.9 / 3 / 1.5); BBMapPacBio.java:55-57 (3.5 / 4.5 / 2.8) */
+    int32_t maxDesiredKeys;         /* 15 / 63 */
+    int32_t minApproxHitsToKeep;    /* AbstractIndex.MIN_APPROX_HITS_TO_KEEP, 1 */
+    int32_t semiperfectMode;        /* PERFECTMODE || SEMIPERFECTMODE */
+    int32_t reserved;
+} bbkeys_config;
+int bbkeys_default_config(int32_t profile, bbkeys_config *cfg);
+/* One read.  quality: numeric phred values (not ASCII), or NULL for a read without qualities.  Writes baseScores[len]; returns the
+ * number of keys written to offsets[] / keyScores[] (cap entries each), 0 when quickMap would return without probing (read shorter
+ * than k, mostly undefined, no usable key, all keys probably wrong), < 0 on a bad argument. */
+int bbkeys_make(const bbkeys_config *cfg, const uint8_t *bases, const uint8_t *quality, int32_t len,
+                int32_t *offsets, int32_t *keyScores, int32_t cap, int8_t *baseScores);
+/* A batch: read i occupies bases[bases_off[i] .. + lens[i]) (qualities at the same offsets, or quality == NULL).  Fills reads[i],
+ * keyinfo (offsets[nkeys] then keyScores[nkeys] per read, keys_off in ints) and baseScores; *keyinfo_used = ints written. */
+int bbkeys_make_batch(const bbkeys_config *cfg, int64_t n_reads, const int64_t *bases_off, const int32_t *lens,
+                      const uint8_t *bases, const uint8_t *quality, bbidx_read *reads, int32_t *keyinfo, int64_t keyinfo_cap,
+                      int8_t *baseScores, int64_t *keyinfo_used);
 
 /* =====================================================================================
  * Batch helpers (device-resident) used by the mapper below; also callable on their own.
@@ -419,7 +463,8 @@ typedef struct bbmap_config {
     int32_t device;
     int32_t paired;                /* 0: processRead per read; 1: processReadPair, reads 2p and 2p+1 are mates */
     int32_t max_reads;             /* capacity in reads (not pairs) */
-    int32_t max_read_len;          /* <= 600 */
+    int32_t max_read_len;          /* <= 600 (BBIDX_PROFILE_BBMAP), <= 6016 (BBIDX_PROFILE_PACBIO: maxReadLength() = ALIGN_ROWS - 1 = 6019,
+                                    * current/align2/BBMapThreadPacBio.java:28,70; pieces are cut at 6000) */
     int32_t max_sites;             /* per-read capacity of the probe output and of the mapper's site list (<= 4096); reads that
                                     * need more go to the overflow tier */
     float   minRatio;              /* MINIMUM_ALIGNMENT_SCORE_RATIO (0.56) */
@@ -442,7 +487,8 @@ typedef struct bbmap_config {
     int32_t jobsPerRead;           /* capacity of the job log = jobsPerRead * max_reads (0 = 3) */
     int32_t reserved[4];           /* [0] != 0: strictly one fill per read and round (no fills ahead of time; for tests)
                                     * [1] overflow tier: reads it can hold per batch (0 = 4096, < 0 = no tier)
-                                    * [2] overflow tier: its max_sites (0 = 1024) */
+                                    * [2] overflow tier: its max_sites (0 = 1024)
+                                    * [3] BBIDX_PROFILE_*: which mapper / aligner classes are followed (must equal the index's) */
 } bbmap_config;
 
 typedef struct bbmap_output {      /* device pointers, valid until the next bbmap_map_batch_device / bbmap_destroy */
@@ -475,6 +521,9 @@ typedef struct bbmap_stats {
 
 typedef struct bbmap_ctx bbmap_ctx;
 int bbmap_default_config(bbmap_config *cfg);
+/* bbmap.sh's defaults (BBMap.setDefaults, current/align2/BBMap.java:45-65) or mapPacBio.sh's (BBMapPacBio.setDefaults,
+ * current/align2/BBMapPacBio.java:47-69: minRatio 0.46, padding 8 / 16, tip search 15, 7600 columns, single-ended) */
+int bbmap_default_config_profile(int32_t profile, bbmap_config *cfg);
 /* The context borrows `index` (which must outlive it) and owns two DP contexts (plain and gapped-reference), the overflow tier
  * (a second, small set of the same) and every intermediate buffer.  One batch at a time per context, from one thread at a time; the
  * call itself uses two internal streams and a helper thread (the overflow tier's pass runs beside the main one) and has joined

@@ -29,17 +29,58 @@
 
 #include "msa11ts_oracle.h"
 
-#define KEYBUF 256
+#define KEYBUF 2048                 /* BBIndexPacBio.HEAP_LENGTH 2047 (BBIndexPacBio.java:2395); BBIndex keeps 256 (BBIndex.java:3102) */
 #define BASE_HIT_SCORE 100
-#define Z_SCORE_MULT 20
 #define Y_SCORE_MULT 10
+#define MINGAP 256
+#ifdef ORC_PACBIO
+/* align2.BBIndexPacBio: the same class with other tunables (a diff of BBIndexPacBio.java against BBIndex.java shows constants, the
+ * thresholds of find()'s "too few hits" retries and array sizes; BBIndex's camelWalk3 is dead code, USE_CAMELWALK=false).
+ * BBIndexPacBio.java:2475 (Z_SCORE_MULT), :2538 (SMALL_GENOME_LIST), :2527, :2523, :2590-2593, :76-77 (INDEL_PENALTY), :2545-2546 */
+#define Z_SCORE_MULT 25
+#define SMALL_GENOME_LIST 80
+#define MIN_HIT_LISTS_TO_RETAIN 12
+static const float HIT_FRACTION_TO_RETAIN = 0.97f;
+static const float MIN_SCORE_MULT = 0.02f;
+static const float MIN_QSCORE_MULT = 0.005f, MIN_QSCORE_MULT2 = 0.005f;
+static const float DYNAMIC_SCORE_THRESH = 0.64f, DYNAMIC_QSCORE_THRESH = 0.6f, DYNAMIC_QSCORE_THRESH_PERFECT = 0.8f;
+#define INDEL_PENALTY_OF(bkhs) (((bkhs) / 8) - 1)
+#define INDEL_PENALTY_MULT 25
+#define RELAX1 20
+#define RELAX2 18
+#define RELAX3 16
+#define RELAX4 14
+#define CLUMPY_MIN_LENGTH_INDEX 2800
+#define CLUMPY_FRACTION 0.8f
+#define DEF_MAX_INDEL 100
+#define DEF_MAX_INDEL2 800
+#define DEF_MAX_HITS_REDUCTION2 3
+#define DEF_MAXIMUM_MAX_HITS_REDUCTION 6
+#define DEF_HIT_REDUCTION_DIV 4
+#define MAX_HITS_REDUCTION_PERFECT 2     /* BBIndexPacBio.java:2557 */
+#else
+#define Z_SCORE_MULT 20
 #define SMALL_GENOME_LIST 20
 #define MIN_HIT_LISTS_TO_RETAIN 6
-#define MINGAP 256
 static const float HIT_FRACTION_TO_RETAIN = 0.85f;
 static const float MIN_SCORE_MULT = 0.15f;          /* USE_AFFINE_SCORE */
 static const float MIN_QSCORE_MULT = 0.025f, MIN_QSCORE_MULT2 = 0.1f;
 static const float DYNAMIC_SCORE_THRESH = 0.84f, DYNAMIC_QSCORE_THRESH = 0.6f, DYNAMIC_QSCORE_THRESH_PERFECT = 0.8f;
+#define INDEL_PENALTY_OF(bkhs) (((bkhs) / 2) - 1)   /* BBIndex.java:75-76 */
+#define INDEL_PENALTY_MULT 20
+#define RELAX1 4                    /* BBIndex.java:424-436 */
+#define RELAX2 3
+#define RELAX3 3
+#define RELAX4 2
+#define CLUMPY_MIN_LENGTH_INDEX 2000
+#define CLUMPY_FRACTION 0.75f
+#define DEF_MAX_INDEL 16000
+#define DEF_MAX_INDEL2 32000
+#define DEF_MAX_HITS_REDUCTION2 2
+#define DEF_MAXIMUM_MAX_HITS_REDUCTION 3
+#define DEF_HIT_REDUCTION_DIV 5
+#define MAX_HITS_REDUCTION_PERFECT 0     /* BBIndex.java:3262 */
+#endif
 #define PRESCAN_QSCORE_THRESH (DYNAMIC_QSCORE_THRESH * .95f)
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
@@ -130,7 +171,7 @@ orc_index *orc_index_build(int k, int chromBits, int nchroms, const uint8_t **ch
     for (int key = 0; key < keyspace; key++) {
         if (clumpsOf[key] > 0) {
             const int64_t clumps = clumpsOf[key], len = COUNTS[key];
-            if (len > 2000 && (float)clumps > 0.75f * (float)len) { COUNTS[key] = 0; COUNTS[rc_key(key, k)] = 0; }
+            if (len > CLUMPY_MIN_LENGTH_INDEX && (float)clumps > CLUMPY_FRACTION * (float)len) { COUNTS[key] = 0; COUNTS[rc_key(key, k)] = 0; }
         }
     }
     free(clumpsOf);
@@ -152,9 +193,9 @@ orc_index *orc_index_build(int k, int chromBits, int nchroms, const uint8_t **ch
         free(cnt);
     }
     orc_index_params *p = &ix->p;
-    p->maxIndel = 16000; p->maxIndel2 = 32000; p->minApproxHitsToKeep = 1; p->kfilter = 0;
+    p->maxIndel = DEF_MAX_INDEL; p->maxIndel2 = DEF_MAX_INDEL2; p->minApproxHitsToKeep = 1; p->kfilter = 0;
     p->quitAfterTwoPerfects = 1; p->prescanQscore = 1; p->trimByGreedy = 1; p->slow = 0;
-    p->maxHitsReduction2 = 2; p->maximumMaxHitsReduction = 3; p->hitReductionDiv = 5;
+    p->maxHitsReduction2 = DEF_MAX_HITS_REDUCTION2; p->maximumMaxHitsReduction = DEF_MAXIMUM_MAX_HITS_REDUCTION; p->hitReductionDiv = DEF_HIT_REDUCTION_DIV;
     const double f = fractionToExclude;                   /* BBIndex.setFractionToExclude: double arithmetic on a float */
     p->maxAverageListToSearch = (int)(1000 * (1 - 2.3 * f));
     p->maxAverageListToSearch2 = (int)(1000 * (1 - 1.4 * f));
@@ -251,7 +292,7 @@ static int calc_approx_hits_cutoff(const orc_index_params *p, int keys, int hits
     const int reduction = imin(imax(hits / p->hitReductionDiv, p->maxHitsReduction2), imax(p->maximumMaxHitsReduction, keys / 8));
     int r = hits - reduction;
     r = imax(mahtk, imax(currentCutoff, r));
-    if (perfect) r = imax(r, keys - 0);
+    if (perfect) r = imax(r, keys - MAX_HITS_REDUCTION_PERFECT);
     return r;
 }
 
@@ -323,8 +364,33 @@ typedef struct {
     int row[KEYBUF], stop[KEYBUF], value[KEYBUF], offs[KEYBUF], kscore[KEYBUF];
     int live[KEYBUF];         /* still in the heap */
     int nlive;
+    int hp[KEYBUF], hn;       /* the heap: indices of the live lists */
     const int32_t *sites;
 } lists;
+
+/* QuadHeap (align2/QuadHeap.java) ordered by Quad.compareTo = (site, column) (Quad.java:19-22): a binary heap of list
+ * indices.  Only its minimum is ever observed, so any correct heap gives the reference's pop sequence. */
+static inline int heap_less(const lists *L, int a, int b) { return L->value[a] < L->value[b] || (L->value[a] == L->value[b] && a < b); }
+static void heap_sift_down(lists *L, int i) {
+    const int n = L->hn; const int x = L->hp[i];
+    for (;;) {
+        int c = 2 * i + 1;
+        if (c >= n) break;
+        if (c + 1 < n && heap_less(L, L->hp[c + 1], L->hp[c])) c++;
+        if (!heap_less(L, L->hp[c], x)) break;
+        L->hp[i] = L->hp[c]; i = c;
+    }
+    L->hp[i] = x;
+}
+static void heap_build(lists *L) {
+    L->hn = 0;
+    for (int i = 0; i < L->n; i++) if (L->live[i]) L->hp[L->hn++] = i;
+    for (int i = L->hn / 2 - 1; i >= 0; i--) heap_sift_down(L, i);
+}
+/* heap.peek(): smallest (site, column) among live lists */
+static inline int lists_peek(const lists *L) { return L->hn > 0 ? L->hp[0] : -1; }
+static inline void heap_fix_top(lists *L) { heap_sift_down(L, 0); }                 /* the top's value grew */
+static inline void heap_pop(lists *L) { L->hp[0] = L->hp[--L->hn]; if (L->hn > 0) heap_sift_down(L, 0); }
 
 static inline int adjust_site(const walker *w, int a, int offset, int baseChrom) {
     if ((a & w->c.siteMask) >= offset) return a - offset;
@@ -342,14 +408,8 @@ static void lists_init(const walker *w, lists *L, int block, const int *starts, 
         L->live[j] = 1;
     }
     L->nlive = L->n;
+    heap_build(L);
 }
-/* heap.peek(): smallest (site, column) among live lists */
-static inline int lists_peek(const lists *L) {
-    int best = -1;
-    for (int i = 0; i < L->n; i++) if (L->live[i] && (best < 0 || L->value[i] < L->value[best])) best = i;
-    return best;
-}
-
 /* ------------------------------------------------------------------------------------ findMaxQscore2 */
 static void find_max_qscore2(const walker *w, lists *L, int baseChrom, int prevMaxHits, int earlyExit, int perfectOnly,
                              int *outQ, int *outHits) {
@@ -385,9 +445,9 @@ static void find_max_qscore2(const walker *w, lists *L, int baseChrom, int prevM
             if (col < 0 || L->value[col] != site) break;
             if (w->stats) w->stats[0]++;
             const int row = L->row[col] + 1;
-            if (row < L->stop[col]) { L->row[col] = row; L->value[col] = adjust_site(w, L->sites[row], L->offs[col], baseChrom); }
+            if (row < L->stop[col]) { L->row[col] = row; L->value[col] = adjust_site(w, L->sites[row], L->offs[col], baseChrom); heap_fix_top(L); }
             else {
-                L->live[col] = 0; L->nlive--;
+                L->live[col] = 0; L->nlive--; heap_pop(L);
                 if (earlyExit && (perfectOnly || L->nlive < approxHitsCutoff)) { *outQ = topQscore; *outHits = maxHits; return; }
             }
             if (L->nlive == 0) break;
@@ -646,9 +706,9 @@ static void slow_walk3(const walker *w, int block, const int *starts, const int 
             if (col < 0 || L.value[col] != site) break;
             if (w->stats) w->stats[1]++;
             const int row = L.row[col] + 1;
-            if (row < L.stop[col]) { L.row[col] = row; L.value[col] = adjust_site(w, L.sites[row], L.offs[col], baseChrom); }
+            if (row < L.stop[col]) { L.row[col] = row; L.value[col] = adjust_site(w, L.sites[row], L.offs[col], baseChrom); heap_fix_top(&L); }
             else {
-                L.live[col] = 0; L.nlive--;
+                L.live[col] = 0; L.nlive--; heap_pop(&L);
                 if (L.nlive < approxHitsCutoff) { finished = 1; break; }
             }
             if (L.nlive == 0) break;
@@ -770,7 +830,7 @@ int orc_index_find(const orc_index *ix, const uint8_t *basesP, const uint8_t *ba
     w.c.ix = ix; w.c.shift = 31 - p->chromBits; w.c.siteMask = (int)(0xFFFFFFFFu >> (p->chromBits + 1));
     w.c.cpb = 1 << p->chromBits; w.c.lowMask = w.c.cpb - 1; w.c.highMask = ~w.c.lowMask;
     w.keylen = p->k; w.baseKeyHitScore = BASE_HIT_SCORE * p->k;
-    w.indelPenalty = (w.baseKeyHitScore / 2) - 1; w.indelPenaltyMult = 20;
+    w.indelPenalty = INDEL_PENALTY_OF(w.baseKeyHitScore); w.indelPenaltyMult = INDEL_PENALTY_MULT;
     w.maxPenalty = w.baseKeyHitScore - (1 + w.baseKeyHitScore / 8);
     w.scoreZ1Key = Z_SCORE_MULT * p->k;
 
@@ -785,10 +845,10 @@ int orc_index_find(const orc_index *ix, const uint8_t *basesP, const uint8_t *ba
     int numHits = count_hits(ix, keysP, n, maxLen);
     if (numHits > 0) {
         const int trigger = (3 * n) / 4;
-        if (numHits < 4 && numHits < trigger) { memcpy(keysP, keysOriginal, sizeof(int) * (size_t)n); numHits = count_hits(ix, keysP, n, (maxLen * 3) / 2); }
-        if (numHits < 3 && numHits < trigger) { memcpy(keysP, keysOriginal, sizeof(int) * (size_t)n); numHits = count_hits(ix, keysP, n, maxLen * 2); }
-        if (numHits < 3 && numHits < trigger) { memcpy(keysP, keysOriginal, sizeof(int) * (size_t)n); numHits = count_hits(ix, keysP, n, maxLen * 3); }
-        if (numHits < 2 && numHits < trigger) { memcpy(keysP, keysOriginal, sizeof(int) * (size_t)n); numHits = count_hits(ix, keysP, n, maxLen * 5); }
+        if (numHits < RELAX1 && numHits < trigger) { memcpy(keysP, keysOriginal, sizeof(int) * (size_t)n); numHits = count_hits(ix, keysP, n, (maxLen * 3) / 2); }
+        if (numHits < RELAX2 && numHits < trigger) { memcpy(keysP, keysOriginal, sizeof(int) * (size_t)n); numHits = count_hits(ix, keysP, n, maxLen * 2); }
+        if (numHits < RELAX3 && numHits < trigger) { memcpy(keysP, keysOriginal, sizeof(int) * (size_t)n); numHits = count_hits(ix, keysP, n, maxLen * 3); }
+        if (numHits < RELAX4 && numHits < trigger) { memcpy(keysP, keysOriginal, sizeof(int) * (size_t)n); numHits = count_hits(ix, keysP, n, maxLen * 5); }
     }
     const int nOriginal = n;
     if (numHits < n) n = shrink2(offsetsP, keysP, keyScoresP, n);

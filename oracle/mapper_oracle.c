@@ -55,6 +55,12 @@ enum { TIP_DELETION_MAX_TIPLEN = 8, OUTER_DIST_MULT = 14, OUTER_DIST_DIV = 32 };
 enum { MIN_TRIM_SITES_TO_RETAIN_SINGLE = 3, MIN_TRIM_SITES_TO_RETAIN_PAIRED = 2 };   /* BBMapThread.java:62-63 */
 
 #define LISTCAP 2048
+/* AbstractMapThread.java:142: CLEARZONE1e = 2*POINTS_MATCH2 - POINTS_MATCH - POINTS_SUB + 1; quickRescue's points (:1205-1206) */
+#ifdef ORC_PACBIO
+enum { CLEARZONE1E = 2 * 100 - 90 + 137 + 1, QR_MATCH = 90, QR_MATCH2 = 100 };     /* MultiStateAligner9PacBio.java:2377-2380 */
+#else
+enum { CLEARZONE1E = 2 * 100 - 70 + 127 + 1, QR_MATCH = 70, QR_MATCH2 = 100 };     /* = 258 */
+#endif
 
 typedef struct { orc_msite s[LISTCAP]; int n; } slist;
 
@@ -301,13 +307,20 @@ static void complement_into(uint8_t *dst, const uint8_t *src, int L) {
     }
 }
 
-static void quick_map(mapper *M, const uint8_t *bp, const uint8_t *bm, int L, const int32_t *offsets, const int32_t *keyScores, int nkeys,
-                      slist *out) {
+/* what quickMap hands to the index for one read: AbstractMapThread.java:659-736 (offsets, key scores and base scores come from the
+ * read's qualities there; here they are inputs).  bs == NULL: all-zero base scores (a read without qualities, QualityTools.java:164-181) */
+typedef struct { const uint8_t *bp; int L; const int8_t *bs; const int32_t *offsets, *keyScores; int nkeys; } readin;
+
+static void quick_map(mapper *M, const readin *in, const uint8_t *bm, slist *out) {
+    const uint8_t *bp = in->bp; const int L = in->L;
     out->n = 0;
-    if (L < M->ix->p.k) return;                                           /* AbstractMapThread.java:646 */
+    if (L < M->ix->p.k || in->nkeys < 1) return;                          /* AbstractMapThread.java:646, :701 */
     static __thread orc_site raw[LISTCAP];
-    int8_t bs[1024]; memset(bs, 0, sizeof bs);
-    const int ns = orc_index_find(M->ix, bp, bm, L, bs, keyScores, offsets, nkeys, raw, LISTCAP, NULL);
+    int8_t *zero = NULL;
+    const int8_t *bs = in->bs;
+    if (!bs) { zero = (int8_t *)calloc((size_t)L + 1, 1); bs = zero; }
+    const int ns = orc_index_find(M->ix, bp, bm, L, bs, in->keyScores, in->offsets, in->nkeys, raw, LISTCAP, NULL);
+    free(zero);
     const int expLimit = (M->P->alignColumns * 17) / 20 - (2 * (M->P->slowAlignPadding + 10));     /* EXPECTED_LEN_LIMIT :92 */
     for (int i = 0; i < ns; i++) {
         orc_msite ss; memset(&ss, 0, sizeof ss);
@@ -476,7 +489,7 @@ static void score_slow(mapper *M, int which, slist *l, const uint8_t *bp, const 
     const orc_map_params *P = M->P;
     const float R = P->minRatio;
     const float ratio = paired ? orc_ratio_pre_rescue(R) : R;
-    const int CZ1e = 258, CZ3 = P->clearzone3;
+    const int CZ1e = CLEARZONE1E, CZ3 = P->clearzone3;
     int minMsaLimit = -CZ1e + (int)(ratio * (float)maxSw);
     const int expLimit = (P->alignColumns * 17) / 20 - (2 * (P->slowAlignPadding + 10));
     for (int i = 0; i < l->n; i++) {
@@ -575,7 +588,7 @@ static void slow_rescue(mapper *M, int which, const uint8_t *bases, int L, orc_m
         if (tipR || tipL) {
             if (find_tip_deletions_site(M, ss, bases, L, maxImp, tipR, tipL)) { ss->match_job = -1; sw = orc_score_no_indels(bases, L, c, cl, NULL, ss->start); }
         }
-        const int minMsaLimit = -258 + (int)(orc_ratio_paired(P->minRatio) * (float)maxScore);
+        const int minMsaLimit = -CLEARZONE1E + (int)(orc_ratio_paired(P->minRatio) * (float)maxScore);
         const int minscore = imax(sw, minMsaLimit);
         int32_t sc[8]; int job = -1;
         const int n = fill_and_score(M, which, 2, bases, L, ss, P->slowRescuePadding, minscore, sc, &job);
@@ -614,7 +627,7 @@ static void rescue(mapper *M, int whichLoose, slist *anchor, slist *loose, int a
             else { bases = bp; loc = ssa->start + searchIntoAnchor; idealStart = ssa->start - P->averagePairDist; }
             int32_t q[8];
             const uint8_t *c = M->ix->chromArr[ssa->chrom]; const int cl = M->ix->chromArrLen[ssa->chrom];
-            orc_quick_rescue(bases, L, c, cl, 0, loc, searchDist + searchIntoAnchor, searchRight, idealStart, maxMismatches, 70, 100, 1, 100, q);
+            orc_quick_rescue(bases, L, c, cl, 0, loc, searchDist + searchIntoAnchor, searchRight, idealStart, maxMismatches, QR_MATCH, QR_MATCH2, 1, 100, q);
             M->rescueScans++;
             if (q[0]) {
                 orc_msite ss; memset(&ss, 0, sizeof ss);
@@ -641,10 +654,11 @@ static void rescue(mapper *M, int whichLoose, slist *anchor, slist *loose, int a
 }
 
 /* ------------------------------------------------------------------ processRead (BBMapThread.java:389-490) */
-static void process_read(mapper *M, const uint8_t *bp, int L, const int32_t *offsets, const int32_t *keyScores, int nkeys, slist *l) {
-    uint8_t bm[1024];
+static void process_read(mapper *M, const readin *in, slist *l) {
+    const uint8_t *bp = in->bp; const int L = in->L;
+    uint8_t *bm = (uint8_t *)malloc((size_t)L + 1);
     complement_into(bm, bp, L);
-    quick_map(M, bp, bm, L, offsets, keyScores, nkeys, l);
+    quick_map(M, in, bm, l);
     const int maxSw = orc_max_quality(L), maxImp = orc_max_imperfect_score(L);
     if (M->P->trimList && l->n > 1) { sort_list(l, cmp_score); trim_list(l, 0, maxSw, 1, MIN_TRIM_SITES_TO_RETAIN_SINGLE, M->P->maxTrimSitesToRetain); }
     if (l->n > 0) {
@@ -654,16 +668,19 @@ static void process_read(mapper *M, const uint8_t *bp, int L, const int32_t *off
         if (near < 1) score_slow(M, 0, l, bp, bm, L, maxSw, maxImp, 0);
     }
     if (l->n > 0) { merge_duplicate_sites(l); sort_list(l, cmp_score); }
+    free(bm);
 }
 
 /* ------------------------------------------------------------------ processReadPair (BBMapThread.java:943-1098) */
-static void process_pair(mapper *M, const uint8_t *bp1, const uint8_t *bp2, int L, const int32_t *offsets, const int32_t *keyScores, int nkeys,
-                         slist *l1, slist *l2) {
+static void process_pair_tail(mapper *M, const uint8_t *bp1, const uint8_t *bm1, const uint8_t *bp2, const uint8_t *bm2, int L, slist *l1, slist *l2);
+static void process_pair(mapper *M, const readin *in1, const readin *in2, slist *l1, slist *l2) {
     const orc_map_params *P = M->P;
-    uint8_t bm1[1024], bm2[1024];
+    const uint8_t *bp1 = in1->bp, *bp2 = in2->bp;
+    const int L = in1->L;                                   /* both mates have one length in every caller of this restatement */
+    uint8_t *bm1 = (uint8_t *)malloc((size_t)L + 1), *bm2 = (uint8_t *)malloc((size_t)L + 1);
     complement_into(bm1, bp1, L); complement_into(bm2, bp2, L);
-    quick_map(M, bp1, bm1, L, offsets, keyScores, nkeys, l1);
-    quick_map(M, bp2, bm2, L, offsets, keyScores, nkeys, l2);
+    quick_map(M, in1, bm1, l1);
+    quick_map(M, in2, bm2, l2);
     const int maxSw = orc_max_quality(L), maxImp = orc_max_imperfect_score(L);
     pair_site_scores_initial(M, l1, l2, L, L, P->trimList);
     if (P->trimList) {
@@ -685,6 +702,12 @@ static void process_pair(mapper *M, const uint8_t *bp1, const uint8_t *bp2, int 
             merge_duplicate_sites(l);
         }
     }
+    process_pair_tail(M, bp1, bm1, bp2, bm2, L, l1, l2);
+    free(bm1); free(bm2);
+}
+static void process_pair_tail(mapper *M, const uint8_t *bp1, const uint8_t *bm1, const uint8_t *bp2, const uint8_t *bm2, int L, slist *l1, slist *l2) {
+    const orc_map_params *P = M->P;
+    const int maxSw = orc_max_quality(L);
     if (P->doRescue) {
         int unpaired1 = 0, unpaired2 = 0;
         for (int i = 0; i < l1->n; i++) if (l1->s[i].pairedScore == 0) unpaired1++;
@@ -712,17 +735,22 @@ float orc_ratio_pre_rescue(float R) { const float a = R * .60f, b = 1.0f - ((1.0
 
 void orc_map_default_params(orc_map_params *P) {
     memset(P, 0, sizeof *P);
-    P->minRatio = 0.56f; P->slowAlignPadding = 4; P->slowRescuePadding = 8; P->extraPadding = 10; P->tipSearchDist = 100;
     P->maxPairDist = 32000; P->averagePairDist = 100; P->maxRescueDist = 1200; P->maxRescueMismatches = 32;
-    P->maxTrimSitesToRetain = 800; P->trimList = 1; P->doRescue = 1; P->alignColumns = 3000; P->clearzone3 = 800;
-    P->msaMaxRows = 601; P->msaMaxColumns = 3000;
+    P->maxTrimSitesToRetain = 800; P->trimList = 1; P->doRescue = 1; P->clearzone3 = 800; P->extraPadding = 10;
+#ifdef ORC_PACBIO   /* BBMapPacBio.setDefaults (BBMapPacBio.java:47-69), BBMapThreadPacBio.java:27-28, BBIndexPacBio.java:2462 */
+    P->minRatio = 0.46f; P->slowAlignPadding = 8; P->slowRescuePadding = 16; P->tipSearchDist = 15;
+    P->alignColumns = 7600; P->msaMaxRows = 6020; P->msaMaxColumns = 7600;
+#else               /* BBMap.setDefaults (BBMap.java:45-65), BBMapThread.java:27-28 */
+    P->minRatio = 0.56f; P->slowAlignPadding = 4; P->slowRescuePadding = 8; P->tipSearchDist = 100;
+    P->alignColumns = 3000; P->msaMaxRows = 601; P->msaMaxColumns = 3000;
+#endif
 }
 
 typedef struct {
     const orc_index *ix; const orc_map_params *P;
-    const uint8_t *reads1, *reads2; int64_t n; int L;
-    const int32_t *offsets, *keyScores; int nkeys;
-    int cap; orc_msite *sites1, *sites2; int32_t *nsites1, *nsites2;
+    const orc_read *recs; const uint8_t *bases; const int8_t *baseScores; const int32_t *keyinfo;
+    int64_t n; int paired;         /* n = reads (single-ended) or pairs; pair p = records 2p, 2p+1 */
+    int cap; orc_msite *sites; int32_t *nsites;
     orc_mjob *log; int64_t logcap; volatile int64_t *nlog; uint8_t *match; int matchStride;
     volatile int64_t *next;
     int64_t dpJobs, cells, rescueScans, mapped;
@@ -735,6 +763,14 @@ static void store_list(const slist *l, orc_msite *out, int32_t *nout, int cap) {
     memcpy(out, l->s, sizeof(orc_msite) * (size_t)l->n);
 }
 
+static readin read_in(const drv_arg *w, int64_t r) {
+    const orc_read *rec = &w->recs[r];
+    readin in;
+    in.bp = w->bases + rec->bases_off; in.L = rec->len; in.bs = w->baseScores ? w->baseScores + rec->bases_off : NULL;
+    in.offsets = w->keyinfo + rec->keys_off; in.keyScores = in.offsets + rec->nkeys; in.nkeys = rec->nkeys;
+    return in;
+}
+
 static void *drv_worker(void *p) {
     drv_arg *w = (drv_arg *)p;
     mapper M; memset(&M, 0, sizeof M);
@@ -742,23 +778,25 @@ static void *drv_worker(void *p) {
     M.tbcap = w->P->msaMaxRows + w->P->msaMaxColumns + 64 + 128 * 64; M.tb = (uint8_t *)malloc((size_t)M.tbcap);
     M.log = w->log; M.logcap = w->logcap; M.nlog = w->nlog; M.match = w->match; M.matchStride = w->matchStride;
     slist *l1 = (slist *)malloc(sizeof(slist)), *l2 = (slist *)malloc(sizeof(slist));
-    const int L = w->L;
+    const int64_t chunk = w->recs[0].len > 1000 ? 1 : 64;
     for (;;) {
-        const int64_t i0 = __sync_fetch_and_add(w->next, 64);
+        const int64_t i0 = __sync_fetch_and_add(w->next, chunk);
         if (i0 >= w->n) break;
-        const int64_t hi = i0 + 64 < w->n ? i0 + 64 : w->n;
+        const int64_t hi = i0 + chunk < w->n ? i0 + chunk : w->n;
         for (int64_t r = i0; r < hi; r++) {
             M.seq[0] = M.seq[1] = 0;
-            if (w->reads2) {
+            if (w->paired) {
                 M.readIdx[0] = 2 * r; M.readIdx[1] = 2 * r + 1;
-                process_pair(&M, w->reads1 + r * L, w->reads2 + r * L, L, w->offsets, w->keyScores, w->nkeys, l1, l2);
-                store_list(l1, w->sites1 ? w->sites1 + r * w->cap : NULL, w->nsites1 ? &w->nsites1[r] : NULL, w->cap);
-                store_list(l2, w->sites2 ? w->sites2 + r * w->cap : NULL, w->nsites2 ? &w->nsites2[r] : NULL, w->cap);
+                const readin a = read_in(w, 2 * r), b = read_in(w, 2 * r + 1);
+                process_pair(&M, &a, &b, l1, l2);
+                store_list(l1, w->sites ? w->sites + 2 * r * w->cap : NULL, w->nsites ? &w->nsites[2 * r] : NULL, w->cap);
+                store_list(l2, w->sites ? w->sites + (2 * r + 1) * w->cap : NULL, w->nsites ? &w->nsites[2 * r + 1] : NULL, w->cap);
                 w->mapped += (l1->n > 0) + (l2->n > 0);
             } else {
                 M.readIdx[0] = r;
-                process_read(&M, w->reads1 + r * L, L, w->offsets, w->keyScores, w->nkeys, l1);
-                store_list(l1, w->sites1 ? w->sites1 + r * w->cap : NULL, w->nsites1 ? &w->nsites1[r] : NULL, w->cap);
+                const readin a = read_in(w, r);
+                process_read(&M, &a, l1);
+                store_list(l1, w->sites ? w->sites + r * w->cap : NULL, w->nsites ? &w->nsites[r] : NULL, w->cap);
                 w->mapped += (l1->n > 0);
             }
         }
@@ -768,15 +806,19 @@ static void *drv_worker(void *p) {
     return NULL;
 }
 
-/* Maps n reads (reads2 == NULL) or n pairs of L-base reads.  sites*: n x cap records (may be NULL: timing only).  log (optional):
- * one record per fillAndScoreLimited call; match: logcap x matchStride bytes.  stats4 = {DP calls, visited cells, quickRescue
- * scans, reads with at least one site}.  Returns elapsed seconds. */
-double orc_map_batch(const orc_index *ix, const orc_map_params *P, const uint8_t *reads1, const uint8_t *reads2, int64_t n, int L,
-                     const int32_t *offsets, const int32_t *keyScores, int nkeys, int cap,
-                     orc_msite *sites1, int32_t *nsites1, orc_msite *sites2, int32_t *nsites2,
+/* Maps n_reads read records (paired: records 2p and 2p+1 are mates of equal length).  A record addresses its bases (and, when
+ * baseScores != NULL, its base scores) at bases_off and its keys at keyinfo[keys_off]: offsets[nkeys] then keyScores[nkeys] -- the
+ * layout of bbidx_read (include/bbmap_amd.h).  sites: n_reads x cap records (may be NULL: timing only).  log (optional): one record
+ * per fillAndScoreLimited call; match: logcap x matchStride bytes.  stats4 = {DP calls, visited cells, quickRescue scans, reads
+ * with at least one site}.  Returns elapsed seconds (-1: bad argument). */
+double orc_map_reads(const orc_index *ix, const orc_map_params *P, const orc_read *recs, int64_t n_reads, int paired,
+                     const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo, int cap,
+                     orc_msite *sites, int32_t *nsites,
                      orc_mjob *log, int64_t logcap, int64_t *nlog, uint8_t *match, int matchStride, int threads, int64_t *stats4) {
     if (threads < 1) threads = 1;
-    if (L > 1000) return -1.0;
+    if (n_reads < 1 || (paired && (n_reads & 1))) return -1.0;
+    for (int64_t r = 0; r < n_reads; r++) if (recs[r].len > P->msaMaxRows - 1) return -1.0;      /* maxReadLength() = ALIGN_ROWS - 1 */
+    if (paired) for (int64_t r = 0; r < n_reads; r += 2) if (recs[r].len != recs[r + 1].len) return -1.0;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
     drv_arg *wa = (drv_arg *)calloc((size_t)threads, sizeof(drv_arg));
     volatile int64_t next = 0, nl = 0;
@@ -784,8 +826,9 @@ double orc_map_batch(const orc_index *ix, const orc_map_params *P, const uint8_t
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int t = 0; t < threads; t++) {
         drv_arg *a = &wa[t];
-        a->ix = ix; a->P = P; a->reads1 = reads1; a->reads2 = reads2; a->n = n; a->L = L; a->offsets = offsets; a->keyScores = keyScores; a->nkeys = nkeys;
-        a->cap = cap; a->sites1 = sites1; a->sites2 = sites2; a->nsites1 = nsites1; a->nsites2 = nsites2;
+        a->ix = ix; a->P = P; a->recs = recs; a->bases = bases; a->baseScores = baseScores; a->keyinfo = keyinfo;
+        a->n = paired ? n_reads / 2 : n_reads; a->paired = paired;
+        a->cap = cap; a->sites = sites; a->nsites = nsites;
         a->log = log; a->logcap = logcap; a->nlog = &nl; a->match = match; a->matchStride = matchStride; a->next = &next;
         pthread_create(&th[t], NULL, drv_worker, a);
     }
@@ -796,4 +839,36 @@ double orc_map_batch(const orc_index *ix, const orc_map_params *P, const uint8_t
     if (stats4) memcpy(stats4, s, sizeof s);
     free(th); free(wa);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* The uniform special case (every read L bases, one set of offsets / key scores for all, no base scores): n reads (reads2 == NULL)
+ * or n pairs.  Site lists come back per mate as before. */
+double orc_map_batch(const orc_index *ix, const orc_map_params *P, const uint8_t *reads1, const uint8_t *reads2, int64_t n, int L,
+                     const int32_t *offsets, const int32_t *keyScores, int nkeys, int cap,
+                     orc_msite *sites1, int32_t *nsites1, orc_msite *sites2, int32_t *nsites2,
+                     orc_mjob *log, int64_t logcap, int64_t *nlog, uint8_t *match, int matchStride, int threads, int64_t *stats4) {
+    const int paired = reads2 != NULL;
+    const int64_t nr = paired ? 2 * n : n;
+    orc_read *recs = (orc_read *)malloc(sizeof(orc_read) * (size_t)nr);
+    uint8_t *bases = (uint8_t *)malloc((size_t)nr * (size_t)L + 1);
+    int32_t *keyinfo = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)nkeys + 4);
+    memcpy(keyinfo, offsets, sizeof(int32_t) * (size_t)nkeys); memcpy(keyinfo + nkeys, keyScores, sizeof(int32_t) * (size_t)nkeys);
+    for (int64_t r = 0; r < nr; r++) {
+        const uint8_t *src = paired ? ((r & 1) ? reads2 + (r / 2) * L : reads1 + (r / 2) * L) : reads1 + r * L;
+        memcpy(bases + r * L, src, (size_t)L);
+        recs[r].bases_off = r * L; recs[r].keys_off = 0; recs[r].len = L; recs[r].nkeys = nkeys;
+    }
+    orc_msite *sites = NULL; int32_t *nsites = NULL;
+    if (sites1) { sites = (orc_msite *)malloc(sizeof(orc_msite) * (size_t)nr * (size_t)cap); nsites = (int32_t *)malloc(sizeof(int32_t) * (size_t)nr); }
+    const double t = orc_map_reads(ix, P, recs, nr, paired, bases, NULL, keyinfo, cap, sites, nsites, log, logcap, nlog, match, matchStride, threads, stats4);
+    if (sites) {
+        for (int64_t r = 0; r < nr; r++) {
+            orc_msite *dst = paired ? ((r & 1) ? sites2 : sites1) + (r / 2) * cap : sites1 + r * cap;
+            int32_t *nd = paired ? ((r & 1) ? nsites2 : nsites1) + (r / 2) : nsites1 + r;
+            *nd = nsites[r];
+            if (nsites[r] > 0) memcpy(dst, sites + r * cap, sizeof(orc_msite) * (size_t)nsites[r]);
+        }
+    }
+    free(sites); free(nsites); free(recs); free(bases); free(keyinfo);
+    return t;
 }

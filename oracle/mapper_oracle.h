@@ -51,7 +51,17 @@ typedef struct orc_mjob {          /* one MSA.fillAndScoreLimited call */
     int64_t iterations;
 } orc_mjob;                        /* 88 bytes */
 
+/* one read of a batch: the layout of bbidx_read (include/bbmap_amd.h) */
+typedef struct orc_read { int64_t bases_off, keys_off; int32_t len, nkeys; } orc_read;     /* 24 bytes */
+
 void orc_map_default_params(orc_map_params *P);
+/* with -DORC_PACBIO the same source follows align2.BBMapThreadPacBio / BBMapPacBio.setDefaults (current/align2/BBMapPacBio.java:47-69):
+ * processRead, scoreSlow and trimList of the two classes differ in nothing the path up to the end of scoreSlow reads (a diff shows
+ * clearzone ratios of the later ambiguity policy, ALIGN_ROWS 6020 and ALIGN_COLUMNS 7600) */
+double orc_map_reads(const orc_index *ix, const orc_map_params *P, const orc_read *recs, int64_t n_reads, int paired,
+                     const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo, int cap,
+                     orc_msite *sites, int32_t *nsites,
+                     orc_mjob *log, int64_t logcap, int64_t *nlog, uint8_t *match, int matchStride, int threads, int64_t *stats4);
 float orc_ratio_paired(float R);
 float orc_ratio_pre_rescue(float R);
 double orc_map_batch(const orc_index *ix, const orc_map_params *P, const uint8_t *reads1, const uint8_t *reads2, int64_t n, int L,

@@ -767,7 +767,11 @@ int orc_calc_affine_score(const int32_t *locArray, int n, const int8_t *baseScor
                 timeInMode = 1;
             } else {
                 maxContig = imax(maxContig, contig); contig = 0;
+#ifdef ORC_PACBIO   /* MultiStateAligner9PacBio.java:1727-1742: dif = min(loc-lastLoc+1, 5), tier formula (= the cumulative table for dif <= 5) */
+                score += PTS_MATCH + baseScores[i] + T_INS_C[imin(loc - lastLoc + 1, 5)];
+#else
                 score += PTS_MATCH + baseScores[i] + T_INS_C[imin(loc - lastLoc, 5)];
+#endif
                 timeInMode = 1;
             }
             lastLoc = loc;

@@ -51,7 +51,8 @@ _LIB_PB = None
 
 
 def lib_pacbio():
-    """The DP restatement compiled with the MultiStateAligner9PacBio constants (fills, traceback2, score2 only)."""
+    """The same restatements compiled with mapPacBio's classes' constants (-DORC_PACBIO): MultiStateAligner9PacBio, BBIndexPacBio,
+    BBMapThreadPacBio / BBMapPacBio.setDefaults."""
     global _LIB_PB
     if _LIB_PB is None:
         _LIB_PB = _declare_msa(C.CDLL(build(pacbio=True)))
@@ -249,8 +250,15 @@ def small_genome_tuning(ix_struct, defined_bases):
             p.hitReductionDiv = max(p.hitReductionDiv - 1, 3)
 
 
-def fraction_to_exclude(defined_bases):
-    f = np.float32(0.03)
+def _lib_for(profile):
+    assert profile in ("bbmap", "pacbio")
+    return lib_pacbio() if profile == "pacbio" else lib()
+
+
+def fraction_to_exclude(defined_bases, profile="bbmap"):
+    # FRACTION_GENOME_TO_EXCLUDE: BBIndex.java:3214 (0.03), BBIndexPacBio.java:2509 (0.005); scaled as BBMap.java:367-381 /
+    # BBMapPacBio.java:351-365 do
+    f = np.float32(0.005 if profile == "pacbio" else 0.03)
     if defined_bases < 30000000:
         return float(f * np.float32(0.5))
     if defined_bases < 100000000:
@@ -263,8 +271,11 @@ def fraction_to_exclude(defined_bases):
 class OracleIndex:
     """Index + probe of the CPU oracle.  chroms: list of bytes-like (chromosome 1..n), already padded with N."""
 
-    def __init__(self, chroms, k=13, chromBits=None):
-        self.L = lib()
+    def __init__(self, chroms, k=None, chromBits=None, profile="bbmap"):
+        self.L = _lib_for(profile)
+        self.profile = profile
+        if k is None:
+            k = 12 if profile == "pacbio" else 13                           # BBMapPacBio.java:51 / BBMap.java:48
         self.chroms = [np.frombuffer(bytes(c), np.uint8).copy() for c in chroms]
         n = len(self.chroms)
         maxlen = max(len(c) for c in self.chroms)
@@ -280,7 +291,7 @@ class OracleIndex:
         self.defined_bases = defined
         self.L.orc_index_build.restype = C.c_void_p
         self.L.orc_index_build.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(c_u8p), c_i32p, C.c_float]
-        self.h = self.L.orc_index_build(k, chromBits, n, arr, lens, fraction_to_exclude(defined))
+        self.h = self.L.orc_index_build(k, chromBits, n, arr, lens, fraction_to_exclude(defined, profile))
         self.s = IndexStruct.from_address(self.h)
         small_genome_tuning(self.s, defined)
         self._keep = (arr, lens)
@@ -328,9 +339,10 @@ class OracleIndexView(OracleIndex):
     that build equal to the oracle's own, array by array).  Keeps bench.py's CPU leg and parity sample affordable on a
     3 Gbp reference, where the oracle's single-threaded index build would take longer than the whole benchmark."""
 
-    def __init__(self, chroms, k, chromBits, params, blocks):
+    def __init__(self, chroms, k, chromBits, params, blocks, profile="bbmap"):
         """blocks: list of (starts, sites, counts, lengthHistogram) per block (counts / histogram taken from block 0)."""
-        self.L = lib()
+        self.L = _lib_for(profile)
+        self.profile = profile
         self.chroms = [np.ascontiguousarray(c, np.uint8) for c in chroms]
         self.k, self.chromBits = k, chromBits
         n, nb = len(self.chroms), len(blocks)
@@ -416,9 +428,9 @@ class MapParams(C.Structure):
         "clearzone3", "msaMaxRows", "msaMaxColumns")]
 
 
-def map_default_params(**kw):
+def map_default_params(profile="bbmap", **kw):
     p = MapParams()
-    lib().orc_map_default_params(C.byref(p))
+    _lib_for(profile).orc_map_default_params(C.byref(p))
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -428,8 +440,8 @@ def map_batch(oi, reads1, reads2, L, offsets, key_scores, params=None, cap=64, w
     """The mapper control flow (BBMapThread.processRead / processReadPair up to the end of rescue) on the CPU oracle.
     reads1/reads2: uint8 arrays of n*L bases (reads2 None = single-ended).  Returns a dict: sites1/nsites1 (and 2), the job
     log (one record per fillAndScoreLimited call, with its traceback string), stats, seconds."""
-    L_ = lib()
-    p = params or map_default_params()
+    L_ = oi.L
+    p = params or map_default_params(getattr(oi, "profile", "bbmap"))
     r1 = np.ascontiguousarray(reads1, np.uint8)
     n = r1.size // L
     r2 = None if reads2 is None else np.ascontiguousarray(reads2, np.uint8)
@@ -457,4 +469,42 @@ def map_batch(oi, reads1, reads2, L, offsets, key_scores, params=None, cap=64, w
     if want_log and nlog.value > logcap:
         raise RuntimeError("job log overflow")
     return dict(sites1=s1, nsites1=n1, sites2=s2, nsites2=n2, log=log[:nlog.value] if want_log else None,
+                match=match[:nlog.value] if want_log else None, stats=stats.tolist(), seconds=t)
+
+
+READ_DTYPE = np.dtype([("bases_off", "<i8"), ("keys_off", "<i8"), ("len", "<i4"), ("nkeys", "<i4")])     # orc_read = bbidx_read
+
+
+def map_reads(oi, recs, bases, keyinfo, base_scores=None, paired=False, params=None, cap=64, want_log=True, threads=1,
+              match_stride=0, jobs_per_read=8):
+    """The general form of map_batch: per-read records (READ_DTYPE: where a read's bases / base scores and its keys are, its
+    length and key count; keyinfo holds offsets[nkeys] then keyScores[nkeys] per read), as bbmap_map_batch_device takes them.
+    Returns a dict: sites (n x cap), nsites, log, match, stats, seconds."""
+    L_ = oi.L
+    p = params or map_default_params(getattr(oi, "profile", "bbmap"))
+    rc = np.ascontiguousarray(recs, READ_DTYPE)
+    n = rc.size
+    b = np.ascontiguousarray(bases, np.uint8)
+    ki = np.ascontiguousarray(keyinfo, np.int32)
+    bs = None if base_scores is None else np.ascontiguousarray(base_scores, np.int8)
+    sites = np.zeros((n, cap), MSITE_DTYPE)
+    ns = np.zeros(n, np.int32)
+    logcap = (n * jobs_per_read + 64) if want_log else 0
+    log = np.zeros(max(1, logcap), MJOB_DTYPE)
+    stride = match_stride or (p.msaMaxRows + p.msaMaxColumns + 64 if p.msaMaxRows > 1000 else p.msaMaxRows + 700)
+    match = np.zeros((max(1, logcap), stride), np.uint8) if want_log else None
+    nlog = C.c_int64(0)
+    stats = np.zeros(4, np.int64)
+    L_.orc_map_reads.restype = C.c_double
+    L_.orc_map_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    t = L_.orc_map_reads(C.c_void_p(oi.h), C.byref(p), rc.ctypes.data, n, 1 if paired else 0, b.ctypes.data,
+                         None if bs is None else bs.ctypes.data, ki.ctypes.data, cap, sites.ctypes.data, ns.ctypes.data,
+                         log.ctypes.data if want_log else None, logcap, C.addressof(nlog),
+                         match.ctypes.data if want_log else None, stride, threads, stats.ctypes.data)
+    if t < 0:
+        raise ValueError("orc_map_reads: bad argument (read longer than the MSA's rows, or mates of different length)")
+    if want_log and nlog.value > logcap:
+        raise RuntimeError("job log overflow")
+    return dict(sites=sites, nsites=ns, log=log[:nlog.value] if want_log else None,
                 match=match[:nlog.value] if want_log else None, stats=stats.tolist(), seconds=t)
