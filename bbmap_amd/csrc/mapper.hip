@@ -40,7 +40,6 @@ typedef bbmap_msite Site;
 constexpr int GAPBUFFER2 = 128, GAPLEN = 128, MINGAP = 256;                       // Shared.java:21-26
 constexpr int TIP_MAX_TIPLEN = 8, OUTER_DIST_MULT = 14, OUTER_DIST_DIV = 32;      // AbstractMapThread.java:2987-2993
 constexpr int MIN_TRIM_SINGLE = 3, MIN_TRIM_PAIRED = 2;                           // BBMapThread.java:62-63
-constexpr int CLEARZONE1E = 258;                                                  // AbstractMapThread.java:142: 2*100-70+127+1
 constexpr int GAPPED_BIT = 1 << 30;
 constexpr int DEAD_MARK = 0x7fffffff;
 
@@ -48,6 +47,11 @@ struct Settings {
     float minRatio, ratioPaired, ratioPreRescue;
     int slowAlignPadding, slowRescuePadding, extraPadding, tipSearchDist, maxPairDist, averagePairDist, maxRescueDist,
         maxRescueMismatches, maxTrimSitesToRetain, trimList, doRescue, alignColumns, clearzone3, maxIndel, expLimit, paired;
+    // the aligner class's points (MultiStateAligner11ts: jni/MultiStateAligner11tsJNI.c:18-98; MultiStateAligner9PacBio:
+    // current/align2/MultiStateAligner9PacBio.java:2375-2407): POINTS_MATCH, POINTS_MATCH2, POINTS_SUB / SUB2 / SUB3,
+    // min(POINTS_DEL, POINTS_INS - POINTS_MATCH2) of maxImperfectScore, and CLEARZONE1e = 2*MATCH2 - MATCH - SUB + 1
+    // (AbstractMapThread.java:142)
+    int ptsMatch, ptsMatch2, ptsSub, ptsSub2, ptsSub3, impDelta, clearzone1e;
 };
 
 struct SlowState {      // scoreSlow's loop state of one read
@@ -97,8 +101,8 @@ struct Dev {
 __device__ inline int imin(int a, int b) { return a < b ? a : b; }
 __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 __device__ inline int iabsdif(int a, int b) { return a > b ? a - b : b - a; }
-__device__ inline int max_quality(int len) { return 70 + (len - 1) * 100; }                  // MSA.maxQuality
-__device__ inline int max_imperfect(int len) { return max_quality(len) - 495; }              // maxImperfectScore: min(DEL, INS - MATCH2)... = -495
+__device__ inline int max_quality(const Settings &S, int len) { return S.ptsMatch + (len - 1) * S.ptsMatch2; }      // MSA.maxQuality
+__device__ inline int max_imperfect(const Settings &S, int len) { return max_quality(S, len) + S.impDelta; }      // maxImperfectScore
 
 // ---------------------------------------------------------------------------------------------- SiteScore / GapTools
 __device__ void fix_gaps2(Site &ss) {                                                        // GapTools.fixGaps2 :127-175
@@ -178,8 +182,9 @@ struct Words {
         return x;
     }
 };
-// MSA.scoreNoIndels(read, ref, refStart) (MultiStateAligner11tsJNI.java:1034-1089)
-__device__ int score_no_indels(const uint8_t *read, int len, const uint8_t *ref, int reflen, int refStart) {
+// MSA.scoreNoIndels(read, ref, refStart) (MultiStateAligner11tsJNI.java:1034-1089; MultiStateAligner9PacBio.java:1876-1937 is the
+// same statement with its own points)
+__device__ int score_no_indels(const Settings &S, const uint8_t *read, int len, const uint8_t *ref, int reflen, int refStart) {
     int readStart = 0, readStop = len;
     if (refStart < 0) readStart = -refStart;
     if (refStart + len > reflen) readStop -= (refStart + len - reflen);
@@ -194,10 +199,10 @@ __device__ int score_no_indels(const uint8_t *read, int len, const uint8_t *ref,
         for (int q = 0; q < 4; q++) {
             if (i + q < n) {
                 const int c = (int)((c4 >> (8 * q)) & 255u), r = (int)((r4 >> (8 * q)) & 255u);
-                if (c == r && c != 'N') { if (mode == 0) { t++; score += 100; } else { t = 0; score += 70; } mode = 0; }
+                if (c == r && c != 'N') { if (mode == 0) { t++; score += S.ptsMatch2; } else { t = 0; score += S.ptsMatch; } mode = 0; }
                 else if (c >= 128 || c == 'N') { }
                 else if (r >= 128 || r == 'N') { }
-                else { if (mode == 1) t++; else t = 0; score += (t + 1 > 5 ? -25 : (t + 1 > 1 ? -51 : -127)); mode = 1; }
+                else { if (mode == 1) t++; else t = 0; score += (t + 1 > 5 ? S.ptsSub3 : (t + 1 > 1 ? S.ptsSub2 : S.ptsSub)); mode = 1; }
             }
         }
     }
@@ -531,8 +536,8 @@ __global__ __launch_bounds__(128) void begin_kernel(const Dev D) {
         if (D.S.trimList) {
             if (n1 > MIN_TRIM_PAIRED) sort_sites<false>(s1, n1);
             if (n2 > MIN_TRIM_PAIRED) sort_sites<false>(s2, n2);
-            trim_list(s1, n1, true, max_quality(len1), false, MIN_TRIM_PAIRED, D.S.maxTrimSitesToRetain);
-            trim_list(s2, n2, true, max_quality(len2), false, MIN_TRIM_PAIRED, D.S.maxTrimSitesToRetain);
+            trim_list(s1, n1, true, max_quality(D.S, len1), false, MIN_TRIM_PAIRED, D.S.maxTrimSitesToRetain);
+            trim_list(s2, n2, true, max_quality(D.S, len2), false, MIN_TRIM_PAIRED, D.S.maxTrimSitesToRetain);
         }
         for (int i = 0; i < n1; i++) s1[i].score = s1[i].quickScore;
         for (int i = 0; i < n2; i++) s2[i].score = s2[i].quickScore;
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(128) void begin_kernel(const Dev D) {
         if (n < 0) { atomicAdd(&D.counters[3], 1u); D.mcount[u] = -1; return; }
         if (D.S.trimList && n > 1) {
             sort_sites<false>(s, n);
-            trim_list(s, n, false, max_quality(D.reads[u].len), true, MIN_TRIM_SINGLE, D.S.maxTrimSitesToRetain);
+            trim_list(s, n, false, max_quality(D.S, D.reads[u].len), true, MIN_TRIM_SINGLE, D.S.maxTrimSitesToRetain);
         }
         D.mcount[u] = n;
         if (n == 0) atomicAdd(&D.counters[5], 1u);
@@ -563,7 +568,7 @@ __global__ __launch_bounds__(128) void score_kernel(const Dev D) {
     const int n = D.mcount[r];
     if (n <= 0) { D.slow[r] = st; return; }
     const bbidx_read rr = D.reads[r];
-    const int len = rr.len, maxSw = max_quality(len), maxImp = max_imperfect(len);
+    const int len = rr.len, maxSw = max_quality(D.S, len), maxImp = max_imperfect(D.S, len);
     Site *s = D.ms + r * D.cap;
     int near = 0; bool force = false;
     for (int j = 0; j < n; j++) {
@@ -573,9 +578,9 @@ __global__ __launch_bounds__(128) void score_kernel(const Dev D) {
         if (ss.perfect) { near++; set_slow_score(ss, maxSw); ss.score = maxSw; ss.ngaps = 0; }
         else {
             const uint8_t *ref = D.chromArr[ss.chrom]; const int reflen = D.chromArrLen[ss.chrom];
-            int sw = score_no_indels(bases, len, ref, reflen, ss.start);
+            int sw = score_no_indels(D.S, bases, len, ref, reflen, ss.start);
             if (sw < oldScore && oldScore >= maxImp && ss.stop - ss.start + 1 != len) {            // :806-813
-                const int sw2 = score_no_indels(bases, len, ref, reflen, ss.stop - len + 1);
+                const int sw2 = score_no_indels(D.S, bases, len, ref, reflen, ss.stop - len + 1);
                 if (sw2 >= maxImp) { sw = sw2; set_start(ss, ss.stop - len + 1); set_perfect(ss, bases, len, ref, reflen); }
             }
             set_slow_score(ss, sw); ss.score = sw;
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(128) void score_kernel(const Dev D) {
                 const uint8_t *ref = D.chromArr[ss.chrom]; const int reflen = D.chromArrLen[ss.chrom];
                 if (find_tip_deletions(D.S, ss, bases, len, ref, reflen, maxImp, true, true)) {
                     ss.match_job = -1;
-                    set_slow_score(ss, score_no_indels(bases, len, ref, reflen, ss.start));
+                    set_slow_score(ss, score_no_indels(D.S, bases, len, ref, reflen, ss.start));
                     if (ss.slowScore == maxSw) { set_stop(ss, ss.start + len - 1); ss.perfect = ss.semiperfect = 1; }
                     else { ss.perfect = 0; set_perfect(ss, bases, len, ref, reflen); }
                     s[j] = ss;
@@ -609,7 +614,7 @@ __global__ __launch_bounds__(128) void score_kernel(const Dev D) {
     D.nearArr[r] = numNear;
     if (D.S.paired || numNear < 1) {                       // single-ended: scoreSlow only without a near-perfect site (:466)
         st.phase = 0;
-        st.minMsaLimit = -CLEARZONE1E + (int)__fmul_rn(D.S.paired ? D.S.ratioPreRescue : D.S.minRatio, (float)maxSw);
+        st.minMsaLimit = -D.S.clearzone1e + (int)__fmul_rn(D.S.paired ? D.S.ratioPreRescue : D.S.minRatio, (float)maxSw);
     }
     D.slow[r] = st;
 }
@@ -668,7 +673,7 @@ __device__ void finish_site(const Dev &D, SlowState &st, Site &ss, int job, cons
 __device__ inline int prepare_site(const Settings &S, Site &ss, int len, int &expectedLen, bool &needsFill) {
     if (ss.stop - ss.start != len - 1) { set_slow_score(ss, 0); ss.semiperfect = 0; ss.perfect = 0; }
     const int sw = ss.slowScore;
-    needsFill = sw < max_imperfect(len) && !ss.semiperfect;
+    needsFill = sw < max_imperfect(S, len) && !ss.semiperfect;
     expectedLen = 0;
     if (needsFill) {
         expectedLen = calc_gref_len(ss);
@@ -699,7 +704,7 @@ __global__ __launch_bounds__(128) void slow_round_kernel(const Dev D) {
         SlowState st = D.slow[r];
         if (st.phase != 3) {
             const bbidx_read rr = D.reads[r];
-            const int len = rr.len, maxSw = max_quality(len);
+            const int len = rr.len, maxSw = max_quality(D.S, len);
             const int n = D.mcount[r];
             Site *s = D.ms + r * D.cap;
             while (st.idx < n) {
@@ -813,11 +818,11 @@ __global__ __launch_bounds__(128) void rescue_plan_kernel(const Dev D) {
     pr.ran = 1;
     const int lenA = D.reads[ra].len, L = D.reads[rl].len;
     sort_sites<false>(sa, na);
-    na = remove_low_quality_paired(sa, na, max_quality(lenA), D.S.ratioPreRescue, D.S.ratioPreRescue);
+    na = remove_low_quality_paired(sa, na, max_quality(D.S, lenA), D.S.ratioPreRescue, D.S.ratioPreRescue);
     D.mcount[ra] = na;
     const int searchDist = imin(D.S.maxPairDist, 2 * D.S.averagePairDist + 100);
     if (searchDist > D.S.maxRescueDist || na == 0) { D.pres[p] = pr; return; }
-    const int maxLooseSw = max_quality(L), maxAnchorSw = max_quality(lenA), maxImp = max_imperfect(L);
+    const int maxLooseSw = max_quality(D.S, L), maxAnchorSw = max_quality(D.S, lenA), maxImp = max_imperfect(D.S, L);
     const int bestLoose = nl == 0 ? 0 : sl[0].slowScore, bestAnchor = sa[0].slowScore;
     if (bestLoose == maxLooseSw && bestAnchor == maxAnchorSw && sa[0].pairedScore > 0) { D.pres[p] = pr; return; }
     const int rescueScoreLimit = (int)__fmul_rn(0.95f, (float)bestAnchor);
@@ -864,7 +869,7 @@ __global__ __launch_bounds__(128) void rescue_prep_kernel(const Dev D) {
     if (pr.count == 0 || (long long)pr.first + pr.count > D.rescCap) return;
     const long long rl = 2 * p + (1 - D.pass);
     const bbidx_read rrl = D.reads[rl];
-    const int L = rrl.len, maxImp = max_imperfect(L), maxScore = max_quality(L);
+    const int L = rrl.len, maxImp = max_imperfect(D.S, L), maxScore = max_quality(D.S, L);
     int seq = D.slow[rl].seq;
     for (int k = 0; k < pr.count; k++) {
         const long long q = pr.first + k;
@@ -883,11 +888,11 @@ __global__ __launch_bounds__(128) void rescue_prep_kernel(const Dev D) {
         if (res.found == 1 && ss.start >= 0 && ss.stop <= reflen - 1 && res.mismatches <= pr.maxMismatches) {
             const uint8_t *bases = D.bases + rj.read_off;
             const uint8_t *ref = D.chromArr[rj.chrom];
-            int sw = score_no_indels(bases, L, ref, reflen, ss.start);
+            int sw = score_no_indels(D.S, bases, L, ref, reflen, ss.start);
             if (sw < maxImp && D.S.maxIndel > 0) {
                 set_slow_score(ss, sw);
-                if (pr.findTip && find_tip_deletions(D.S, ss, bases, L, ref, reflen, maxImp, true, true)) sw = score_no_indels(bases, L, ref, reflen, ss.start);
-                const int minMsaLimit = -CLEARZONE1E + (int)__fmul_rn(D.S.ratioPaired, (float)maxScore);
+                if (pr.findTip && find_tip_deletions(D.S, ss, bases, L, ref, reflen, maxImp, true, true)) sw = score_no_indels(D.S, bases, L, ref, reflen, ss.start);
+                const int minMsaLimit = -D.S.clearzone1e + (int)__fmul_rn(D.S.ratioPaired, (float)maxScore);
                 ri.job = emit_fill(D, rl, rrl, ss, -1, D.S.slowRescuePadding, imax(sw, minMsaLimit), 2, seq++);
                 atomicAdd(&D.counters[7], 1u);
                 ss.reserved[0] = 2; ss.reserved[1] = sw;
@@ -914,7 +919,7 @@ __global__ __launch_bounds__(128) void rescue_finish_kernel(const Dev D) {
     int nl = D.mcount[rl];
     const int nsearch = ((long long)pr.first + pr.count > D.rescCap) ? 0 : pr.count;
     const bbidx_read rrl = D.reads[rl];
-    const int L = rrl.len, maxScore = max_quality(L);
+    const int L = rrl.len, maxScore = max_quality(D.S, L);
     bool overflow = false;
     for (int k = 0; k < nsearch; k++) {
         const long long q = pr.first + k;
@@ -1037,16 +1042,23 @@ static thread_local char g_merr[320];
 #define MTRY(expr) do { const int rc_ = (expr); if (rc_ != BBMAP_OK) return rc_; } while (0)
 static int mfail(int code, const char *msg) { bbmap_set_error(msg); return code; }
 
-extern "C" int bbmap_default_config(bbmap_config *c) {
-    if (!c) return mfail(BBMAP_E_ARG, "bbmap_default_config: null argument");
+extern "C" int bbmap_default_config_profile(int32_t profile, bbmap_config *c) {
+    if (!c || (profile != BBIDX_PROFILE_BBMAP && profile != BBIDX_PROFILE_PACBIO)) return mfail(BBMAP_E_ARG, "bbmap_default_config: bad argument");
     memset(c, 0, sizeof *c);
-    c->paired = 0; c->max_reads = 0; c->max_read_len = 150; c->max_sites = 32;
-    c->minRatio = 0.56f; c->slowAlignPadding = 4; c->slowRescuePadding = 8; c->extraPadding = 10; c->tipSearchDist = 100;
-    c->maxPairDist = 32000; c->averagePairDist = 100; c->maxRescueDist = 1200; c->maxRescueMismatches = 32;
-    c->maxTrimSitesToRetain = 800; c->trimList = 1; c->doRescue = 1; c->alignColumns = 3000; c->clearzone3 = 800;
-    c->msaMaxColumns = 3000; c->fastCols = 0; c->jobsPerRead = 0;
+    c->paired = 0; c->max_reads = 0; c->max_sites = 32;
+    c->extraPadding = 10; c->maxPairDist = 32000; c->averagePairDist = 100; c->maxRescueDist = 1200; c->maxRescueMismatches = 32;
+    c->maxTrimSitesToRetain = 800; c->trimList = 1; c->doRescue = 1; c->clearzone3 = 800; c->fastCols = 0; c->jobsPerRead = 0;
+    if (profile == BBIDX_PROFILE_PACBIO) {      // BBMapPacBio.setDefaults (BBMapPacBio.java:47-69), BBMapThreadPacBio.java:27-28
+        c->max_read_len = 6016; c->minRatio = 0.46f; c->slowAlignPadding = 8; c->slowRescuePadding = 16; c->tipSearchDist = 15;
+        c->alignColumns = 7600; c->msaMaxColumns = 7600;
+    } else {                                    // BBMap.setDefaults (BBMap.java:45-65), BBMapThread.java:27-28
+        c->max_read_len = 150; c->minRatio = 0.56f; c->slowAlignPadding = 4; c->slowRescuePadding = 8; c->tipSearchDist = 100;
+        c->alignColumns = 3000; c->msaMaxColumns = 3000;
+    }
+    c->reserved[3] = profile;
     return BBMAP_OK;
 }
+extern "C" int bbmap_default_config(bbmap_config *c) { return bbmap_default_config_profile(BBIDX_PROFILE_BBMAP, c); }
 
 template <class T> static int dalloc(bbmap_ctx *c, T **p, size_t count) {
     void *d = nullptr;
@@ -1069,8 +1081,8 @@ extern "C" void bbmap_destroy(bbmap_ctx *c) {
     if (c->dpStream) (void)hipStreamDestroy(c->dpStream);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
     if (c->evJoin) (void)hipEventDestroy(c->evJoin);
+    if (c->ownsMsa && c->msaGapped && c->msaGapped != c->msa) bbmsa_destroy(c->msaGapped);
     if (c->ownsMsa && c->msa) bbmsa_destroy(c->msa);
-    if (c->ownsMsa && c->msaGapped) bbmsa_destroy(c->msaGapped);
     for (int i = 0; i < 12; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
@@ -1090,10 +1102,15 @@ extern "C" int bbidx_get_chrom_table(bbidx_ctx *ix, int32_t *nchroms, const uint
 static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *parent, bbmap_ctx **out) {
     if (!index || !cfg || !out) return mfail(BBMAP_E_ARG, "bbmap_create: null argument");
     *out = nullptr;
-    if (cfg->max_reads < 1 || cfg->max_read_len < 1 || cfg->max_read_len > 600) return mfail(BBMAP_E_ARG, "bbmap_create: max_reads >= 1 and max_read_len in 1..600");
+    const int profile = cfg->reserved[3];
+    if (profile != BBIDX_PROFILE_BBMAP && profile != BBIDX_PROFILE_PACBIO) return mfail(BBMAP_E_ARG, "bbmap_create: unknown profile (bbmap_config.reserved[3])");
+    if (profile != index->dev.p.profile) return mfail(BBMAP_E_ARG, "bbmap_create: the index was built for the other profile (BBIDX_PROFILE_*)");
+    const bool pacbio = profile == BBIDX_PROFILE_PACBIO;
+    if (cfg->max_reads < 1 || cfg->max_read_len < 1 || cfg->max_read_len > (pacbio ? BBIDX_PACBIO_MAX_READ_LEN : 600))
+        return mfail(BBMAP_E_ARG, "bbmap_create: max_reads >= 1 and max_read_len in 1..600 (1..6016 for BBIDX_PROFILE_PACBIO)");
     if (cfg->max_sites < 1 || cfg->max_sites > BBMAP_MAX_SITES_LIMIT) return mfail(BBMAP_E_ARG, "bbmap_create: max_sites must be 1..4096");
     if (cfg->paired && (cfg->max_reads & 1)) return mfail(BBMAP_E_ARG, "bbmap_create: paired mode takes an even number of reads");
-    if (cfg->msaMaxColumns < 64 || cfg->msaMaxColumns > 4096) return mfail(BBMAP_E_ARG, "bbmap_create: msaMaxColumns must be 64..4096");
+    if (cfg->msaMaxColumns < 64 || cfg->msaMaxColumns > (pacbio ? 8192 : 4096)) return mfail(BBMAP_E_ARG, "bbmap_create: msaMaxColumns must be 64..4096 (..8192 for BBIDX_PROFILE_PACBIO)");
     if (cfg->device != index->device) return mfail(BBMAP_E_ARG, "bbmap_create: the index lives on another device");
     MHIP(hipSetDevice(cfg->device));
     bbmap_ctx *c = new (std::nothrow) bbmap_ctx();
@@ -1112,6 +1129,9 @@ static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *par
     S.maxRescueDist = cfg->maxRescueDist; S.maxRescueMismatches = cfg->maxRescueMismatches; S.maxTrimSitesToRetain = cfg->maxTrimSitesToRetain;
     S.trimList = cfg->trimList; S.doRescue = cfg->doRescue; S.alignColumns = cfg->alignColumns; S.clearzone3 = cfg->clearzone3;
     S.maxIndel = index->dev.p.maxIndel; S.paired = cfg->paired;
+    if (pacbio) { S.ptsMatch = 90; S.ptsMatch2 = 100; S.ptsSub = -137; S.ptsSub2 = -49; S.ptsSub3 = -25; S.impDelta = -305; }   // min(-292, -205 - 100)
+    else { S.ptsMatch = 70; S.ptsMatch2 = 100; S.ptsSub = -127; S.ptsSub2 = -51; S.ptsSub3 = -25; S.impDelta = -495; }          // min(-472, -395 - 100)
+    S.clearzone1e = 2 * S.ptsMatch2 - S.ptsMatch - S.ptsSub + 1;
     // BBMap.java:434: `if(paired){BBIndex.QUIT_AFTER_TWO_PERFECTS=false;}` -- a static of the index class in the reference, so the
     // borrowed index context is switched the same way (and back for a single-ended mapper)
     index->dev.p.quitAfterTwoPerfects = cfg->paired ? 0 : 1;
@@ -1124,16 +1144,35 @@ static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *par
     // buffers are sized for `fastCols` columns, which is what lets four blocks share a CU.  The second has the reference's own
     // 3000 columns (BBMapThread.java:27-28) and takes what does not fit the first: gapped references and wide windows.
     mc.device = cfg->device; mc.maxRows = maxRows;
-    mc.maxColumns = cfg->fastCols > 0 ? cfg->fastCols : 256;
-    if (mc.maxColumns > cfg->msaMaxColumns) mc.maxColumns = cfg->msaMaxColumns;
-    c->plainColumns = mc.maxColumns;
-    bbmsa_config gc = mc;
-    gc.maxColumns = cfg->msaMaxColumns;
-    gc.reserved[0] = 64; gc.reserved[1] = 640 < gc.maxColumns ? 640 : gc.maxColumns;
-    (void)parent;                   // the tier runs beside its parent's pass: DP contexts of its own
-    c->ownsMsa = true;
-    if ((rc = bbmsa_create(&mc, &c->msa)) != BBMAP_OK) return bail(rc);
-    if ((rc = bbmsa_create(&gc, &c->msaGapped)) != BBMAP_OK) return bail(rc);
+    bbmsa_config gc;
+    if (pacbio) {
+        // mapPacBio: ONE context with the MultiStateAligner9PacBio scheme (strip-tiled wavefront kernel, msa_fill_strip.hip) and the
+        // reference's 7600 columns for every fill, with or without a gap array; its traceback records and scratch matrices take tens
+        // of GB, so the overflow tier borrows its parent's context and runs after the main pass instead of beside it
+        mc.maxRows = cfg->max_read_len + 4 > 6100 ? 6100 : cfg->max_read_len + 4;
+        c->maxRows = mc.maxRows;
+        mc.maxColumns = cfg->msaMaxColumns;
+        mc.reserved[2] = BBMSA_SCHEME_9PACBIO;
+        gc = mc;
+        c->plainColumns = mc.maxColumns;
+        if (parent) { c->msa = parent->msa; c->msaGapped = parent->msaGapped; c->ownsMsa = false; }
+        else {
+            c->ownsMsa = true;
+            if ((rc = bbmsa_create(&mc, &c->msa)) != BBMAP_OK) return bail(rc);
+            c->msaGapped = c->msa;
+        }
+    } else {
+        mc.maxColumns = cfg->fastCols > 0 ? cfg->fastCols : 256;
+        if (mc.maxColumns > cfg->msaMaxColumns) mc.maxColumns = cfg->msaMaxColumns;
+        c->plainColumns = mc.maxColumns;
+        gc = mc;
+        gc.maxColumns = cfg->msaMaxColumns;
+        gc.reserved[0] = 64; gc.reserved[1] = 640 < gc.maxColumns ? 640 : gc.maxColumns;
+        (void)parent;                   // the tier runs beside its parent's pass: DP contexts of its own
+        c->ownsMsa = true;
+        if ((rc = bbmsa_create(&mc, &c->msa)) != BBMAP_OK) return bail(rc);
+        if ((rc = bbmsa_create(&gc, &c->msaGapped)) != BBMAP_OK) return bail(rc);
+    }
     const long long n = cfg->max_reads;
     const int cap = cfg->max_sites;
     const int jpr = cfg->jobsPerRead > 0 ? cfg->jobsPerRead : 3;
@@ -1170,7 +1209,7 @@ static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *par
     }
     if (hipHostMalloc((void **)&c->h_counters, 64 * 4) != hipSuccess) return bail(mfail(BBMAP_E_NOMEM, "bbmap_create: pinned allocation failed"));
     for (int i = 0; i < 12; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) return bail(mfail(BBMAP_E_HIP, "bbmap_create: hipEventCreate failed"));
-    if (!getenv("BBMAP_SERIAL_DP")) {
+    if (!getenv("BBMAP_SERIAL_DP") && !pacbio) {
         if (hipStreamCreateWithFlags(&c->dpStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess) return bail(mfail(BBMAP_E_HIP, "bbmap_create: stream / event creation failed"));
     }
@@ -1284,7 +1323,7 @@ static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const 
             float pms = 0; long long ps[5];       // (not for the tier's own pass: the synchronous copy inside would wait for the main stream)
             if (writeRc && bbidx_last_stats(c->index, (int64_t *)ps, &pms) == BBMAP_OK) for (int i = 0; i < 5; i++) c->stats.probe_stats[i] = ps[i];
             c->overAfterBegin = c->h_counters[3];
-            if (c->tier && c->h_counters[16] > 0) tier_start_async(c, c->h_counters[16]);
+            if (c->tier && c->h_counters[16] > 0 && c->tier->msa != c->msa) tier_start_async(c, c->h_counters[16]);     // (a tier that borrows the DP context runs after the pass)
         }
         add_dp_ms(c, ranPlainPrev, ranGappedPrev);
         const long long total = c->h_counters[0], gtotal = c->h_counters[1];
@@ -1321,7 +1360,7 @@ static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const 
             hipEvent_t q0 = c->ev[8], q1 = c->ev[9];
             MHIP(hipEventRecord(q0, stream));
             MTRY(bbpipe_quick_rescue_device(stream, nsearch, c->d_rjobs, bases, (const int64_t *)c->d_chromOff, c->d_chromArrLen, c->d_chromMin, c->refsBase,
-                                            c->d_rres, 70, 100, 1, 100));
+                                            c->d_rres, c->S.ptsMatch, c->S.ptsMatch2, 1, 100));
             MHIP(hipEventRecord(q1, stream));
             hipLaunchKernelGGL(bbmapper::rescue_prep_kernel, dim3((unsigned)((pairs + TB - 1) / TB)), dim3(TB), 0, stream, D);
             MHIP(hipGetLastError());

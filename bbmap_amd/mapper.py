@@ -51,6 +51,8 @@ NSITES_OVERFLOW, NSITES_MATE_OVERFLOW, NSITES_IN_TIER = -1, -2, -3
 
 def _bind(L):
     L.bbmap_default_config.argtypes = [C.POINTER(bbmap_config)]
+    L.bbmap_default_config_profile.argtypes = [C.c_int32, C.POINTER(bbmap_config)]
+    L.bbmap_default_config_profile.restype = C.c_int
     L.bbmap_create.argtypes = [C.c_void_p, C.POINTER(bbmap_config), C.POINTER(C.c_void_p)]
     L.bbmap_destroy.argtypes = [C.c_void_p]
     L.bbmap_destroy.restype = None
@@ -104,6 +106,40 @@ class Mapper:
         recs["nkeys"] = len(offsets)
         self.reads = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(self.dev)
         self.keyinfo = torch.tensor(list(offsets) + list(key_scores), dtype=torch.int32, device=self.dev)
+
+    @classmethod
+    def from_records(cls, di, recs, bases, base_scores, keyinfo, paired=False, device=0, max_sites=32, profile=0, **cfg_kw):
+        """The general form: reads of any lengths with their own keys, as bbkeys_make_batch (bbmap_amd.keys.make_batch) lays them
+        out -- recs (READ_DTYPE), the bases blob, base scores at the same offsets, keyinfo.  profile: 0 = bbmap.sh's classes,
+        1 = mapPacBio.sh's (BBIDX_PROFILE_*; must be the index's)."""
+        self = cls.__new__(cls)
+        self.L = _lib.load()
+        _bind(self.L)
+        recs = np.ascontiguousarray(recs, READ_DTYPE)
+        n = len(recs)
+        self.di, self.n, self.paired = di, n, paired
+        self.read_len = int(recs["len"].max()) if n else 0
+        self.dev = torch.device("cuda", device)
+        if profile == 0:
+            di.set_max_read_len(max(1, self.read_len))
+        cfg = bbmap_config()
+        _lib.check(self.L.bbmap_default_config_profile(profile, C.byref(cfg)), "bbmap_default_config_profile")
+        cfg.device, cfg.paired, cfg.max_reads, cfg.max_read_len, cfg.max_sites = device, int(paired), n, max(1, self.read_len), max_sites
+        for k, v in cfg_kw.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        h = C.c_void_p()
+        _lib.check(self.L.bbmap_create(di.h, C.byref(cfg), C.byref(h)), "bbmap_create")
+        self.h = h
+        blob = np.ascontiguousarray(bases, np.uint8)
+        self.total_bytes = int(blob.size)
+        self.bases = torch.zeros(2 * self.total_bytes, dtype=torch.uint8, device=self.dev)
+        self.bases[: self.total_bytes].copy_(torch.from_numpy(blob))
+        self.base_scores = torch.from_numpy(np.ascontiguousarray(base_scores, np.int8)).to(self.dev)
+        assert self.base_scores.numel() >= self.total_bytes
+        self.reads = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()).to(self.dev)
+        self.keyinfo = torch.from_numpy(np.ascontiguousarray(keyinfo, np.int32)).to(self.dev)
+        return self
 
     def close(self):
         if getattr(self, "h", None):

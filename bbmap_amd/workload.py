@@ -202,3 +202,42 @@ def make_offsets(readlen, blocksize, density, min_keys=2):
         offs[1] = int(fsp)
         offs[middles] = int(np.ceil(np.float64(np.float32(fsp * np.float32(middles)))))
     return offs
+
+
+def make_pacbio_pieces(chroms, n, seed=5, min_len=6000, max_len=6000, err=(0.13, 0.17), pad=START_PAD, junk_frac=0.0):
+    """Pieces of PacBio-like reads as mapPacBio sees them (BASELINE.json configs[4]: 10 kb reads cut at fastareadlen = 6000,
+    current/align2/BBMapPacBio.java; error model pbmin 0.13 / pbmax 0.17, current/align2/RandomReads3.java:1714-1715, split into
+    deletions / substitutions / insertions 35 : 20 : 45): `n` pieces drawn from `chroms` (padded uint8 arrays), either strand.
+    Returns (list of uint8 arrays, truth array of (chrom 1-based, strand, start, stop))."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    comp = np.full(256, ord("N"), np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    pieces, truth = [], np.zeros((n, 4), np.int64)
+    for i in range(n):
+        ci = int(rng.integers(0, len(chroms)))
+        G = chroms[ci]
+        L = int(rng.integers(min_len, max_len + 1))
+        span = L + L // 4 + 64
+        s_ = int(rng.integers(pad + 100, len(G) - pad - span - 100))
+        e = rng.uniform(*err)
+        src = G[s_:s_ + span]
+        x = rng.random(len(src))
+        keep = x >= e * 0.35
+        sub = (x >= e * 0.35) & (x < e * 0.55)
+        piece = src.copy()
+        piece[sub] = BASES[rng.integers(0, 4, size=int(sub.sum()), dtype=np.uint8)]
+        consumed = np.cumsum(np.ones(len(src), np.int64))          # reference bases used up to each kept base
+        piece, consumed = piece[keep], consumed[keep]
+        ins_at = np.nonzero(rng.random(len(piece)) < e * 0.45)[0]
+        piece = np.insert(piece, ins_at, BASES[rng.integers(0, 4, size=len(ins_at), dtype=np.uint8)])
+        consumed = np.insert(consumed, ins_at, consumed[np.minimum(ins_at, len(consumed) - 1)])
+        piece, stop = piece[:L], s_ + int(consumed[min(L, len(consumed)) - 1]) - 1
+        if rng.random() < junk_frac:
+            piece = BASES[rng.integers(0, 4, size=L, dtype=np.uint8)]
+        strand = int(rng.integers(0, 2))
+        if strand:
+            piece = comp[piece[::-1]]
+        pieces.append(np.ascontiguousarray(piece))
+        truth[i] = (ci + 1, strand, s_, stop)
+    return pieces, truth

@@ -88,7 +88,9 @@ def compare(out, orc, n_reads, paired, reads_range=None, check_match=True):
                 bad.append("fill %r traceback string: device (%d) %r, oracle (%d) %r" % (k, a["match_len"], a["match"][:200], b["match_len"], b["match"][:200]))
     o_by_index = {v["index"]: k for k, v in of.items()}
     for r in rng:
-        if paired:
+        if "sites" in orc:                                  # oracle.map_reads: one list per read record, pairs interleaved
+            osites, on, oi = orc["sites"], orc["nsites"], r
+        elif paired:
             osites, on = (orc["sites1"], orc["nsites1"]) if r % 2 == 0 else (orc["sites2"], orc["nsites2"])
             oi = r // 2
         else:
