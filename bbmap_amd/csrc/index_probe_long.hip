@@ -63,19 +63,34 @@ struct ProfPacBio {     // BBIndexPacBio.java:2461-2596 ; MultiStateAligner9PacB
     static constexpr int INS_DIF_PLUS = 1;              // dif = min(loc - lastLoc + 1, 5), :1729
 };
 
+// debug build (-DBBIDXL_TIMERS): the five work counters become cycle counts (in units of 1024 cycles) of
+// {refillAll, popSite without its refills, quick scores, minHead + countWindow, everything else of the walk loops}
+#ifdef BBIDXL_TIMERS
+#define LT_BEGIN(u) const unsigned long long lt0_ = __builtin_readcyclecounter()
+#define LT_END(u, slot) (u).tm[slot] += __builtin_readcyclecounter() - lt0_
+#else
+#define LT_BEGIN(u) do { } while (0)
+#define LT_END(u, slot) do { } while (0)
+#endif
+
 struct LongParams {
     Params P;
     int *ws;                 // per-wave workspace, WS_ARRAYS * KMAX ints each
     int maxKeys, maxLen;     // what the launch's LDS / workspace hold (<= KMAX, <= LMAX)
 };
 
-// LDS of one wave
+constexpr int JM = KMAX / 64;               // lists per lane
+typedef int vJM __attribute__((ext_vector_type(32)));   // JM ints in registers; a uniform variable index is one indexed register move
+static_assert(JM == 32, "vJM holds JM values");
+
+// LDS of one wave (77 KB: two waves per CU)
 struct Lds {
     int loc[LMAX];
-    int val[KMAX];
-    int nb[NB][KMAX];
-    uint8_t cons[KMAX];      // entries of the look-ahead already consumed
-    uint8_t nbuf[KMAX];      // valid look-ahead entries | 0x80 when they reach the list's end
+    int val[KMAX];           // every list's current value (kept after it ran out): what the scoring functions index by column
+    int nb[NB][KMAX];        // look-ahead entries, already adjusted by the key's offset
+    uint8_t st[KMAX];        // bits 0-1 look-ahead entries consumed, bits 2-3 valid look-ahead entries, bit 7 they reach the list's end
+    short ksc[KMAX];         // the list's key score (<= 100 k) and offset (< 6016)
+    short off[KMAX];
     uint8_t base[2][LMAX + 8];
     int8_t bsc[LMAX + 8];
     int gaps[BBIDX_MAX_GAPS];
@@ -88,14 +103,20 @@ struct U {
     int k, baseKeyHitScore, indelPenalty, maxPenalty, scoreZ1Key;
     int lane, blen;
     unsigned cPrescan, cWalk, cExtend, cRefBytes;
+#ifdef BBIDXL_TIMERS
+    mutable unsigned long long tm[5];
+#endif
 };
 
-// the lists of one (block, strand) cycle
+// The lists of one (block, strand) cycle.  The heap stand-in works on registers: lane `lane` keeps the value, cursor and end of its
+// lists 64 j + lane in v[j] (every loop over j is fully unrolled, so the array never leaves the register file).
 struct Lists {
     int n, nlive;            // lists, lists still in the heap
     int J;                   // ceil(n / 64)
     unsigned live;           // bit j: list 64 j + lane is alive (per lane)
-    int *row, *stop, *offs, *ksc;       // workspace arrays [l]
+    int dmax;                // per lane: the largest value among its lists that ran out (INT_MIN: none)
+    vJM v;
+    int *rowW, *stopW;       // every list's cursor and end, in the per-wave workspace (read at refills only)
     GlobalIntsT sites;
 };
 
@@ -118,100 +139,104 @@ __device__ __forceinline__ int adjustSite(const U &u, int a, int offset, int bas
 }
 
 // ---------------------------------------------------------------------------------------------- heap stand-ins
-// heap.peek(): the smallest (site, column) among the live lists
-__device__ __forceinline__ void minHead(const U &u, const Lds &S, const Lists &L, int &site, int &center) {
-    int best = INT_MAX, bl = INT_MAX;
-    for (int j = 0; j < L.J; j++) {
-        const int l = j * 64 + u.lane;
-        const int v = ((L.live >> j) & 1u) ? S.val[l] : INT_MAX;
-        if (v < best) { best = v; bl = l; }
+// heap.peek(): the smallest (site, column) among the live lists.  Per lane also its smallest and second smallest live value, for
+// the window test below.  L.v[j] holds a live list's value, INT_MAX once the list ran out (its last value stays in S.val) and for
+// the columns past the last list, so the scan needs no liveness test; JT = the lists per lane rounded up to a multiple of 8.
+template <int JT> __device__ __forceinline__ void minHeadT(const U &u, const Lists &L, int &site, int &center, int &best, int &second) {
+    best = INT_MAX; second = INT_MAX; int bj = 0;
+#pragma unroll
+    for (int j = 0; j < JT; j++) {
+        const int x = L.v[j];
+        second = min(second, max(best, x));
+        bj = x < best ? j : bj;
+        best = min(best, x);
     }
     site = wmin(best);
-    center = wmin(best == site ? bl : INT_MAX);
+    center = wmin(best == site ? bj * 64 + u.lane : INT_MAX);
+}
+__device__ __forceinline__ void minHead(const U &u, const Lists &L, int &site, int &center, int &best, int &second) {
+    if (L.J <= 8) minHeadT<8>(u, L, site, center, best, second);
+    else if (L.J <= 16) minHeadT<16>(u, L, site, center, best, second);
+    else if (L.J <= 24) minHeadT<24>(u, L, site, center, best, second);
+    else minHeadT<32>(u, L, site, center, best, second);
 }
 // how many columns hold a value in [lo, hi] (the reference's `chances` early exit only cuts the count short when it stays below the
 // cutoff anyway), and the largest such value
-__device__ __forceinline__ int countWindow(const U &u, const Lds &S, const Lists &L, int lo, int hi, int site, int &maxNearby) {
+__device__ __forceinline__ int countWindowFull(const U &u, const Lds &S, const Lists &L, int lo, int hi, int site, int &maxNearby) {
     int cnt = 0, mx = site;
+    const unsigned span = (unsigned)(hi - lo);
     for (int j = 0; j < L.J; j++) {
         const int l = j * 64 + u.lane;
-        const int v = l < L.n ? S.val[l] : DEADV;
-        const bool in = v >= lo && v <= hi;
+        const int x = l < L.n ? S.val[l] : DEADV;
+        const bool in = (unsigned)(x - lo) <= span;
         cnt += in ? 1 : 0;
-        mx = in ? max(mx, v) : mx;
+        mx = in ? max(mx, x) : mx;
     }
     maxNearby = wmax(mx);
     return wsum(cnt);
 }
-// every live list's look-ahead, from its cursor
+// The same, after a test that settles nearly every pop on a large genome: live lists sit at or above `site`, lists that ran out
+// below it, so a second column can only be in the window if some lane's smallest live value (the centre's lane: its second
+// smallest) is <= hi, or some lane's largest run-out value is >= lo.  Otherwise the window holds the centre alone.
+__device__ __forceinline__ int countWindow(const U &u, const Lds &S, const Lists &L, int lo, int hi, int site, int center, int best, int second, int &maxNearby) {
+    const int mine = (u.lane == (center & 63)) ? second : best;
+    if (!__ballot(mine <= hi || L.dmax >= lo)) { maxNearby = site; return 1; }
+    return countWindowFull(u, S, L, lo, hi, site, maxNearby);
+}
+// every live list's look-ahead, from its cursor: 64 x NB gathers in flight per j
 __device__ __forceinline__ void refillAll(const U &u, Lds &S, Lists &L, int baseChrom) {
-    for (int j = 0; j < L.J; j++) {
-        const int l = j * 64 + u.lane;
-        if (l < L.n && ((L.live >> j) & 1u)) {
-            const int row = L.row[l] + (int)S.cons[l];
-            const int stop = L.stop[l], off = L.offs[l];
-            L.row[l] = row;
-            const int avail = stop - row - 1;
+    LT_BEGIN(u);
 #pragma unroll
-            for (int t = 0; t < NB; t++) S.nb[t][l] = adjustSite(u, L.sites[min(row + 1 + t, stop - 1)], off, baseChrom);
-            S.cons[l] = 0;
-            S.nbuf[l] = (uint8_t)(min(avail, NB) | (avail <= NB ? 0x80 : 0));
+    for (int j = 0; j < JM; j++) {
+        if (j < L.J) {
+            const int l = j * 64 + u.lane;
+            if ((L.live >> j) & 1u) {
+                const int row = L.rowW[l] + (int)(S.st[l] & 3);
+                const int stop = L.stopW[l], off = S.off[l];
+                L.rowW[l] = row;
+                const int avail = stop - row - 1;
+#pragma unroll
+                for (int t = 0; t < NB; t++) S.nb[t][l] = adjustSite(u, L.sites[min(row + 1 + t, stop - 1)], off, baseChrom);
+                S.st[l] = (uint8_t)((min(avail, NB) << 2) | (avail <= NB ? 0x80 : 0));
+            }
         }
     }
     wsync();
+    LT_END(u, 0);
 }
-// Pops every live list whose head equals `site`, in (site, column) order (QuadHeap.poll / add of the reference's inner loops,
-// BBIndexPacBio.java:1618-1668, BBIndex.java:2420-2444).  The loop the caller is in ends -- returns true -- at the first list that
-// runs out while fewer than `cutoff` stay alive (or at the first that runs out at all when `anyDeath`).
-__device__ __forceinline__ bool popSite(const U &u, Lds &S, Lists &L, int site, int cutoff, bool anyDeath, int baseChrom, unsigned &counter) {
-    for (;;) {
-        // which of my lists sit on `site`; does any of them need entries that are not buffered?
-        unsigned mine = 0; bool need = false;
-        for (int j = 0; j < L.J; j++) {
-            const int l = j * 64 + u.lane;
-            if (((L.live >> j) & 1u) && S.val[l] == site) {
-                mine |= 1u << j;
-                const int nbf = S.nbuf[l];
-                if ((int)S.cons[l] >= (nbf & 0x7f) && !(nbf & 0x80)) need = true;
-            }
-        }
-        if (!__ballot(mine != 0)) return false;
-        if (__ballot(need)) refillAll(u, S, L, baseChrom);
-        for (int j = 0; j < L.J; j++) {
-            const int l = j * 64 + u.lane;
-            const bool hit = (mine >> j) & 1u;
-            const u64 Pm = __ballot(hit);
-            if (!Pm) continue;
-            const int t = hit ? (int)S.cons[l] : 0, nbf = hit ? (int)S.nbuf[l] : 0;
-            const bool dies = hit && t >= (nbf & 0x7f);            // (after the refill above that can only mean: the list is at its end)
-            const u64 D = __ballot(dies);
-            if (D) {
-                const int nd = popc(D);
-                const int jexit = anyDeath ? 1 : max(1, L.nlive - cutoff + 1);
-                if (jexit <= nd) {
-                    u64 m = D;
-                    for (int q = 1; q < jexit; q++) m &= m - 1;
-                    const int d = __builtin_ctzll(m);
-                    counter += (unsigned)popc(Pm & (lt_mask(d) | (1ull << d)));
-                    L.nlive = 0;
-                    return true;
-                }
-                L.nlive -= nd;
-            }
-            counter += (unsigned)popc(Pm);
-            if (hit) {
-                if (dies) L.live &= ~(1u << j);
-                else { S.val[l] = S.nb[t][l]; S.cons[l] = (uint8_t)(t + 1); }
-            }
-        }
+// Pops the head of list `center`, the smallest (site, column) of the heap (QuadHeap.poll / add of the reference's inner loops,
+// BBIndexPacBio.java:1618-1668, BBIndex.java:2420-2444: they pop while the heap's minimum sits on the site just looked at; the
+// callers here look at a site once and keep popping while the minimum stays on it).  Returns true when the caller's loop ends: the
+// list ran out and fewer than `cutoff` stay alive (or it ran out at all when `anyDeath`).
+__device__ __forceinline__ bool popOne(const U &u, Lds &S, Lists &L, int site, int center, int cutoff, bool anyDeath, int baseChrom, unsigned &counter) {
+    LT_BEGIN(u);
+    int st = S.st[center];                                    // (one address for the whole wave: an LDS broadcast)
+    if ((st & 3) >= ((st >> 2) & 3) && !(st & 0x80)) { refillAll(u, S, L, baseChrom); st = S.st[center]; }
+    st = uni(st);
+    const int t = st & 3;
+    const bool dies = t >= ((st >> 2) & 3);
+    const bool owner = u.lane == (center & 63);
+    const int cj = center >> 6;
+    counter += 1u;
+    bool fin = false;
+    if (dies) {
+        L.nlive -= 1;
+        if (owner) { L.live &= ~(1u << cj); L.dmax = max(L.dmax, site); L.v[cj] = INT_MAX; }
+        fin = anyDeath || L.nlive < cutoff;
+        if (fin) L.nlive = 0;
+    } else {
+        const int nv = S.nb[t][center];
+        if (owner) { S.val[center] = nv; S.st[center] = (uint8_t)(st + 1); }
+        if (owner) L.v[cj] = nv;                              // (cj is uniform: an indexed register move under the owner's EXEC bit)
         wsync();
-        if (L.nlive == 0) return true;
     }
+    LT_END(u, 1);
+    return fin || L.nlive == 0;
 }
 
 // ---------------------------------------------------------------------------------------------- key-level scores
 // BBIndex.maxQuickScore :2473-2487 (+ maxScoreZ :2948-2964) over ascending offsets off[0..n)
-template <class PF> __device__ __forceinline__ int maxQuickScoreL(const U &u, const int *off, const int *ksc, int n) {
+template <class PF, class T> __device__ __forceinline__ int maxQuickScoreL(const U &u, const T *off, const T *ksc, int n) {
     int sum = 0, cover = 0;
     for (int j = 0; j * 64 < n; j++) {
         const int l = j * 64 + u.lane;
@@ -235,7 +260,7 @@ template <class PF> __device__ __forceinline__ int scoreZ2L(const U &u, const Ld
         const bool inr = v >= minLoc && v <= maxLoc;
         const u64 R = __ballot(inr);
         if (!R) continue;
-        const int offs = inr ? L.offs[l] : 0;
+        const int offs = inr ? (int)S.off[l] : 0;
         const u64 above = R & gt_mask(u.lane);
         const int src = above ? __builtin_ctzll(above) : u.lane;
         const int offAbove = __shfl(offs, src);
@@ -251,7 +276,7 @@ template <class PF> __device__ __forceinline__ int scoreZ2L(const U &u, const Ld
 // column whose value lies within MAX_INDEL of the last column taken" is sequential in the columns it takes, not in the ones it
 // passes over: per 64-column chunk a ballot finds the next one.
 template <class PF> __device__ __forceinline__ int quickScoreL(const U &u, const Lds &S, const Lists &L, int centerIndex, int centerVal, int numApproxHits) {
-    const int ksC = L.ksc[centerIndex];
+    const int ksC = S.ksc[centerIndex];
     if (numApproxHits == 1) return ksC;
     const int maxIndel = u.ix->p.maxIndel;
     int x = ksC;
@@ -262,7 +287,7 @@ template <class PF> __device__ __forceinline__ int quickScoreL(const U &u, const
             const int l = j * 64 + u.lane;
             const bool valid = l > centerIndex && l < L.n;
             const int v = valid ? S.val[l] : DEADV;
-            const int ks = valid ? L.ksc[l] : 0;
+            const int ks = valid ? (int)S.ksc[l] : 0;
             u64 pending = __ballot(valid && v >= 0);
             while (pending) {
                 const u64 cand = pending & __ballot(absdif(v, loc) <= maxIndel);
@@ -283,7 +308,7 @@ template <class PF> __device__ __forceinline__ int quickScoreL(const U &u, const
             const int l = j * 64 + u.lane;
             const bool valid = l < centerIndex;
             const int v = valid ? S.val[l] : DEADV;
-            const int ks = valid ? L.ksc[l] : 0;
+            const int ks = valid ? (int)S.ksc[l] : 0;
             u64 pending = __ballot(valid && v >= 0);
             while (pending) {
                 const u64 cand = pending & __ballot(absdif(v, loc) <= maxIndel);
@@ -304,7 +329,7 @@ template <class PF> __device__ __forceinline__ int quickScoreL(const U &u, const
         if (l < L.n && S.val[l] == centerVal) right = l;
     }
     right = wmax(right);
-    return x + Y_MULT * (L.offs[right] - L.offs[centerIndex]);
+    return x + Y_MULT * ((int)S.off[right] - (int)S.off[centerIndex]);
 }
 
 // ---------------------------------------------------------------------------------------------- location-array scores
@@ -391,7 +416,7 @@ template <class PF> __device__ __forceinline__ int extendScoreL(U &u, Lds &S, co
         const int value = l < L.n ? S.val[l] : DEADV;
         const u64 R = __ballot(value >= minVal && value <= maxVal);
         if (!R) continue;
-        const int offs = ((R >> lane) & 1) ? L.offs[l] : 0;
+        const int offs = ((R >> lane) & 1) ? (int)S.off[l] : 0;
         for (u64 m = R; m; m &= m - 1) {
             const int i = __builtin_ctzll(m);
             const int refbase = u.c.siteOf(rl(value, i)), c0 = rl(offs, i) + k - 1;
@@ -428,7 +453,7 @@ template <class PF> __device__ __forceinline__ int extendScoreL(U &u, Lds &S, co
         const int value = l < L.n ? S.val[l] : DEADV;
         const u64 R = __ballot(value >= minVal && value <= maxVal);
         if (!R) continue;
-        const int offs = ((R >> lane) & 1) ? L.offs[l] : 0;
+        const int offs = ((R >> lane) & 1) ? (int)S.off[l] : 0;
         for (u64 m = R; m; m &= m - 1) {
             const int i = __builtin_ctzll(m);
             const int refbase = u.c.siteOf(rl(value, i));
@@ -541,26 +566,33 @@ template <class PF> __device__ __forceinline__ void findMaxQscore2L(U &u, Lds &S
                                                                     int &outQ, int &outHits) {
     const bbidx_params &p = u.ix->p;
     const int numHits = L.n;
-    const int mqs = uni(maxQuickScoreL<PF>(u, L.offs, L.ksc, numHits));      // of THIS cycle's lists (:2307)
+    const int mqs = uni(maxQuickScoreL<PF>(u, S.off, S.ksc, numHits));      // of THIS cycle's lists (:2307)
     int topQscore = -999999999, maxHits = 0, approxHitsCutoff, indelCutoff;
     if (perfectOnly) { approxHitsCutoff = numHits; indelCutoff = 0; }
     else { approxHitsCutoff = max(prevMaxHits, min(p.minApproxHitsToKeep, numHits - 1)); indelCutoff = p.maxIndel2; }
+    int lastSite = INT_MIN;
     while (L.nlive > 0) {
         approxHitsCutoff = uni(approxHitsCutoff); topQscore = uni(topQscore); maxHits = uni(maxHits); L.nlive = uni(L.nlive); u.cPrescan = uni(u.cPrescan);
-        int site, centerIndex, unusedMax;
-        minHead(u, S, L, site, centerIndex);
-        const int approxHits = countWindow(u, S, L, site - min(p.maxIndel, indelCutoff), site + p.maxIndel2, site, unusedMax);
-        if (approxHits >= approxHitsCutoff) {
-            int qscore = quickScoreL<PF>(u, S, L, centerIndex, site, approxHits);
-            qscore += scoreZ2L<PF>(u, S, L, site, approxHits);
-            if (qscore > topQscore) {
-                maxHits = max(approxHits, maxHits);
-                approxHitsCutoff = max(approxHitsCutoff, approxHits - 1);
-                topQscore = qscore;
-                if (qscore >= mqs) break;
+        lastSite = uni(lastSite);
+        int site, centerIndex, best, second;
+        { LT_BEGIN(u); minHead(u, L, site, centerIndex, best, second); LT_END(u, 3); }
+        if (site != lastSite) {                                 // a site is looked at once, with every list that sits on it still there
+            lastSite = site;
+            int unusedMax, approxHits;
+            { LT_BEGIN(u); approxHits = countWindow(u, S, L, site - min(p.maxIndel, indelCutoff), site + p.maxIndel2, site, centerIndex, best, second, unusedMax); LT_END(u, 3); }
+            if (approxHits >= approxHitsCutoff) {
+                int qscore;
+                { LT_BEGIN(u); qscore = quickScoreL<PF>(u, S, L, centerIndex, site, approxHits);
+                  qscore += scoreZ2L<PF>(u, S, L, site, approxHits); LT_END(u, 2); }
+                if (qscore > topQscore) {
+                    maxHits = max(approxHits, maxHits);
+                    approxHitsCutoff = max(approxHitsCutoff, approxHits - 1);
+                    topQscore = qscore;
+                    if (qscore >= mqs) break;
+                }
             }
         }
-        if (popSite(u, S, L, site, approxHitsCutoff, perfectOnly, baseChrom, u.cPrescan)) break;
+        if (popOne(u, S, L, site, centerIndex, approxHitsCutoff, perfectOnly, baseChrom, u.cPrescan)) break;
     }
     outQ = topQscore; outHits = maxHits;
 }
@@ -586,16 +618,21 @@ template <class PF> __device__ __forceinline__ void slowWalk3L(U &u, Lds &S, Lis
 
     PrevSite pv; pv.idx = -1; pv.chrom = pv.strand = pv.start = pv.stop = pv.score = pv.perfect = pv.semiperfect = pv.ngaps = 0;
     bool finished = false;
+    int lastSite = INT_MIN;
     while (L.nlive > 0 && !finished) {
         approxHitsCutoff = uni(approxHitsCutoff); cutoff = uni(cutoff); qcutoff = uni(qcutoff); currentTopScore = uni(currentTopScore);
         maxHits = uni(maxHits); perfectsFound = uni(perfectsFound); bestqscore = uni(bestqscore); L.nlive = uni(L.nlive);
         pv.idx = uni(pv.idx); pv.chrom = uni(pv.chrom); pv.strand = uni(pv.strand); pv.start = uni(pv.start); pv.stop = uni(pv.stop);
         pv.score = uni(pv.score); pv.perfect = uni(pv.perfect); pv.semiperfect = uni(pv.semiperfect); pv.ngaps = uni(pv.ngaps);
         ssl.n = uni(ssl.n); ssl.overflow = uni(ssl.overflow); u.cWalk = uni(u.cWalk); u.cExtend = uni(u.cExtend); u.cRefBytes = uni(u.cRefBytes);
-        int site, centerIndex, maxNearbySite;
-        minHead(u, S, L, site, centerIndex);
-        const int approxHits = countWindow(u, S, L, site - p.maxIndel, site + p.maxIndel2, site, maxNearbySite);
-        if (approxHits >= approxHitsCutoff) {
+        lastSite = uni(lastSite);
+        int site, centerIndex, maxNearbySite = 0, best, second;
+        int approxHits = 0;
+        { LT_BEGIN(u); minHead(u, L, site, centerIndex, best, second); LT_END(u, 3); }
+        const bool fresh = site != lastSite;                    // a site is looked at once, with every list that sits on it still there
+        lastSite = site;
+        if (fresh) { LT_BEGIN(u); approxHits = countWindow(u, S, L, site - p.maxIndel, site + p.maxIndel2, site, centerIndex, best, second, maxNearbySite); LT_END(u, 3); }
+        if (fresh && approxHits >= approxHitsCutoff) {
             int score;
             int qscore = filter_by_qscore ? quickScoreL<PF>(u, S, L, centerIndex, site, approxHits) : qcutoff;
             qscore += scoreZ2L<PF>(u, S, L, site, approxHits);
@@ -723,7 +760,7 @@ template <class PF> __device__ __forceinline__ void slowWalk3L(U &u, Lds &S, Lis
             }
         }
         if (uni(finished)) break;
-        if (popSite(u, S, L, site, approxHitsCutoff, false, baseChrom, u.cWalk)) break;
+        if (popOne(u, S, L, site, centerIndex, approxHitsCutoff, false, baseChrom, u.cWalk)) break;
     }
     bestScores[0] = max(bestScores[0], currentTopScore);
     bestScores[1] = max(bestScores[1], maxHits);
@@ -866,7 +903,7 @@ template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(cons
     int *ws = Q.ws + (long long)blockIdx.x * (WS_ARRAYS * KMAX);
     int *keyW = ws, *offW = ws + KMAX, *kscW = ws + 2 * KMAX, *lenW = ws + 3 * KMAX, *origW = ws + 4 * KMAX, *listsW = ws + 5 * KMAX;
     Lists L;
-    L.row = ws + 6 * KMAX; L.stop = ws + 7 * KMAX; L.offs = ws + 8 * KMAX; L.ksc = ws + 9 * KMAX;
+    L.rowW = ws + 6 * KMAX; L.stopW = ws + 7 * KMAX;
     U u;
     u.ix = &ix;
     u.c.shift = 31 - p.chromBits; u.c.siteMask = (int)(0xFFFFFFFFu >> (p.chromBits + 1));
@@ -877,6 +914,9 @@ template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(cons
     u.scoreZ1Key = PF::Z_MULT * p.k;
     u.lane = lane; u.blen = 0;
     u.cPrescan = u.cWalk = u.cExtend = u.cRefBytes = 0;
+#ifdef BBIDXL_TIMERS
+    for (int q = 0; q < 5; q++) u.tm[q] = 0;
+#endif
     unsigned cSites = 0;
 
     for (;;) {
@@ -926,7 +966,7 @@ template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(cons
             }
             if (__ballot(badOrder)) { result = -2; break; }      // the coverage arithmetic needs ascending offsets (KeyRing.makeOffsets3 gives them)
             wsfence();
-            auto countHits = [&](int maxLen) -> int {
+            auto countHits = [&](int maxLen) __attribute__((always_inline)) -> int {
                 int cnt = 0;
                 for (int j = 0; j * 64 < n; j++) {
                     const int l = j * 64 + lane;
@@ -980,7 +1020,7 @@ template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(cons
             int precount = n, prescore = mqs;                 // lane c holds the prescan result of cycle c
 
             // BBIndex.getHits :354-391 + the heap fill of slowWalk3 / findMaxQscore2: the lists of one (block, strand) cycle
-            auto makeLists = [&](int block, int strand, int baseChrom, int minHits) -> int {
+            auto makeLists = [&](int block, int strand, int baseChrom, int minHits) __attribute__((always_inline)) -> int {
                 int nh = 0;
                 for (int j = 0; j * 64 < n; j++) {
                     const int l = j * 64 + lane;
@@ -998,17 +1038,25 @@ template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(cons
                     const u64 M = __ballot(hit);
                     if (hit) {
                         const int d = nh + popc(M & lt_mask(lane));
-                        L.row[d] = start; L.stop[d] = start + len; L.offs[d] = off; L.ksc[d] = ksc;
+                        L.rowW[d] = start; L.stopW[d] = start + len;
+                        S.off[d] = (short)off; S.ksc[d] = (short)ksc;
                         S.val[d] = adjustSite(u, first, off, baseChrom);
-                        S.cons[d] = 0; S.nbuf[d] = 0;
+                        S.st[d] = 0;
                     }
                     nh += popc(M);
                 }
                 L.n = L.nlive = nh; L.J = (nh + 63) >> 6; L.sites = (GlobalIntsT)ix.sites[block];
-                L.live = 0;
-                for (int j = 0; j < L.J; j++) if (j * 64 + lane < nh) L.live |= 1u << j;
                 wsync();
                 wsfence();
+                L.live = 0; L.dmax = INT_MIN;
+#pragma unroll
+                for (int j = 0; j < JM; j++) {
+                    L.v[j] = INT_MAX;
+                    if (j < L.J) {
+                        const int l = j * 64 + lane;
+                        if (l < nh) { L.v[j] = S.val[l]; L.live |= 1u << j; }
+                    }
+                }
                 if (nh >= minHits && nh > 0) refillAll(u, S, L, baseChrom);
                 return nh;
             };
@@ -1024,7 +1072,7 @@ template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(cons
                         if (nh < minHitsToScore) { if (lane == cycle) { prescore = -9999; precount = 0; } }
                         else {
                             int tq, th;
-                            findMaxQscore2L<PF>(u, S, L, baseChrom, minHitsToScore, bestqscore >= mqs && pretend, tq, th);
+                            { LT_BEGIN(u); findMaxQscore2L<PF>(u, S, L, baseChrom, minHitsToScore, bestqscore >= mqs && pretend, tq, th); LT_END(u, 4); }
                             tq = uni(tq); th = uni(th);
                             if (lane == cycle) { prescore = tq; precount = th; }
                             bestqscore = max(tq, bestqscore); maxHits = max(maxHits, th);
@@ -1059,7 +1107,7 @@ template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(cons
                     if (!prescan || rl(precount, cycle) >= hitsCutoff || rl(prescore, cycle) >= qscoreCutoff) {
                         const int nh = makeLists(block, strand, baseChrom, p.minApproxHitsToKeep);
                         if (nh >= p.minApproxHitsToKeep)
-                            slowWalk3L<PF>(u, S, L, strand, n, mqs, chrom, ssl, bestScores, allBasesCovered, maxScore, fullyDefined);
+                            { LT_BEGIN(u); slowWalk3L<PF>(u, S, L, strand, n, mqs, chrom, ssl, bestScores, allBasesCovered, maxScore, fullyDefined); LT_END(u, 4); }
                     }
                     if (p.quitAfterTwoPerfects && bestScores[5] >= 2) quit = true;
                 }
@@ -1072,9 +1120,13 @@ template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(cons
     }
     if (P.stats && lane == 0) {
         unsigned long long *st = P.stats + 8 * (blockIdx.x % STAT_SHARDS);
+#ifdef BBIDXL_TIMERS
+        for (int q = 0; q < 5; q++) atomicAdd(&st[q], u.tm[q] >> 10);
+#else
         atomicAdd(&st[0], (unsigned long long)u.cPrescan); atomicAdd(&st[1], (unsigned long long)u.cWalk);
         atomicAdd(&st[2], (unsigned long long)u.cExtend); atomicAdd(&st[3], (unsigned long long)u.cRefBytes);
         atomicAdd(&st[4], (unsigned long long)cSites);
+#endif
     }
 }
 
