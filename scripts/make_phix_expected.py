@@ -1,0 +1,27 @@
+"""Writes tests/golden/phix_expected.json: what the CPU oracle returns for the reference's PhiX fixture (tests/golden/*.gz, copied
+from the reference's resources/), read by read -- the top site of every read in six runs (sample1 / sample2 single-ended and the
+pairs, each with keys placed from the qualities and as for quality-less input) and the score of the fill against each read's
+TRUTH window (the coordinates in its name +- SLOW_ALIGN_PADDING).  tests/test_golden_phix.py asserts the oracle (and, on the GPU,
+the device mapper) against this table field by field, so that a change that moves a single read shows.  The table is the
+restatement's output pinned at the commit that wrote it -- not output of the reference (no JVM in this image).
+Run from the repository root: python scripts/make_phix_expected.py"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.golden_phix import fixture_runs, truth_window_scores      # noqa: E402
+
+if __name__ == "__main__":
+    table = {"runs": {}, "truth_window": {}}
+    for name, run in fixture_runs().items():
+        out = run["oracle"]()
+        top = out["sites"][:, 0]
+        table["runs"][name] = [[int(out["nsites"][i]), int(top["strand"][i]), int(top["start"][i]), int(top["stop"][i]), int(top["slowScore"][i])]
+                               if out["nsites"][i] > 0 else [int(out["nsites"][i]), 0, 0, 0, 0] for i in range(len(top))]
+    for which in (1, 2):
+        table["truth_window"]["sample%d" % which] = truth_window_scores(which)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "phix_expected.json")
+    with open(path, "w") as f:
+        json.dump(table, f, separators=(",", ":"))
+    print("wrote", path, {k: len(v) for k, v in table["runs"].items()})

@@ -26,6 +26,29 @@ def phix_reference():
     return ref
 
 
+def fix_qualities(bases, qual):
+    """What stream.Read does to a FASTQ record's qualities on input (CHANGE_QUALITY, current/stream/Read.java:164-177): a called
+    base's quality is capped to [MIN_CALLED_QUALITY 2, MAX_CALLED_QUALITY 41], an undefined base's becomes 0."""
+    b = np.asarray(bases, np.uint8)
+    q = np.asarray(qual, np.uint8).copy()
+    defined = np.isin(b & ~np.uint8(32), np.frombuffer(b"ACGTU", np.uint8))
+    q[defined] = np.clip(q[defined], 2, 41)
+    q[~defined] = 0
+    return q
+
+
+def sample_qualities(which):
+    """Numeric phred qualities (ASCII - 33) of sample1 / sample2, as stream.Read holds them after input: uint8[n, 100]."""
+    with gzip.open(os.path.join(HERE, "sample%d.fq.gz" % which), "rt") as f:
+        lines = [ln.rstrip("\n") for ln in f]
+    out = []
+    for i in range(0, len(lines), 4):
+        b = np.frombuffer(lines[i + 1].upper().encode(), np.uint8)
+        q = np.frombuffer(lines[i + 3].encode(), np.uint8) - 33
+        out.append(fix_qualities(b, q))
+    return np.stack(out)
+
+
 def sample_reads(which):
     """Returns (reads uint8[n, 100], truth dict of int arrays: strand, start, stop) for sample1 / sample2."""
     bases, strand, start, stop = [], [], [], []
@@ -40,3 +63,69 @@ def sample_reads(which):
     lens = {len(b) for b in bases}
     assert lens == {100}, lens
     return np.stack(bases), dict(strand=np.array(strand), start=np.array(start), stop=np.array(stop))
+
+
+def _revcomp(b):
+    comp = np.full(256, ord("N"), np.uint8)
+    for x, y in zip(b"ACGTN", b"TGCAN"):
+        comp[x] = y
+    return comp[np.asarray(b, np.uint8)[::-1]]
+
+
+def fixture_inputs(mode, use_qualities):
+    """(reads list, qualities list or None, paired) of one run: mode "se1" / "se2" = sample1 / sample2 single-ended, "pe" = the pairs."""
+    r1, _ = sample_reads(1)
+    r2, _ = sample_reads(2)
+    q1, q2 = sample_qualities(1), sample_qualities(2)
+    if mode == "pe":
+        reads = [x for p in zip(r1, r2) for x in p]
+        quals = [x for p in zip(q1, q2) for x in p]
+    else:
+        reads, quals = (list(r1), list(q1)) if mode == "se1" else (list(r2), list(q2))
+    return reads, (quals if use_qualities else None), mode == "pe"
+
+
+def fixture_runs():
+    """name -> {"inputs": (recs, blob, baseScores, keyinfo, paired), "oracle": callable} for the six runs of the fixture.  Keys are
+    placed by the product's host code (bbkeys_make_batch = AbstractMapThread.quickMap's key stage) with bbmap.sh's densities."""
+    from bbmap_amd import keys as K
+    from oracle import oracle as O
+    ref = phix_reference()
+    runs = {}
+    for mode in ("se1", "se2", "pe"):
+        for use_q in (False, True):
+            reads, quals, paired = fixture_inputs(mode, use_q)
+            recs, blob, bs, ki = K.make_batch(reads, quals)
+
+            def oracle(recs=recs, blob=blob, bs=bs, ki=ki, paired=paired):
+                oi = O.OracleIndex([ref], k=13)
+                oi.s.p.quitAfterTwoPerfects = 0 if paired else 1            # BBMap.java:434
+                return O.map_reads(oi, recs, blob, ki, base_scores=bs, paired=paired, cap=64)
+            runs["%s_%s" % (mode, "qual" if use_q else "noqual")] = {"inputs": (recs, blob, bs, ki, paired), "oracle": oracle}
+    return runs
+
+
+def truth_window_jobs(which):
+    """Per read of sample `which`: (bases on the truth strand, refStartLoc, refEndLoc, minScore) of the fill scoreSlow would issue for a
+    site at exactly the coordinates in the read's name: window +- SLOW_ALIGN_PADDING 4, minScore = the initial minMsaLimit
+    (-CLEARZONE1e + (int)(0.56 * maxSwScore), current/align2/BBMapThread.java:262-264)."""
+    reads, truth = sample_reads(which)
+    max_sw = 70 + 99 * 100
+    floor = -258 + int(np.float32(0.56) * np.float32(max_sw))
+    jobs = []
+    for i in range(len(reads)):
+        rd = _revcomp(reads[i]) if truth["strand"][i] else reads[i]
+        jobs.append((rd.tobytes(), int(truth["start"][i]) - 4, int(truth["stop"][i]) + 4, floor))
+    return jobs
+
+
+def truth_window_scores(which):
+    """score2's {score, start, stop} of each truth-window fill on the CPU oracle (None where fillAndScoreLimited returns null)."""
+    from oracle import oracle as O
+    ref = phix_reference().tobytes()
+    msa = O.OracleMSA(601, 3000)
+    out = []
+    for rd, a, b, floor in truth_window_jobs(which):
+        sv, _ = msa.fillAndScoreLimited(rd, ref, a, b, floor)
+        out.append(None if sv is None else [int(sv[0]), int(sv[1]), int(sv[2])])
+    return out

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "bbmap_amd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(bb(?:map|msa|band|idx|pipe)_[a-z0-9_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(bb(?:map|msa|band|idx|pipe|keys)_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -32,4 +32,4 @@ def test_struct_layouts_match_header():
 
 
 def test_abi_version():
-    assert _lib.load().bbmap_abi_version() == 4
+    assert _lib.load().bbmap_abi_version() == 5

@@ -1,21 +1,33 @@
 """configs[0] of BASELINE.json and the only fixture the reference holds for this path: phix174_ill.ref.fa.gz + sample1.fq.gz /
 sample2.fq.gz (100 synthetic 100-bp read pairs whose names carry the true strand, start and stop, written by the reference's
-own generator).  What it pins: the END RESULT of the whole path -- probe, ungapped scores, scoreSlow DP, score2's limits, mate
-rescue -- lands on the coordinates the reference's generator recorded, under the reference's own two correctness rules
-(AbstractMapThread.isCorrectHit / isCorrectHitLoose, current/align2/AbstractMapThread.java:2692-2717, thresh = CORRECT_THRESH = 0).
-What it does not pin: intermediate values (scores, visited-cell counts, match strings); for those the oracle remains a
-restatement.  The reads' qualities are ignored (key offsets and key scores as for quality-less input), so the few reads whose
-placement depends on quality-weighted keys may differ from a real BBMap run; the counts below are what the restatement gives
-and are asserted as floors.
-CPU test: the oracle against the truth.  GPU tests: the device mapper equals the oracle on all 200 reads, single-ended and
-paired, and therefore meets the same truth."""
+own generator, with qualities).  Six runs: sample1 / sample2 single-ended and the pairs, each with keys placed from the qualities
+(GENERATE_KEY_SCORES_FROM_QUALITY: makeKeyProbs / makeOffsets3 / makeKeyScores / makeByteScoreArray, the product's bbkeys_*) and as
+for quality-less input.
+
+What is pinned, and by what:
+ * END RESULT vs the fixture's truth (reference-held): the reference's own two correctness rules (AbstractMapThread.isCorrectHit /
+   isCorrectHitLoose, current/align2/AbstractMapThread.java:2692-2717, thresh 0) as floors;
+ * the TRUTH-WINDOW property (reference-held truth + the DP): the fill scoreSlow would issue for a site at exactly the coordinates
+   in a read's name never scores above what the mapper found for that read -- a mapper may beat the generator's placement, never
+   lose to it (a wrong tie-break or window in the flow would show here);
+ * a per-read table (tests/golden/phix_expected.json, written by scripts/make_phix_expected.py from the oracle at the commit that
+   made it): every read's top site (strand, start, stop, slowScore) in all six runs, compared field by field -- not reference
+   output, a regression pin: a change that moves one read fails.
+What it does not pin: intermediate values (visited-cell counts, match strings); for those the oracle remains a restatement.
+CPU tests: the oracle.  GPU tests: the device mapper equals the oracle on every run (site lists, fills, traceback strings), so it
+meets the same truth, table and property."""
+import json
+import os
+
 import numpy as np
 import pytest
 
-from oracle import oracle as O
-from tests.golden_phix import phix_reference, sample_reads
+from tests.golden_phix import (HERE, fixture_runs, phix_reference, sample_reads, truth_window_jobs, truth_window_scores)
 
-L, K = 100, 13
+FLOORS = {      # (mapped, strict, loose) of a sample's 100 reads, as the restatement gives them: asserted as floors against the truth
+    ("se", 1): (99, 86, 98), ("se", 2): (98, 79, 95),       # mapped on their own (sample2 with quality-placed keys: 95 loose, 96 without)
+    ("pe", 1): (99, 86, 98), ("pe", 2): (98, 82, 98),       # as pairs (rescue brings three of sample2's reads home)
+}
 
 
 def _score_against_truth(sites, nsites, truth):
@@ -27,69 +39,127 @@ def _score_against_truth(sites, nsites, truth):
     return int(mapped.sum()), int(strict.sum()), int(loose.sum())
 
 
-def _oracle(paired):
-    ref = phix_reference()
-    assert len(ref) == 5386 + 16000
-    r1, t1 = sample_reads(1)
-    r2, t2 = sample_reads(2)
-    oi = O.OracleIndex([ref], k=K)
-    offs = O.make_offsets(L, K, 1.9)
-    ks = [100 * K] * len(offs)
-    if paired:
-        oi.s.p.quitAfterTwoPerfects = 0
-        out = O.map_batch(oi, r1.reshape(-1), r2.reshape(-1), L, offs, ks)
-    else:
-        out = O.map_batch(oi, r1.reshape(-1), None, L, offs, ks)
-    return ref, (r1, t1), (r2, t2), offs, ks, out
+def _split(name, out):
+    """{sample: (sites, nsites)} of one run's output"""
+    if name.startswith("pe"):
+        return {1: (out["sites"][0::2], out["nsites"][0::2]), 2: (out["sites"][1::2], out["nsites"][1::2])}
+    return {int(name[2]): (out["sites"], out["nsites"])}
 
 
-def test_oracle_single_ended_meets_the_fixture_truth():
-    _, (r1, t1), _, _, _, out = _oracle(False)
-    mapped, strict, loose = _score_against_truth(out["sites1"], out["nsites1"], t1)
-    assert mapped >= 99 and strict >= 86 and loose >= 96, (mapped, strict, loose)
+@pytest.fixture(scope="module")
+def runs():
+    r = fixture_runs()
+    for v in r.values():
+        v["out"] = v["oracle"]()
+    return r
+
+
+@pytest.fixture(scope="module")
+def expected():
+    return json.load(open(os.path.join(HERE, "phix_expected.json")))
+
+
+def _check_truth(name, out):
+    for which, (sites, nsites) in _split(name, out).items():
+        _, truth = sample_reads(which)
+        got = _score_against_truth(sites, nsites, truth)
+        floor = FLOORS[(name[:2], which)]
+        assert all(g >= f for g, f in zip(got, floor)), (name, which, got, floor)
+
+
+def _check_table(name, out, expected):
+    top = out["sites"][:, 0]
+    for i, exp in enumerate(expected["runs"][name]):
+        ns = int(out["nsites"][i])
+        got = [ns, int(top["strand"][i]), int(top["start"][i]), int(top["stop"][i]), int(top["slowScore"][i])] if ns > 0 else [ns, 0, 0, 0, 0]
+        assert got == exp, "%s read %d: %s, table %s" % (name, i, got, exp)
+
+
+def _check_truth_window(name, out, tw):
+    """The mapper's best slowScore of a read is at least the score of the fill against the read's truth window whenever the read's
+    site list holds a site (on the truth's strand) whose span covers the truth's: that site's own fill window contains the truth
+    window, so its optimum cannot be lower (and a limit raised by an earlier, better site only proves the point).  A read without
+    such a site is a PROBE miss -- the heuristic never proposed the locus -- and is returned, not failed."""
+    worse, uncovered = [], []
+    for which, (sites, nsites) in _split(name, out).items():
+        _, truth = sample_reads(which)
+        for i, t in enumerate(tw["sample%d" % which]):
+            if t is None:
+                continue                                   # the truth window itself does not reach the minimum score
+            n = max(int(nsites[i]), 0)
+            best = int(sites[i]["slowScore"][:n].max()) if n else -1
+            if best >= t[0]:
+                continue
+            s = sites[i][:n]
+            covered = bool(((s["strand"] == truth["strand"][i]) & (s["start"] <= t[1]) & (s["stop"] >= t[2])).any()) if n else False
+            (worse if covered else uncovered).append((name, which, i, best, t))
+    assert not worse, worse
+    return uncovered
+
+
+def test_oracle_meets_the_fixture_truth_in_all_six_runs(runs):
+    for name, r in runs.items():
+        _check_truth(name, r["out"])
+    # the rescue stage ran in the paired runs, and qualities changed the inputs (key scores below the maximum)
+    assert runs["pe_qual"]["out"]["stats"][2] > 50
+    ki = runs["se1_qual"]["inputs"][3]
+    assert (ki < 1300).sum() > 100 and (runs["se1_qual"]["inputs"][2] < 0).sum() > 1000
     # a read the generator left unmutated comes back perfect at exactly its origin
-    top = out["sites1"][:, 0]
-    perfect = (out["nsites1"] > 0) & (top["slowScore"] == 70 + 99 * 100)
+    out = runs["se1_noqual"]["out"]
+    _, t1 = sample_reads(1)
+    top = out["sites"][:, 0]
+    perfect = (out["nsites"] > 0) & (top["slowScore"] == 70 + 99 * 100)
     assert perfect.sum() >= 5
     assert ((top["start"] == t1["start"]) & (top["stop"] == t1["stop"]) & (top["strand"] == t1["strand"]))[perfect].all()
 
 
-def test_oracle_paired_meets_the_fixture_truth():
-    _, (r1, t1), (r2, t2), _, _, out = _oracle(True)
-    m1 = _score_against_truth(out["sites1"], out["nsites1"], t1)
-    m2 = _score_against_truth(out["sites2"], out["nsites2"], t2)
-    assert m1[0] >= 99 and m1[1] >= 86 and m1[2] >= 96, m1
-    assert m2[0] >= 99 and m2[1] >= 83 and m2[2] >= 95, m2
-    assert out["stats"][2] > 50                      # quickRescue scans ran
+def test_oracle_equals_the_per_read_table(runs, expected):
+    for name, r in runs.items():
+        _check_table(name, r["out"], expected)
+
+
+def test_mapper_never_loses_to_the_truth_window(runs, expected):
+    tw = {"sample1": truth_window_scores(1), "sample2": truth_window_scores(2)}
+    assert tw == expected["truth_window"]                  # the fills themselves are pinned too
+    assert sum(t is not None for t in tw["sample1"]) >= 90    # (the rest: the truth window itself stays below the minimum score)
+    missed = []
+    for name, r in runs.items():
+        missed += _check_truth_window(name, r["out"], tw)
+    # One read loses to its truth window, and not in the DP: sample2's read 43 (an 85-base deletion) with quality-placed keys -- the
+    # probe proposes [11721, 11864], 46 bases left of the truth and 87 short of its end, and that window's fill stays below the
+    # minimum score; as a mate, rescue finds [11767, 11863] (5,135 points), again short of the deletion.  With the quality-less
+    # key offsets the same read comes home at 6,993 points.  Every other read of every run holds the property.
+    assert sorted((m[0], m[1], m[2]) for m in missed) == [("pe_qual", 2, 43), ("se2_qual", 2, 43)], missed
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("paired", [False, True])
-def test_device_mapper_equals_oracle_on_the_fixture(paired):
+def test_device_mapper_equals_oracle_on_the_fixture(runs, expected):
+    """All six runs through bbmap_map_batch_device: equal to the oracle fill by fill, hence to the table, the truth and the property;
+    the truth-window fills on the device equal the oracle's."""
+    from bbmap_amd import msa as M
     from bbmap_amd.index import DeviceIndex
     from bbmap_amd.mapper import Mapper
     from tests.mapper_check import compare
-    ref, (r1, t1), (r2, t2), offs, ks, orc = _oracle(paired)
-    if paired:
-        reads = np.empty((200, L), np.uint8)
-        reads[0::2], reads[1::2] = r1, r2
-    else:
-        reads = r1
-    n = len(reads)
-    di = DeviceIndex.build([ref], k=K)
-    mp = Mapper(di, n, L, offs, ks, paired=paired, max_sites=32)
-    mp.load_reads(reads)
-    mp.step()
-    out, st = mp.fetch(), mp.stats()
-    mp.close()
+    ref = phix_reference()
+    di = DeviceIndex.build([ref], k=13)
+    tw = expected["truth_window"]
+    for name, r in runs.items():
+        recs, blob, bs, ki, paired = r["inputs"]
+        mp = Mapper.from_records(di, recs, blob, bs, ki, paired=paired, max_sites=32)
+        mp.step()
+        out, st = mp.fetch(), mp.stats()
+        mp.close()
+        assert st["reads_overflowed"] == 0
+        bad = compare(out, r["out"], len(recs), paired)
+        assert not bad, name + "\n" + "\n".join(bad[:20])
+        _check_truth(name, out)
+        _check_table(name, out, expected)
+        _check_truth_window(name, out, tw)
     di.close()
-    assert st["reads_overflowed"] == 0
-    bad = compare(out, orc, n, paired)
-    assert not bad, "\n".join(bad[:20])
-    if paired:
-        m1 = _score_against_truth(out["sites"][0::2], out["nsites"][0::2], t1)
-        m2 = _score_against_truth(out["sites"][1::2], out["nsites"][1::2], t2)
-        assert m1[1] >= 86 and m1[2] >= 96 and m2[1] >= 83 and m2[2] >= 95, (m1, m2)
-    else:
-        m = _score_against_truth(out["sites"], out["nsites"], t1)
-        assert m[0] >= 99 and m[1] >= 86 and m[2] >= 96, m
+    msa = M.MultiStateAligner11ts(maxRows=601, maxColumns=3000)
+    for which in (1, 2):
+        probs = [(rd, ref.tobytes(), a, b, floor) for rd, a, b, floor in truth_window_jobs(which)]
+        got = msa.align(probs, M.FILL_AND_SCORE_LIMITED)
+        for g, t in zip(got, tw["sample%d" % which]):
+            assert (None if g["score"] is None else g["score"][:3]) == t
+    msa.ctx.close()
