@@ -379,7 +379,10 @@ __device__ __forceinline__ int batchPop(const U &u, WL &L, int lo, int hi, int c
 #define BBIDX_CYCLE 1               // 0: always the sequential heap walk (for A/B measurements)
 #endif
 constexpr int CYC_EMAX = 384, CYC_CMAX = 64;
-constexpr int CYC_MAPW = 192;        // words per presence map (6,144 slots)
+#ifndef BBIDX_CYC_MAPW
+#define BBIDX_CYC_MAPW 192
+#endif
+constexpr int CYC_MAPW = BBIDX_CYC_MAPW;        // words per presence map (6,144 slots)
 struct CycleLds {
     int ent[CYC_EMAX];               // adjusted sites, list after list
     unsigned short isoq[CYC_EMAX];   // 0 for a candidate, else the entry's prescan quick score keyScore + scoreZ1Key

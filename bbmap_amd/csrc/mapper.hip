@@ -630,7 +630,10 @@ __device__ inline bbmsa_job make_job(const Dev &D, const bbidx_read &rr, const S
     j.flags = BBMSA_FILL_AND_SCORE_LIMITED | BBMSA_DO_TRACEBACK;
     return j;
 }
-// appends one fill to the plain or (sites with a gap array) the gapped log; returns its index (GAPPED_BIT marks the gapped log)
+// appends one fill to the plain or (sites with a gap array) the gapped log; returns its index (GAPPED_BIT marks the gapped log), or
+// NO_ROOM when that log is full: the caller then leaves its state untouched and asks again in the next round, before which the host
+// has grown the log (the reference's lists have no capacity; nothing may be lost or the batch refused because a log was sized too small)
+constexpr int NO_ROOM = -2;
 __device__ int emit_fill(const Dev &D, long long r, const bbidx_read &rr, const Site &ss, int site, int pad, int minscore, int kind, int seq) {
     bbmap_jobinfo info; info.read = (int)r; info.seq = seq; info.kind = kind; info.site = site;
     const bbmsa_job j = make_job(D, rr, ss, pad, minscore);
@@ -638,16 +641,16 @@ __device__ int emit_fill(const Dev &D, long long r, const bbidx_read &rr, const 
     // first context's column limit; a job without gaps is an ordinary job there
     if (ss.ngaps || (imin(j.ref_len - 1, j.refEndLoc) - imax(0, j.refStartLoc) + 1) > D.plainColumns) {
         const unsigned k = atomicAdd(&D.counters[1], 1u);
-        if ((long long)k < D.gjobCap) {
-            D.gjobs[k] = j; D.ginfo[k] = info;
-            bbmsa_gaps g; g.ngaps = ss.ngaps;
-            for (int q = 0; q < BBMSA_MAX_GAPS; q++) g.gaps[q] = q < ss.ngaps ? ss.gaps[q] : 0;
-            D.ggaps[k] = g;
-        }
+        if ((long long)k >= D.gjobCap) return NO_ROOM;
+        D.gjobs[k] = j; D.ginfo[k] = info;
+        bbmsa_gaps g; g.ngaps = ss.ngaps;
+        for (int q = 0; q < BBMSA_MAX_GAPS; q++) g.gaps[q] = q < ss.ngaps ? ss.gaps[q] : 0;
+        D.ggaps[k] = g;
         return (int)k | GAPPED_BIT;
     }
     const unsigned k = atomicAdd(&D.counters[0], 1u);
-    if ((long long)k < D.jobCap) { D.jobs[k] = j; D.jinfo[k] = info; }
+    if ((long long)k >= D.jobCap) return NO_ROOM;
+    D.jobs[k] = j; D.jinfo[k] = info;
     return (int)k;
 }
 __device__ inline const bbmsa_result &fill_result(const Dev &D, int job) {
@@ -715,10 +718,12 @@ __global__ __launch_bounds__(128) void slow_round_kernel(const Dev D) {
                     const int nsc = res.score_len;
                     if (nsc > 6 && (res.score[3] + res.score[4] + st.expectedLen < D.S.expLimit)) {
                         set_limits(ss, ss.start - res.score[6], ss.stop + res.score[7]);
-                        st.oldJob = st.pending;
-                        st.pending = emit_fill(D, r, rr, ss, st.idx, D.S.slowAlignPadding + D.S.extraPadding, st.minscore, 1, st.seq++);
+                        const int job = emit_fill(D, r, rr, ss, st.idx, D.S.slowAlignPadding + D.S.extraPadding, st.minscore, 1, st.seq);
+                        stillActive = true;
+                        if (job == NO_ROOM) break;                                     // log full: the same step again next round
+                        st.seq++; st.oldJob = st.pending; st.pending = job;
                         atomicAdd(&D.counters[6], 1u);
-                        st.phase = 2; s[st.idx] = ss; stillActive = true;
+                        st.phase = 2; s[st.idx] = ss;
                         break;
                     }
                     finish_site(D, st, ss, nsc > 0 ? st.pending : -1, bases, len, maxSw);
@@ -745,9 +750,12 @@ __global__ __launch_bounds__(128) void slow_round_kernel(const Dev D) {
                         st.phase = 1; s[st.idx] = ss;
                         continue;                                                  // its result is there already
                     }
+                    const int job = emit_fill(D, r, rr, ss, st.idx, D.S.slowAlignPadding, st.minscore, 0, st.seq);
+                    stillActive = true;
+                    if (job == NO_ROOM) break;                                         // log full: this site again next round
                     if (early) atomicAdd(&D.counters[8], 1u);                      // a fill ahead of time that the sequence does not contain
-                    st.pending = emit_fill(D, r, rr, ss, st.idx, D.S.slowAlignPadding, st.minscore, 0, st.seq++);
-                    st.phase = 1; s[st.idx] = ss; stillActive = true;
+                    st.seq++; st.pending = job;
+                    st.phase = 1; s[st.idx] = ss;
                     break;
                 }
                 if (early) atomicAdd(&D.counters[8], 1u);
@@ -755,7 +763,7 @@ __global__ __launch_bounds__(128) void slow_round_kernel(const Dev D) {
                 s[st.idx] = ss; st.idx++;
             }
             if (!stillActive) st.phase = 3;
-            else if (st.idx >= 1 && D.fillAhead) {
+            else if (st.idx >= 1 && D.fillAhead && (st.phase == 1 || st.phase == 2)) {
                 for (int j = st.idx + 1; j < n; j++) {
                     Site tmp = s[j];
                     bool needsFill; int expectedLen;
@@ -763,8 +771,9 @@ __global__ __launch_bounds__(128) void slow_round_kernel(const Dev D) {
                     if (!needsFill) continue;
                     const int minscore = imax(sw, st.minMsaLimit);
                     if (tmp.reserved[0] && tmp.reserved[1] == minscore) continue;  // already in the log with this bound
-                    if (tmp.reserved[0]) atomicAdd(&D.counters[8], 1u);
                     const int job = emit_fill(D, r, rr, tmp, j, D.S.slowAlignPadding, minscore, 0, -1);
+                    if (job == NO_ROOM) break;                                         // no room for fills ahead of time this round
+                    if (tmp.reserved[0]) atomicAdd(&D.counters[8], 1u);
                     s[j].reserved[0] = job + 1; s[j].reserved[1] = minscore;
                 }
             }
@@ -991,6 +1000,8 @@ __global__ __launch_bounds__(256) void pack_sites_kernel(const Site *ms, const i
     ((uint4 *)(packed + dst))[piece] = ((const uint4 *)(ms + r * cap + j))[piece];
 }
 
+struct ToLL { __host__ __device__ long long operator()(int x) const { return (long long)x; } };
+
 }  // namespace bbmapper
 
 // ================================================================================================= host side
@@ -1175,9 +1186,11 @@ static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *par
     }
     const long long n = cfg->max_reads;
     const int cap = cfg->max_sites;
+    // starting capacities of the two fill logs; they grow when a batch needs more (grow_logs)
     const int jpr = cfg->jobsPerRead > 0 ? cfg->jobsPerRead : 3;
     c->jobCap = n * jpr + 1024;
-    c->gjobCap = parent ? n * 16 + 4096 : n / 8 + 4096;
+    c->gjobCap = parent ? n * 16 + 4096 : (n * jpr) / 24 + 4096;
+    if (cfg->jobsPerRead < 0) c->jobCap = c->gjobCap = -(long long)cfg->jobsPerRead;       // exact starting capacity (tests of the growth path)
     c->rescCap = parent ? n * 64 + 1024 : n * 2 + 1024;
     c->matchStride = ((maxRows + c->plainColumns + 15) / 16) * 16;
     // a gapped match string expands every gap symbol to 128 'D's (traceback, MultiStateAligner11tsJNI.java:481-493)
@@ -1246,6 +1259,48 @@ extern "C" int bbmap_create(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx
 static int read_counters(bbmap_ctx *c, hipStream_t stream) {
     MHIP(hipMemcpyAsync(c->h_counters, c->d_counters, 64 * 4, hipMemcpyDeviceToHost, stream));
     MHIP(hipStreamSynchronize(stream));
+    return BBMAP_OK;
+}
+
+// Replaces a device array by a larger one (contents kept), in stream order; the old one is freed once the stream has passed.
+template <class T> static int regrow(bbmap_ctx *c, hipStream_t stream, T **p, size_t oldCount, size_t newCount, std::vector<void *> &dead) {
+    void *d = nullptr;
+    if (hipMalloc(&d, (newCount ? newCount : 1) * sizeof(T)) != hipSuccess) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: growing a fill log failed (device memory)");
+    if (oldCount) MHIP(hipMemcpyAsync(d, *p, oldCount * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    for (void *&q : c->allocs) if (q == (void *)*p) q = d;
+    dead.push_back((void *)*p);
+    *p = (T *)d;
+    return BBMAP_OK;
+}
+// The reference's per-read lists of fills have no capacity.  When a round asks for more log entries than there are (the kernels
+// then hold the affected reads back, emit_fill's NO_ROOM), the logs are grown here before the next round; `needJobs` / `needGapped`
+// = entries that must fit.  The device counters are set back to the number of entries that were really written.
+static int grow_logs(bbmap_ctx *c, hipStream_t stream, bbmapper::Dev &D, long long needJobs, long long needGapped, long long usedJobs, long long usedGapped) {
+    std::vector<void *> dead;
+    if (needJobs > c->jobCap) {
+        long long nc = c->jobCap * 2; if (nc < needJobs) nc = needJobs + needJobs / 4 + 1024;
+        MTRY(regrow(c, stream, &c->d_jobs, (size_t)usedJobs, (size_t)nc, dead));
+        MTRY(regrow(c, stream, &c->d_jinfo, (size_t)usedJobs, (size_t)nc, dead));
+        MTRY(regrow(c, stream, &c->d_results, (size_t)usedJobs, (size_t)nc, dead));
+        MTRY(regrow(c, stream, &c->d_match, (size_t)usedJobs * c->matchStride, (size_t)nc * c->matchStride, dead));
+        c->jobCap = nc;
+    }
+    if (needGapped > c->gjobCap) {
+        long long nc = c->gjobCap * 2; if (nc < needGapped) nc = needGapped + needGapped / 4 + 1024;
+        MTRY(regrow(c, stream, &c->d_gjobs, (size_t)usedGapped, (size_t)nc, dead));
+        MTRY(regrow(c, stream, &c->d_ggaps, (size_t)usedGapped, (size_t)nc, dead));
+        MTRY(regrow(c, stream, &c->d_ginfo, (size_t)usedGapped, (size_t)nc, dead));
+        MTRY(regrow(c, stream, &c->d_gresults, (size_t)usedGapped, (size_t)nc, dead));
+        MTRY(regrow(c, stream, &c->d_gmatch, (size_t)usedGapped * c->gmatchStride, (size_t)nc * c->gmatchStride, dead));
+        c->gjobCap = nc;
+    }
+    c->h_counters[32] = (unsigned)usedJobs; c->h_counters[33] = (unsigned)usedGapped;
+    MHIP(hipMemcpyAsync(c->d_counters, c->h_counters + 32, 8, hipMemcpyHostToDevice, stream));
+    MHIP(hipStreamSynchronize(stream));
+    for (void *q : dead) (void)hipFree(q);
+    D.jobs = c->d_jobs; D.jinfo = c->d_jinfo; D.results = c->d_results; D.jobCap = c->jobCap;
+    D.gjobs = c->d_gjobs; D.ggaps = c->d_ggaps; D.ginfo = c->d_ginfo; D.gresults = c->d_gresults; D.gjobCap = c->gjobCap;
+    c->stats.log_growths += 1.0f;              // (how often the logs grew in this batch)
     return BBMAP_OK;
 }
 
@@ -1326,11 +1381,13 @@ static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const 
             if (c->tier && c->h_counters[16] > 0 && c->tier->msa != c->msa) tier_start_async(c, c->h_counters[16]);     // (a tier that borrows the DP context runs after the pass)
         }
         add_dp_ms(c, ranPlainPrev, ranGappedPrev);
-        const long long total = c->h_counters[0], gtotal = c->h_counters[1];
-        if (total > c->jobCap || gtotal > c->gjobCap) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: job log full (raise bbmap_config.jobsPerRead)");
+        const long long asked = c->h_counters[0], gasked = c->h_counters[1];
+        const long long total = asked < c->jobCap ? asked : c->jobCap, gtotal = gasked < c->gjobCap ? gasked : c->gjobCap;     // entries really written
         MTRY(run_fills(c, stream, bases, jobBase, total - jobBase, gBase, gtotal - gBase));
         ranPlainPrev = total > jobBase; ranGappedPrev = gtotal > gBase;
         jobBase = total; gBase = gtotal;
+        // a log was too small: the reads that found no room ask again next round (emit_fill's NO_ROOM), after it has grown
+        if (asked > c->jobCap || gasked > c->gjobCap) MTRY(grow_logs(c, stream, D, asked, gasked, total, gtotal));
         nActive = c->h_counters[2];
         cur = 1 - cur; first = false;
         c->stats.rounds++;
@@ -1362,12 +1419,14 @@ static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const 
             MTRY(bbpipe_quick_rescue_device(stream, nsearch, c->d_rjobs, bases, (const int64_t *)c->d_chromOff, c->d_chromArrLen, c->d_chromMin, c->refsBase,
                                             c->d_rres, c->S.ptsMatch, c->S.ptsMatch2, 1, 100));
             MHIP(hipEventRecord(q1, stream));
+            // every search issues at most one fill, into either log: room for all of them before the kernel that writes them
+            if (jobBase + nsearch > c->jobCap || gBase + nsearch > c->gjobCap) MTRY(grow_logs(c, stream, D, jobBase + nsearch, gBase + nsearch, jobBase, gBase));
             hipLaunchKernelGGL(bbmapper::rescue_prep_kernel, dim3((unsigned)((pairs + TB - 1) / TB)), dim3(TB), 0, stream, D);
             MHIP(hipGetLastError());
             MTRY(read_counters(c, stream));
             { float ms = 0; if (hipEventElapsedTime(&ms, q0, q1) == hipSuccess) c->stats.ms_quick_rescue += ms; }
             const long long total = c->h_counters[0], gtotal = c->h_counters[1];
-            if (total > c->jobCap || gtotal > c->gjobCap) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: job log full (raise bbmap_config.jobsPerRead)");
+            if (total > c->jobCap || gtotal > c->gjobCap) return mfail(BBMAP_E_HIP, "bbmap_map_batch_device: rescue fills beyond the reserved log entries (internal error)");
             MTRY(run_fills(c, stream, bases, jobBase, total - jobBase, gBase, gtotal - gBase));
             const bool ranPlain = total > jobBase, ranGapped = gtotal > gBase;
             jobBase = total; gBase = gtotal;
@@ -1470,12 +1529,14 @@ extern "C" int bbmap_map_batch_device(bbmap_ctx *c, void *stream_, int64_t n_rea
     if (c->tier) c->tier->ran = false;
     const int rc = map_records(c, stream, n_reads, reads, bases, minus_delta, baseScores, keyinfo, true);
     hipEvent_t e0 = c->ev[10], e1 = c->ev[11];
-    if (rc == BBMAP_OK && c->tier) MHIP(hipEventRecord(e0, stream));
+    // the tier's helper thread is joined before anything else can return: a joinable std::thread left behind would terminate the
+    // process at the next batch's assignment
     if (c->tierStarted) {
         c->tierThread.join();
         if (rc == BBMAP_OK && c->tierRc != BBMAP_OK) return mfail(c->tierRc, c->tierErr);
     }
     MTRY(rc);
+    if (c->tier) MHIP(hipEventRecord(e0, stream));
     if (!c->tier || c->stats.reads_overflowed == 0) return BBMAP_OK;
     if (c->stats.reads_overflowed > c->overAfterBegin || !c->tierStarted) {
         // lists that outgrew max_sites in rescue: one more tier pass, over every flagged read
@@ -1506,7 +1567,9 @@ extern "C" int bbmap_pack_sites_device(bbmap_ctx *c, void *stream_, int64_t n_re
     MHIP(hipSetDevice(c->cfg.device));
     const long long n = n_reads;
     size_t need = 0;
-    MHIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, (const int *)counts, (long long *)offsets, (int)(n + 1), stream));
+    // (the scan's accumulator type follows its INPUT type: the counts go in as long long so that offsets beyond 2^31 records stay exact)
+    auto wide = hipcub::TransformInputIterator<long long, bbmapper::ToLL, const int *>((const int *)counts, bbmapper::ToLL());
+    MHIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, wide, (long long *)offsets, (int)(n + 1), stream));
     if (need > c->packTmpBytes) {
         if (c->d_packTmp) { MHIP(hipStreamSynchronize(stream)); (void)hipFree(c->d_packTmp); c->d_packTmp = nullptr; c->packTmpBytes = 0; }
         MHIP(hipMalloc(&c->d_packTmp, need));
@@ -1516,7 +1579,7 @@ extern "C" int bbmap_pack_sites_device(bbmap_ctx *c, void *stream_, int64_t n_re
     hipLaunchKernelGGL(bbmapper::pack_counts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c->d_mcount, n, counts);
     MHIP(hipGetLastError());
     MHIP(hipMemsetAsync(counts + n, 0, 4, stream));
-    MHIP(hipcub::DeviceScan::ExclusiveSum(c->d_packTmp, need, (const int *)counts, (long long *)offsets, (int)(n + 1), stream));
+    MHIP(hipcub::DeviceScan::ExclusiveSum(c->d_packTmp, need, wide, (long long *)offsets, (int)(n + 1), stream));
     const long long threads = n * c->cfg.max_sites * 8;
     hipLaunchKernelGGL(bbmapper::pack_sites_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, c->d_ms, c->d_mcount, (const long long *)offsets, n,
                        c->cfg.max_sites, (long long)packed_cap, packed);

@@ -189,7 +189,7 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     long long threads = budget / perThread;
     if (threads > 16384) threads = 16384;
     threads = (threads / 64) * 64;
-    if (threads < 64) threads = 64;
+    if (threads < 64) return fail(BBMAP_E_NOMEM, "bbmsa_create: BBMSA_GENERIC_SCRATCH_MB cannot hold one wavefront of scratch matrices for this maxRows x maxColumns");
     c->genThreads = (int)threads;
     HIP_TRY(hipMalloc(&c->d_matrix, (size_t)(threads * perThread)));
     HIP_TRY(hipMalloc(&c->d_limits, (size_t)(threads * (cfg->maxRows + cfg->maxColumns + 4) * 4)));

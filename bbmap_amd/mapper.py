@@ -39,7 +39,7 @@ class bbmap_stats(C.Structure):
                                          "rescue_scans", "rescue_fills", "rounds", "fills_dropped")] + \
                [(n, C.c_float) for n in ("ms_probe", "ms_begin", "ms_score", "ms_slow", "ms_finish", "ms_rescue", "ms_total",
                                          "ms_dp_narrow", "ms_dp_wave", "ms_dp_generic", "ms_dp_gapped", "ms_quick_rescue")] + \
-               [("probe_stats", C.c_int64 * 5), ("reads_reprobed", C.c_int64), ("ms_overflow", C.c_float), ("reserved_f", C.c_float)]
+               [("probe_stats", C.c_int64 * 5), ("reads_reprobed", C.c_int64), ("ms_overflow", C.c_float), ("log_growths", C.c_float)]
 
 
 class bbmap_overflow_output(C.Structure):
@@ -185,7 +185,7 @@ class Mapper:
     def stats(self):
         st = bbmap_stats()
         _lib.check(self.L.bbmap_last_stats(self.h, C.byref(st)), "bbmap_last_stats")
-        d = {n: getattr(st, n) for n, _ in bbmap_stats._fields_ if n not in ("probe_stats", "reserved_f")}
+        d = {n: getattr(st, n) for n, _ in bbmap_stats._fields_ if n not in ("probe_stats",)}
         d["probe_stats"] = list(st.probe_stats)
         return d
 

@@ -196,7 +196,7 @@ def _hip_copy(dst, src, nbytes, kind, stream):
     if nbytes > 0:
         rc = _HIP.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), nbytes, kind, C.c_void_p(stream))
         if rc != 0:
-            raise SystemExit("hipMemcpyAsync failed (%d)" % rc)
+            raise RuntimeError("hipMemcpyAsync failed (%d)" % rc)
 
 
 def streaming_region(mp, batches, steps, warmup):
@@ -244,7 +244,7 @@ def streaming_region(mp, batches, steps, warmup):
         o = mp.output_pointers()
         nj, ng = int(o.n_jobs), int(o.n_gapped_jobs)
         if nj > job_cap or ng > gjob_cap:
-            raise SystemExit("streaming_region: log staging buffers too small")
+            raise RuntimeError("streaming_region: log staging buffers too small")
         # the logs live in the mapper's buffers, which the next step overwrites: staged device to device, then sent from the stage
         pieces = [(o.jobs, nj * 40), (o.results, nj * 80), (o.jobinfo, nj * 16), (o.match, nj * o.match_stride),
                   (o.gjobs, ng * 40), (o.gresults, ng * 80), (o.gjobinfo, ng * 16), (o.ggaps, ng * 68), (o.gmatch, ng * o.gmatch_stride)]
@@ -254,7 +254,7 @@ def streaming_region(mp, batches, steps, warmup):
             off += nb
         total_sites = int(offsets[s][n].item())                    # (waits for the pack; the step itself is over)
         if total_sites > cap_rec:
-            raise SystemExit("streaming_region: packed site buffer too small")
+            raise RuntimeError("streaming_region: packed site buffer too small")
         out_ready[s].record(main)
         copy.wait_event(out_ready[s])
         h = host_out[s].data_ptr()
@@ -581,8 +581,13 @@ def main():
     # every rank draws its own shard of reads (same generator, different stream); the index is replicated per GPU
     reads = make_batch(chroms, n, paired, D.shard_seed(4, rank))
     log("reads ready")
-    offsets = W.make_offsets(L, k, 1.9)
-    key_scores = [100 * k] * len(offsets)          # GENERATE_KEY_SCORES_FROM_QUALITY needs qualities; synthetic reads have none
+    # Key offsets and scores as quickMap makes them for a read without qualities (AbstractMapThread.java:659-728 through the product's
+    # bbkeys_make): all key error probabilities 0, density window floor 1.5 -> 18 keys for 150 bases, every key score
+    # BASE_KEY_HIT_SCORE.  (Rounds 1-2 placed 22 keys with KeyRing.makeOffsets at density 1.9, the branch the reference only takes
+    # for reads WITH qualities when GENERATE_KEY_SCORES_FROM_QUALITY is off.)
+    from bbmap_amd import keys as K
+    kcfg = K.default_config(K.PROFILE_BBMAP, k=k)
+    offsets, key_scores, _ = K.make_keys(np.frombuffer(b"ACGT" * ((L + 3) // 4), np.uint8)[:L], None, kcfg)
 
     # BBMAP_BENCH_REHEARSE=1: every rank on GPU 0 and gloo instead of RCCL -- a way to run the N > 1 code path on a one-GPU box
     rehearse = os.environ.get("BBMAP_BENCH_REHEARSE") == "1"

@@ -484,7 +484,8 @@ typedef struct bbmap_config {
     int32_t msaMaxColumns;         /* columns of the MSA instance (3000 in the reference): limit of the second DP context */
     int32_t fastCols;              /* column limit of the first DP context, which takes the ordinary windows (0 = 256); wider
                                     * windows and gapped references go to the second context (the "gapped" log) */
-    int32_t jobsPerRead;           /* capacity of the job log = jobsPerRead * max_reads (0 = 3) */
+    int32_t jobsPerRead;           /* STARTING capacity of the job log = jobsPerRead * max_reads (0 = 3); the logs grow on demand.
+                                    * < 0: exactly -jobsPerRead entries in each log to start with (tests of the growth path) */
     int32_t reserved[4];           /* [0] != 0: strictly one fill per read and round (no fills ahead of time; for tests)
                                     * [1] overflow tier: reads it can hold per batch (0 = 4096, < 0 = no tier)
                                     * [2] overflow tier: its max_sites (0 = 1024)
@@ -516,7 +517,7 @@ typedef struct bbmap_stats {
     int64_t probe_stats[5];        /* bbidx_last_stats of the probe launch */
     int64_t reads_reprobed;        /* reads the overflow tier mapped (pairs count both mates); fills etc. above include the tier's */
     float ms_overflow;             /* the overflow tier's whole pass (included in ms_total) */
-    float reserved_f;
+    float log_growths;             /* times a fill log had to grow during the batch (the logs start at jobsPerRead entries per read) */
 } bbmap_stats;
 
 typedef struct bbmap_ctx bbmap_ctx;
@@ -529,6 +530,8 @@ int bbmap_default_config_profile(int32_t profile, bbmap_config *cfg);
  * call itself uses two internal streams and a helper thread (the overflow tier's pass runs beside the main one) and has joined
  * them when it returns.  Two contexts over the same index must not map at the same time (the probe keeps its queue and counters
  * in the index context). */
+/* Side effect on the borrowed index context: its quitAfterTwoPerfects tunable is set to !cfg->paired, as BBMap does with the index
+ * class's static (`if(paired){BBIndex.QUIT_AFTER_TWO_PERFECTS=false;}`, current/align2/BBMap.java:434). */
 int bbmap_create(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx **out);
 void bbmap_destroy(bbmap_ctx *ctx);
 /* Maps a batch that is resident on the device.  reads[i].bases_off addresses the plus strand inside `bases`; the call writes

@@ -23,8 +23,10 @@ reads = B.make_batch(chroms, n, paired, 4)
 t = time.time()
 di = DeviceIndex.build(chroms, k=13)
 print("index %.1fs" % (time.time() - t), flush=True)
-offs = W.make_offsets(150, 13, 1.9)
-mp = Mapper(di, n, 150, offs, [1300] * len(offs), paired=paired, max_sites=max_sites)
+import numpy as np
+from bbmap_amd import keys as K
+offs, ks, _ = K.make_keys(np.frombuffer(b"ACGT" * 38, np.uint8)[:150])       # quickMap's placement for a read without qualities: 18 keys
+mp = Mapper(di, n, 150, offs, ks, paired=paired, max_sites=max_sites)
 mp.load_reads(reads)
 for i in range(3):
     t = time.time()

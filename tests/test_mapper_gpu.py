@@ -192,3 +192,21 @@ def test_packed_site_lists_equal_the_padded_ones():
     assert int(small[100 * 128:].sum()) == 0 and small.cpu().numpy()[: 100 * 128].tobytes() == want[:100].tobytes()
     mp.close()
     di.close()
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_fill_logs_grow_instead_of_refusing_the_batch(paired):
+    """The reference's lists of fills have no capacity.  With logs that start at 64 entries (jobsPerRead = -64) the rounds run
+    into the end of both logs: the reads that find no room ask again after the host has grown the log, rescue
+    reserves its entries beforehand, and every site list, fill and traceback string still equals the oracle's."""
+    L, k = 150, 12
+    ref = W.make_reference(300000, seed=5, pad=2000, repeat_frac=0.15)
+    if paired:
+        reads, _ = W.make_pairs(ref, 1500, read_len=L, seed=4, pad=2000, hard_frac=0.08)
+    else:
+        reads, _, _ = W.make_reads_and_jobs(ref, 3000, read_len=L, seed=9, pad=2000, long_del_frac=0.3, hard_frac=0.05)
+    out, orc, st, n = _run(ref, reads, L, k, paired=paired, jobsPerRead=-64)
+    assert st["log_growths"] >= 1 and st["fills"] > 64 and st["gapped_fills"] > (0 if paired else 64)
+    assert st["reads_overflowed"] == 0
+    bad = compare(out, orc, n, paired=paired)
+    assert not bad, "\n".join(bad[:20])
