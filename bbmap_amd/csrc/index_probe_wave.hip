@@ -1507,7 +1507,9 @@ template <bool LONG, int WLEN> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK
             if (lane < n) { offM = blen - (so + p.k); keyM = rc_key(sk, p.k); kscM = ss; }
         }
         // every (block, strand) cycle reloads the fused records of its keys: 32 bytes per key lane, two vector loads.  (Parking block
-        // 0's records in LDS saved the reload but cost 2 KB per wave, which the cycle's presence maps make better use of.)
+        // 0's records in LDS saved the reload but cost 2 KB per wave, which the cycle's presence maps make better use of.  Round 3:
+        // one load per block held in registers across its two strands, with the next block's records requested ahead, cost 8 more
+        // live VGPRs: 62.8 -> 71.7 ms at 5 waves per SIMD (spills), 88.7 -> 72.2 ms at 4 -- the reload is the cheaper choice.)
         auto keyHits = [&](int block, int strand) -> KeyHit {
             KeyEntry eb; eb.cnt = eb.cntRC = eb.startF = eb.lenF = eb.firstF = eb.startR = eb.lenR = eb.firstR = 0;
             if (lane < n && key >= 0) eb = ix.fused[block][key];

@@ -1179,6 +1179,8 @@ static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *par
         gc = mc;
         gc.maxColumns = cfg->msaMaxColumns;
         gc.reserved[0] = 64; gc.reserved[1] = 640 < gc.maxColumns ? 640 : gc.maxColumns;
+        if (const char *e = getenv("BBMAP_G2_LANES")) { if (*e) gc.reserved[0] = atoi(e); }          // experiments: geometry of the second context
+        if (const char *e = getenv("BBMAP_G2_COLS")) { if (*e) gc.reserved[1] = atoi(e) < gc.maxColumns ? atoi(e) : gc.maxColumns; }
         (void)parent;                   // the tier runs beside its parent's pass: DP contexts of its own
         c->ownsMsa = true;
         if ((rc = bbmsa_create(&mc, &c->msa)) != BBMAP_OK) return bail(rc);

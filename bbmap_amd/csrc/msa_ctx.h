@@ -10,7 +10,7 @@ struct bbmsa_ctx {
     int numCUs;
     int scheme;                 // BBMSA_SCHEME_*
     // fast kernel geometry
-    int G, R, fastCols, tmpBytes, blocks, ldsBytes, tableLen;
+    int G, R, fastCols, tmpBytes, blocks, ldsBytes, tableLen, wideTableLen;
     long long dirSlotDwords;
     unsigned int *d_dir;
     unsigned int *d_counters;   // [0]=fast queue, [1]=slow count, [2]=generic queue

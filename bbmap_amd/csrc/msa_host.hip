@@ -154,12 +154,16 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     c->tmpBytes = ((G * c->R + fastCols + 8) + 3) & ~3;
     const int jobsPerWave = 64 / G;
     const int perJobInts = (fastCols + 2) * 2 + c->tmpBytes / 4;
-    {   // index = time + needed: time <= min(longer side + 1, 2047 (clamped)), needed <= rows
+    {   // index = time + needed: time <= min(longer side + 1, 2047 (clamped)), needed <= rows.  The first pass only takes windows of
+        // up to fastCols columns, so its tables are sized for those; the wide pass has its own (wideTableLen).
         const int side = (cfg->maxColumns > cfg->maxRows ? cfg->maxColumns : cfg->maxRows) + 2;
-        c->tableLen = (side < 2048 ? side : 2048) + cfg->maxRows + 8;
+        c->wideTableLen = (side < 2048 ? side : 2048) + cfg->maxRows + 8;
+        const int sideF = (fastCols > cfg->maxRows ? fastCols : cfg->maxRows) + 2;
+        c->tableLen = (sideF < 2048 ? sideF : 2048) + cfg->maxRows + 8;
     }
     if (c->tableLen > bbmsa::kTableLen) c->tableLen = bbmsa::kTableLen;
-    c->tableLen = (c->tableLen + 3) & ~3;
+    if (c->wideTableLen > bbmsa::kTableLen) c->wideTableLen = bbmsa::kTableLen;
+    c->tableLen = (c->tableLen + 3) & ~3; c->wideTableLen = (c->wideTableLen + 3) & ~3;
     c->ldsBytes = (bbmsa::lds_table_ints(c->tableLen) + 4 * jobsPerWave * perJobInts) * 4;
     if (c->ldsBytes > 160 * 1024) return fail(BBMAP_E_ARG, "bbmsa_create: fast-path LDS budget exceeded; lower reserved[1] (fastCols)");
 
@@ -200,7 +204,7 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
         c->wideCols = cfg->maxColumns;
         c->wideTmpBytes = ((64 * c->wideR + c->wideCols + 8) + 3) & ~3;
         const int perJob = (c->wideCols + 2) * 2 + c->wideTmpBytes / 4;
-        c->wideLdsBytes = (bbmsa::lds_table_ints(c->tableLen) + perJob) * 4;
+        c->wideLdsBytes = (bbmsa::lds_table_ints(c->wideTableLen) + perJob) * 4;
         const void *wfn = bbmsa::fast_kernel_for(c->wideR, c->banded);
         if (wfn && c->wideLdsBytes <= 160 * 1024) {
             if (c->wideLdsBytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(wfn, hipFuncAttributeMaxDynamicSharedMemorySize, c->wideLdsBytes));
@@ -363,7 +367,7 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
         wp.queue = c->d_counters + 8; wp.dirbuf = c->d_wideDir; wp.dir_slot_dwords = c->wideDirSlotDwords;
         wp.list = c->d_slowList; wp.list_count = c->d_counters + 1;
         wp.slow_list = c->d_slowList2; wp.slow_count = c->d_counters + 7;
-        wp.lanesPerJob = 64; wp.fastCols = c->wideCols; wp.tmpBytes = c->wideTmpBytes;
+        wp.lanesPerJob = 64; wp.fastCols = c->wideCols; wp.tmpBytes = c->wideTmpBytes; wp.tableLen = c->wideTableLen;
         void *wargs[] = {&wp};
         HIP_TRY(hipLaunchKernel(bbmsa::fast_kernel_for(c->wideR, c->banded), dim3((unsigned)c->wideBlocks), dim3(64), wargs, (size_t)c->wideLdsBytes, stream));
         genList = c->d_slowList2; genCount = c->d_counters + 7;

@@ -26,7 +26,11 @@ print("index %.1fs" % (time.time() - t), flush=True)
 import numpy as np
 from bbmap_amd import keys as K
 offs, ks, _ = K.make_keys(np.frombuffer(b"ACGT" * 38, np.uint8)[:150])       # quickMap's placement for a read without qualities: 18 keys
-mp = Mapper(di, n, 150, offs, ks, paired=paired, max_sites=max_sites)
+import os
+extra = {}
+if os.environ.get("BBMAP_FASTCOLS"):
+    extra["fastCols"] = int(os.environ["BBMAP_FASTCOLS"])
+mp = Mapper(di, n, 150, offs, ks, paired=paired, max_sites=max_sites, **extra)
 mp.load_reads(reads)
 for i in range(3):
     t = time.time()
@@ -34,3 +38,12 @@ for i in range(3):
     wall = time.time() - t
     st = mp.stats()
     print(json.dumps({"wall_ms": 1e3 * wall, **{k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}}), flush=True)
+
+import os
+if os.environ.get("BBMAP_G2_HIST"):
+    out = mp.fetch(with_match=False)
+    g = out["gjobs"]
+    w = (np.minimum(g["ref_len"] - 1, g["refEndLoc"]) - np.maximum(0, g["refStartLoc"]) + 1)
+    ng = out["ggaps"]["ngaps"]
+    print("gapped widths: n=%d with gap array %d; columns pct 10/50/90/99/max = %s; share <=384 %.3f <=512 %.3f <=640 %.3f" % (
+        len(g), int((ng > 0).sum()), np.percentile(w, [10, 50, 90, 99, 100]).astype(int).tolist(), (w <= 384).mean(), (w <= 512).mean(), (w <= 640).mean()), flush=True)
