@@ -1178,7 +1178,7 @@ static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *par
         c->plainColumns = mc.maxColumns;
         gc = mc;
         gc.maxColumns = cfg->msaMaxColumns;
-        gc.reserved[0] = 64; gc.reserved[1] = 640 < gc.maxColumns ? 640 : gc.maxColumns;
+        gc.reserved[0] = 32; gc.reserved[1] = 640 < gc.maxColumns ? 640 : gc.maxColumns;      // (32 lanes x 5 rows per job: 80 vs 85 ms of scoreSlow with sh/randomreads.sh's deletions; bbmsa_create widens the group for longer reads)
         if (const char *e = getenv("BBMAP_G2_LANES")) { if (*e) gc.reserved[0] = atoi(e); }          // experiments: geometry of the second context
         if (const char *e = getenv("BBMAP_G2_COLS")) { if (*e) gc.reserved[1] = atoi(e) < gc.maxColumns ? atoi(e) : gc.maxColumns; }
         (void)parent;                   // the tier runs beside its parent's pass: DP contexts of its own

@@ -50,13 +50,17 @@ def make_reference(length, seed, pad=START_PAD, repeat_frac=0.0, families=2000):
 def make_reads_and_jobs(ref, n_reads, read_len=150, seed=2, pad=START_PAD, align_pad=4,
                         min_ratio=0.56, perfect_frac=0.5, flags=FILL_AND_SCORE_LIMITED | DO_TRACEBACK,
                         chunk=131072, max_del=40, max_ins=12, long_del_frac=0.0, long_del=(300, 800), starts=None,
-                        hard_frac=0.0):
+                        hard_frac=0.0, del_model="short"):
     """Returns (reads_blob uint8[n*read_len... variable], jobs structured array, truth dict).  starts: read start
     coordinates to use instead of drawing them; hard_frac: share of the reads that additionally get 8-12 % substitutions
-    (mates the index probe tends to miss and the paired rescue has to find)."""
+    (mates the index probe tends to miss and the paired rescue has to find).  del_model: "short" = geometric lengths capped at
+    max_del (plus long_del_frac); "randomreads" = the reference generator's own draw, 1 + min(U[0, 399], U[0, 399]) with
+    maxdellen 400 (RandomReads3.makeDelsa, current/align2/RandomReads3.java:809-820; sh/randomreads.sh:64-78)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     n = n_reads
     body = len(ref) - 2 * pad
+    if del_model == "randomreads":
+        max_del = 400
     reach = max(max_del, long_del[1] if long_del_frac > 0 else 0)
     start = rng.integers(pad, pad + body - read_len - reach - 8, size=n, dtype=np.int64)
     if starts is not None:
@@ -69,6 +73,8 @@ def make_reads_and_jobs(ref, n_reads, read_len=150, seed=2, pad=START_PAD, align
     has_n = imperfect & (rng.random(n) < 0.2)
     # geometric-ish indel lengths, short ones most common
     del_len = np.where(has_del, np.minimum(max_del, rng.geometric(0.25, size=n)), 0).astype(np.int64)
+    if del_model == "randomreads":
+        del_len = np.where(has_del, 1 + np.minimum(rng.integers(0, 400, size=n), rng.integers(0, 400, size=n)), 0).astype(np.int64)
     if long_del_frac > 0:                        # long deletions (sh/randomreads.sh maxdellen): the probe reports gap arrays
         is_long = has_del & (rng.random(n) < long_del_frac)
         del_len = np.where(is_long, rng.integers(long_del[0], long_del[1] + 1, size=n), del_len).astype(np.int64)
@@ -142,7 +148,7 @@ def revcomp_rows(reads2d):
     return _COMP[reads2d[:, ::-1]]
 
 
-def make_pairs(ref, n_pairs, read_len=150, seed=3, pad=START_PAD, hard_frac=0.03, middle=(-100, 100)):
+def make_pairs(ref, n_pairs, read_len=150, seed=3, pad=START_PAD, hard_frac=0.03, middle=(-100, 100), del_model="short"):
     """Synthetic read pairs as randomreads.sh makes them (current/align2/RandomReads3.java:1726-1727 mateMiddleMin/Max = -100/100,
     mates on opposite strands): the unsequenced middle between the mates is triangular on [-100, 100] (negative = the mates
     overlap), each mate carries the mutated mix of make_reads_and_jobs, a share hard_frac of the mates is additionally riddled
@@ -152,10 +158,10 @@ def make_pairs(ref, n_pairs, read_len=150, seed=3, pad=START_PAD, hard_frac=0.03
     rng = np.random.Generator(np.random.PCG64(seed))
     body = len(ref) - 2 * pad
     mid = np.rint(rng.triangular(middle[0], 0.5 * (middle[0] + middle[1]), middle[1], size=n_pairs)).astype(np.int64)
-    left = rng.integers(pad, pad + body - 2 * read_len - middle[1] - 64, size=n_pairs, dtype=np.int64)
+    left = rng.integers(pad, pad + body - 2 * read_len - middle[1] - 64 - (400 if del_model == "randomreads" else 0), size=n_pairs, dtype=np.int64)
     right = left + read_len + mid
-    ra, _, ta = make_reads_and_jobs(ref, n_pairs, read_len=read_len, seed=seed * 7919 + 1, pad=pad, starts=left, hard_frac=hard_frac)
-    rb, _, tb = make_reads_and_jobs(ref, n_pairs, read_len=read_len, seed=seed * 7919 + 2, pad=pad, starts=right, hard_frac=hard_frac)
+    ra, _, ta = make_reads_and_jobs(ref, n_pairs, read_len=read_len, seed=seed * 7919 + 1, pad=pad, starts=left, hard_frac=hard_frac, del_model=del_model)
+    rb, _, tb = make_reads_and_jobs(ref, n_pairs, read_len=read_len, seed=seed * 7919 + 2, pad=pad, starts=right, hard_frac=hard_frac, del_model=del_model)
     ra = ra.reshape(n_pairs, read_len)
     rb = revcomp_rows(rb.reshape(n_pairs, read_len))              # the right-hand mate is read from the other strand
     flip = rng.random(n_pairs) < 0.5                               # fragment from the minus strand: mate 1 is the right-hand one

@@ -111,6 +111,9 @@ def shared_reference(name, lens, repeat_frac, local_rank, world_local):
     return chroms, None
 
 
+DEL_MODEL = "randomreads"      # deletions as sh/randomreads.sh draws them (1..400 bases); "short" = rounds 1-2's cap of 40
+
+
 def make_batch(chroms, n_reads, paired, seed):
     """n_reads reads (n_reads / 2 pairs) drawn from the chromosomes in proportion to their lengths."""
     from bbmap_amd import workload as W
@@ -124,9 +127,9 @@ def make_batch(chroms, n_reads, paired, seed):
         if m <= 0:
             continue
         if paired:
-            parts.append(W.make_pairs(c, int(m), read_len=L, seed=seed + 7 * i)[0].reshape(-1, 2 * L))
+            parts.append(W.make_pairs(c, int(m), read_len=L, seed=seed + 7 * i, del_model=DEL_MODEL)[0].reshape(-1, 2 * L))
         else:
-            parts.append(W.make_reads_and_jobs(c, int(m), read_len=L, seed=seed + 7 * i)[0].reshape(-1, L))
+            parts.append(W.make_reads_and_jobs(c, int(m), read_len=L, seed=seed + 7 * i, del_model=DEL_MODEL)[0].reshape(-1, L))
     allp = np.concatenate(parts)
     perm = np.random.Generator(np.random.PCG64(seed)).permutation(len(allp))      # mix the chromosomes within the batch
     return np.ascontiguousarray(allp[perm]).reshape(-1)
