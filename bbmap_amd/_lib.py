@@ -13,7 +13,7 @@ SO_PATH = os.path.join(HERE, "libbbmap_amd.so")
 EXPORTS = [
     "bbmap_last_error", "bbmap_abi_version",
     "bbmsa_create", "bbmsa_destroy", "bbmsa_align_batch_device", "bbmsa_align_batch",
-    "bbmsa_fill_packed", "bbmsa_last_kernel_ms", "bbmsa_last_kernel_ms3", "bbmsa_last_counts", "bbmsa_align_gapped_batch_device", "bbmsa_align_gapped_batch", "bbmsa_align_batch_device_indirect",
+    "bbmsa_fill_packed", "bbmsa_fill_submit", "bbmsa_fill_collect", "bbmsa_legacy_stats", "bbmsa_last_kernel_ms", "bbmsa_last_kernel_ms3", "bbmsa_last_counts", "bbmsa_align_gapped_batch_device", "bbmsa_align_gapped_batch", "bbmsa_align_batch_device_indirect",
     "bbmsa_align_gapped_batch_device_indirect",
     "bbband_create", "bbband_destroy", "bbband_align_batch_device", "bbband_align_batch",
     "bbband_align_quadruple_batch", "bbband_align_quadruple_progressive_batch", "bbband_align_double_batch",
@@ -104,6 +104,13 @@ def load():
     L.bbmsa_fill_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
     L.bbmsa_fill_packed.restype = C.c_int
+    L.bbmsa_fill_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
+    L.bbmsa_fill_submit.restype = C.c_int
+    L.bbmsa_fill_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bbmsa_fill_collect.restype = C.c_int
+    L.bbmsa_legacy_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.bbmsa_legacy_stats.restype = C.c_int
     L.bbmsa_last_kernel_ms3.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.bbmsa_last_kernel_ms3.restype = C.c_int
     L.bbmsa_last_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]

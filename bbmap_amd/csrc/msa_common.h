@@ -140,6 +140,13 @@ struct FillParams {
     int maxRows, maxColumns;      // context limits (MSA(maxRows_, maxColumns_))
     int bandwidth;
     float bandwidthRatio;
+    // matrix-materialising mode (the legacy per-call JNI shape, msa_legacy.hip; kernels instantiated with MAT only): job j's three
+    // score planes go to planes + plane_off[j], each rows x columns ints (state-major; rows 1..rows, columns 1..columns of the matrix), its
+    // vertLimit[0..rows] / horizLimit[0..columns] to limits + limits_off[j] (rows + 1 ints, then columns + 1)
+    int *planes;
+    const long long *plane_off;
+    int *limits;
+    const long long *limits_off;
 };
 
 // one job per lane, a band of diagonals in registers (msa_fill_narrow.hip)

@@ -39,7 +39,8 @@ struct bbmsa_ctx {
     hipEvent_t ev[4];      // start, after wavefront kernel, after generic kernel, after narrow kernel
     bool timed;
     bool banded;
-    bool legacyOnly;            // created with BBMSA_LEGACY_ONLY: bbmsa_fill_packed only
+    bool legacyOnly;            // created with BBMSA_LEGACY_ONLY: bbmsa_fill_submit / _collect / _packed only
+    struct bbmsa_legacy *legacy;   // the per-call service of such a context (msa_legacy.hip)
     // strip-tiled wavefront kernel of the 9PacBio scheme (msa_fill_strip.hip)
     int stripBlocks, stripLds;
     long long stripDwords, stripSlotDwords;
@@ -47,3 +48,7 @@ struct bbmsa_ctx {
     uint8_t *d_stripTmp;
 };
 
+
+// msa_legacy.hip: persistent buffers, stream and the call combiner of a BBMSA_LEGACY_ONLY context (c->d_matrix / d_limits exist)
+int bbmsa_legacy_create(bbmsa_ctx *c);
+void bbmsa_legacy_destroy(bbmsa_ctx *c);

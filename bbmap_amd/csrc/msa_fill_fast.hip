@@ -65,7 +65,11 @@ __device__ __forceinline__ unsigned load_coherent(const unsigned *p) {
 #define BBMSA_MIN_WAVES(R) ((R) <= 5 ? 4 : ((R) <= 7 ? 2 : 1))
 #endif
 
-template <int R, bool BANDED>
+// MAT: also write every computed cell's three planes (12 bytes per cell) and the two limit vectors -- what the reference's native
+// code leaves in the Java class's `packed` matrix for score2 / traceback2 to walk (jni/MultiStateAligner11tsJNI.c:124-127, :707-812).
+// A cell that is visited but not "good" is stored as subfloor | time, as the reference stores it (:556-562); cells this schedule
+// computes beyond a row's end are stored as subfloor -- the reference leaves those untouched, and never reads them (its sentinels).
+template <int R, bool BANDED, bool MAT = false>
 __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(const FillParams p) {
     extern __shared__ int lds[];
     int *delC = lds;
@@ -166,6 +170,8 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
 
         const uint8_t *rd = p.reads + jb.read_off;
         const uint8_t *rf = p.refs + jb.ref_off + a;       // rf[c-1] is the reference byte of column c
+        int *planeM = nullptr; long long planeInts = 0; int planeW = 0;
+        if (MAT && valid) { planeW = columns; planeInts = (long long)rows * planeW; planeM = p.planes + p.plane_off[j]; }      // cell (row, c) at (row - 1) * columns + c - 1
 
         const int maxGain = (rows - 1) * P_MATCH2 + P_MATCH;
         const int minScoreOff = minScore * 2048;
@@ -212,6 +218,16 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 suffix += cst[k];
                 vlim[k] = limited ? max(minScoreOff - suffix, floorv) : kNegInf;
             }
+            if (MAT && run && limited) {                                 // vertLimit[0..rows], jni/...c:413-425
+                int *vout = p.limits + p.limits_off[j];
+#pragma unroll
+                for (int k = 0; k < R; k++) if (r0 + k < rows) vout[r0 + k] = vlim[k];
+                if (gl == 0) {
+                    vout[rows] = minScoreOff;
+                    const int c0 = fully_defined(call1[0]) ? ((rows > 1 && fully_defined(idxByte[0])) ? P_MATCH2 : P_MATCH) : 0;
+                    vout[0] = rows > 1 ? max(vlim[0] - c0, floorv) : max(minScoreOff - c0, floorv);
+                }
+            }
         }
 
         // column info into LDS: reference bytes by the whole group, horizLimit by its first lane
@@ -230,7 +246,9 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const int cost = def ? (prevDef ? P_MATCH2 : P_MATCH) : ((prevDef && cb == '-') ? P_DEL : 0);
                 h = max(h - cost, floorv);
                 prevDef = def;
+                if (MAT && limited) p.limits[p.limits_off[j] + rows + 1 + i + 1] = colinfo[i + 1].x - 2048;      // horizLimit[i + 1]
             }
+            if (MAT && limited) p.limits[p.limits_off[j] + rows + 1] = h;                                        // horizLimit[0]
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -390,6 +408,18 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const int penI = needDel ? pen0 : x2;
                 const bool goodI = !pruneI & (scoreI + penI >= limit);
                 const int nI = goodI ? (scoreI | timeI) : pruneVal;
+                if (MAT) {
+                    if (inRange & rowValid[k]) {
+                        int *cellp = planeM + (long long)(row - 1) * planeW + (c - 1);
+                        const int tD = timeD > kMaxTime ? kMaxTime - 3 : timeD;
+                        // (the reference clamps the stored time at MAX_TIME - MASK5 in every plane, :563, :618, :659)
+                        // skipped by the prune test: plain subfloor (:486, :567, :620); computed but below the limit: subfloor | time
+                        const int sM = pruneM ? pruneVal : (goodM ? nM : (pruneVal | (timeM > kMaxTime ? kMaxTime - 3 : timeM)));
+                        const int sD = pruneD ? pruneVal : (goodD ? nD : (pruneVal | tD));
+                        const int sI = pruneI ? pruneVal : (goodI ? nI : (pruneVal | (timeI > kMaxTime ? kMaxTime - 3 : timeI)));
+                        cellp[0] = sM; cellp[planeInts] = sD; cellp[2 * planeInts] = sI;
+                    }
+                }
 
                 // ---- traceback record (MultiStateAligner11tsJNI.java:389-443): what traceback2 would decide here
                 const bool msStay = (timeM > 1) | (sdm >= mDI);
@@ -645,6 +675,14 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
 BBMSA_INST(1) BBMSA_INST(2) BBMSA_INST(3) BBMSA_INST(4) BBMSA_INST(5)
 BBMSA_INST(6) BBMSA_INST(7) BBMSA_INST(8) BBMSA_INST(9) BBMSA_INST(10)
 
+#define BBMSA_CASE_MAT(R) case R: return banded ? (const void *)msa_fill_fast_kernel<R, true, true> : (const void *)msa_fill_fast_kernel<R, false, true>;
+const void *fast_kernel_mat_for(int R, bool banded) {
+    switch (R) {
+        BBMSA_CASE_MAT(1) BBMSA_CASE_MAT(2) BBMSA_CASE_MAT(3) BBMSA_CASE_MAT(4) BBMSA_CASE_MAT(5)
+        BBMSA_CASE_MAT(6) BBMSA_CASE_MAT(7) BBMSA_CASE_MAT(8) BBMSA_CASE_MAT(9) BBMSA_CASE_MAT(10)
+    }
+    return nullptr;
+}
 #define BBMSA_CASE(R) case R: return banded ? (const void *)msa_fill_fast_kernel<R, true> : (const void *)msa_fill_fast_kernel<R, false>;
 const void *fast_kernel_for(int R, bool banded) {
     switch (R) {

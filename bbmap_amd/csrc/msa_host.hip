@@ -93,6 +93,7 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
         HIP_TRY(hipMalloc(&c->d_matrix, (size_t)(3 * planeInts * 4)));
         HIP_TRY(hipMalloc(&c->d_limits, (size_t)((cfg->maxRows + cfg->maxColumns + 4) * 4)));
         for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+        { const int rc = bbmsa_legacy_create(c); if (rc != BBMAP_OK) return rc; }
         guard.c = nullptr;
         *out = c;
         return BBMAP_OK;
@@ -238,6 +239,7 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
 extern "C" void bbmsa_destroy(bbmsa_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    bbmsa_legacy_destroy(c);
     if (c->d_dir) (void)hipFree(c->d_dir);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_slowList) (void)hipFree(c->d_slowList);
@@ -463,68 +465,4 @@ done:
     if (d_match) (void)hipFree(d_match);
     return rc;
 #undef TRY_GOTO
-}
-
-// Legacy per-call shape (jni/MultiStateAligner11tsJNI.c:707-812): ONE fill whose three score planes are written into the
-// caller's `packed` array, laid out as the Java class allocates it (3 x (maxRows+1) x (maxColumns+1) ints, state-major,
-// current/align2/MultiStateAligner11tsJNI.java:71-113), so that the Java-side score2 / traceback2 can read it.  The fill runs
-// in the generic kernel (one thread, planes in HBM) and the touched rectangle (rows 0..rows, columns 0..columns+1) is copied
-// back plane by plane.  This is the drop-in path for the unmodified Java class; it is slow by construction
-// and exists for completeness -- the batched entry points are the product.
-extern "C" int bbmsa_fill_packed(bbmsa_ctx *c, const uint8_t *read, int32_t read_len, const uint8_t *ref, int32_t ref_len,
-                                 int32_t refStartLoc, int32_t refEndLoc, int32_t minScore, int32_t mode,
-                                 int32_t *result5, int64_t *iterations, int32_t *packed) {
-    if (!c || !read || !ref || !result5 || !packed) return fail(BBMAP_E_ARG, "bbmsa_fill_packed: null argument");
-    if (mode != BBMSA_FILL_LIMITED_RAW && mode != BBMSA_FILL_UNLIMITED_RAW) return fail(BBMAP_E_ARG, "bbmsa_fill_packed: mode must be one of the two raw fills");
-    const int rows = read_len, columns = refEndLoc - refStartLoc + 1;
-    if (rows < 1 || columns < 1 || rows > c->cfg.maxRows || columns > c->cfg.maxColumns || refStartLoc < 0 || refEndLoc >= ref_len)
-        return fail(BBMAP_E_SHAPE, "bbmsa_fill_packed: problem exceeds the context limits or its reference array");
-    HIP_TRY(hipSetDevice(c->device));
-    bbmsa_job job;
-    job.read_off = 0; job.ref_off = 0; job.read_len = read_len; job.ref_len = ref_len;
-    job.refStartLoc = refStartLoc; job.refEndLoc = refEndLoc; job.minScore = minScore; job.flags = mode;
-    bbmsa_job *d_job = nullptr; uint8_t *d_read = nullptr, *d_ref = nullptr; bbmsa_result *d_res = nullptr;
-    int rc = BBMAP_OK;
-    bbmsa_result res;
-#define PK_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(g_err, sizeof g_err, "%s failed: %s", #expr, hipGetErrorString(e_)); rc = BBMAP_E_HIP; goto done; } } while (0)
-    {
-        PK_TRY(hipMalloc(&d_job, sizeof job));
-        PK_TRY(hipMalloc(&d_read, (size_t)read_len));
-        PK_TRY(hipMalloc(&d_ref, (size_t)ref_len));
-        PK_TRY(hipMalloc(&d_res, sizeof res));
-        PK_TRY(hipMemcpy(d_job, &job, sizeof job, hipMemcpyHostToDevice));
-        PK_TRY(hipMemcpy(d_read, read, (size_t)read_len, hipMemcpyHostToDevice));
-        PK_TRY(hipMemcpy(d_ref, ref, (size_t)ref_len, hipMemcpyHostToDevice));
-        PK_TRY(hipMemset(c->d_counters, 0, 64));
-        bbmsa::GenericParams gp;
-        gp.jobs = d_job; gp.reads = d_read; gp.refs = d_ref; gp.results = d_res; gp.match = nullptr;
-        gp.list = nullptr; gp.list_count = nullptr; gp.njobs = 1; gp.njobs_dev = nullptr;
-        gp.matrix = c->d_matrix; gp.limits = c->d_limits; gp.queue = c->d_counters + 2;
-        gp.match_stride = 0; gp.maxRows = c->cfg.maxRows; gp.maxColumns = c->cfg.maxColumns;
-        gp.bandwidth = c->cfg.bandwidth; gp.bandwidthRatio = c->cfg.bandwidthRatio;
-        if (c->scheme == BBMSA_SCHEME_9PACBIO)
-            hipLaunchKernelGGL(bbmsa::msa_fill_generic_kernel<bbmsa::Scheme9PacBio>, dim3(1), dim3(1), 0, nullptr, gp);
-        else
-            hipLaunchKernelGGL(bbmsa::msa_fill_generic_kernel<bbmsa::Scheme11ts>, dim3(1), dim3(1), 0, nullptr, gp);  // thread 0 owns scratch slot 0
-        PK_TRY(hipGetLastError());
-        PK_TRY(hipStreamSynchronize(nullptr));
-        PK_TRY(hipMemcpy(&res, d_res, sizeof res, hipMemcpyDeviceToHost));
-        const size_t planeInts = (size_t)(c->cfg.maxRows + 1) * (size_t)(c->cfg.maxColumns + 2);
-        const size_t W = (size_t)columns + 2;                       // the kernel's row stride for this job
-        const size_t dstPitch = ((size_t)c->cfg.maxColumns + 1) * 4;
-        size_t width = W; if (width > (size_t)c->cfg.maxColumns + 1) width = (size_t)c->cfg.maxColumns + 1;
-        for (int s = 0; s < 3; s++) {
-            int32_t *dst = packed + (size_t)s * (size_t)(c->cfg.maxRows + 1) * (size_t)(c->cfg.maxColumns + 1);
-            PK_TRY(hipMemcpy2D(dst, dstPitch, c->d_matrix + (size_t)s * planeInts, W * 4, width * 4, (size_t)rows + 1, hipMemcpyDeviceToHost));
-        }
-        for (int i = 0; i < 5; i++) result5[i] = res.result[i];
-        if (iterations) *iterations += res.iterations;              // the native code increments, jni/...c:471,:746
-    }
-done:
-    if (d_job) (void)hipFree(d_job);
-    if (d_read) (void)hipFree(d_read);
-    if (d_ref) (void)hipFree(d_ref);
-    if (d_res) (void)hipFree(d_res);
-    return rc;
-#undef PK_TRY
 }

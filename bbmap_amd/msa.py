@@ -32,19 +32,24 @@ assert JOB_DTYPE.itemsize == C.sizeof(bbmsa_job) and RESULT_DTYPE.itemsize == C.
 assert GAPS_DTYPE.itemsize == 68
 
 
+class bbmsa_ticket(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("slot", C.c_int32), ("gen", C.c_int64), ("rows", C.c_int32), ("columns", C.c_int32)]
+
+
 SCHEME_11TS, SCHEME_9PACBIO = 0, 1      # BBMSA_SCHEME_* (include/bbmap_amd.h)
+LEGACY_ONLY = 0x100                     # BBMSA_LEGACY_ONLY: a context for the per-call fills (fill_packed) only
 
 
 class MSAContext:
     """Owns a bbmsa_ctx (one per device and per (maxRows, maxColumns, band) setting)."""
 
     def __init__(self, maxRows=601, maxColumns=3000, bandwidth=0, bandwidthRatio=0.0, device=0,
-                 lanes_per_job=0, fast_cols=0, scheme=SCHEME_11TS):
+                 lanes_per_job=0, fast_cols=0, scheme=SCHEME_11TS, legacy=False):
         self.L = _lib.load()
         cfg = bbmsa_config()
         cfg.device, cfg.maxRows, cfg.maxColumns = device, maxRows, maxColumns
         cfg.bandwidth, cfg.bandwidthRatio = bandwidth, bandwidthRatio
-        cfg.reserved[0], cfg.reserved[1], cfg.reserved[2] = lanes_per_job, fast_cols, scheme
+        cfg.reserved[0], cfg.reserved[1], cfg.reserved[2] = lanes_per_job, fast_cols, scheme | (LEGACY_ONLY if legacy else 0)
         h = C.c_void_p()
         _lib.check(self.L.bbmsa_create(C.byref(cfg), C.byref(h)), "bbmsa_create")
         self.h = h
@@ -91,18 +96,30 @@ class MSAContext:
         _lib.check(rc, "bbmsa_align_gapped_batch")
         return res, match
 
-    def fill_packed(self, read, ref, a, b, minScore, limited, packed):
-        """The legacy per-call fill: writes the planes into `packed` (int32 array of 3*(maxRows+1)*(maxColumns+1)).
-        Returns (result[5], iterations)."""
+    def fill_packed(self, read, ref, a, b, minScore, limited, packed, limits=False):
+        """The legacy per-call fill (context made with legacy=True): writes the planes into `packed` (int32 array of
+        3*(maxRows+1)*(maxColumns+1)).  Returns (result[5], iterations), and with limits=True also (vertLimit, horizLimit).
+        Thread-safe: concurrent calls on one context are combined into one launch."""
         r = np.frombuffer(bytes(read), np.uint8)
         f = np.frombuffer(bytes(ref), np.uint8)
         res = np.zeros(5, np.int32)
         it = C.c_int64(0)
-        rc = self.L.bbmsa_fill_packed(self.h, r.ctypes.data, len(r), f.ctypes.data, len(f), a, b, minScore,
-                                      FILL_LIMITED_RAW if limited else FILL_UNLIMITED_RAW, res.ctypes.data, C.byref(it),
-                                      packed.ctypes.data)
-        _lib.check(rc, "bbmsa_fill_packed")
+        t = bbmsa_ticket()
+        rc = self.L.bbmsa_fill_submit(self.h, r.ctypes.data, len(r), f.ctypes.data, len(f), a, b, minScore,
+                                      FILL_LIMITED_RAW if limited else FILL_UNLIMITED_RAW, res.ctypes.data, C.byref(it), C.byref(t))
+        _lib.check(rc, "bbmsa_fill_submit")
+        vl = np.zeros(len(r) + 1, np.int32)
+        hl = np.zeros(b - a + 2, np.int32)
+        rc = self.L.bbmsa_fill_collect(self.h, C.byref(t), packed.ctypes.data, vl.ctypes.data, hl.ctypes.data)
+        _lib.check(rc, "bbmsa_fill_collect")
+        if limits:
+            return res.tolist(), it.value, vl, hl
         return res.tolist(), it.value
+
+    def legacy_stats(self):
+        st = (C.c_int64 * 6)()
+        _lib.check(self.L.bbmsa_legacy_stats(self.h, st), "bbmsa_legacy_stats")
+        return dict(calls=st[0], launches=st[1], handed_on=st[2], wave_ms=st[3] / 1e6, handed_ms=st[4] / 1e6, wait_collect_ms=st[5] / 1e6)
 
     # -- device buffers (torch tensors or raw pointers) --------------------------------------
     def align_batch_device(self, n_jobs, jobs_ptr, reads_ptr, refs_ptr, results_ptr, match_ptr=0,

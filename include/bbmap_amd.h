@@ -108,8 +108,9 @@ typedef struct bbmsa_config {
  * maxColumns <= 8192; this round every 9PacBio job runs in the one-job-per-thread kernel. */
 #define BBMSA_SCHEME_11TS 0
 #define BBMSA_SCHEME_9PACBIO 1
-/* OR-ed into reserved[2]: a context for bbmsa_fill_packed only (what the per-call JNI symbols use, one per mapping thread):
- * one scratch matrix and no batch buffers, instead of gigabytes of batch scratch per thread */
+/* OR-ed into reserved[2]: a context for bbmsa_fill_submit / _collect / _packed only (what the per-call JNI symbols use, ONE per
+ * process and MSA shape, shared by all mapping threads): persistent pinned + device staging for two batches of calls
+ * (BBMSA_LEGACY_POOL_MB, default 64 MB each) and one scratch matrix, no batch buffers */
 #define BBMSA_LEGACY_ONLY 0x100
 
 int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out);
@@ -136,15 +137,36 @@ int bbmsa_align_batch(bbmsa_ctx *ctx, int64_t n_jobs, const bbmsa_job *jobs,
                       const uint8_t *refs, int64_t refs_bytes,
                       bbmsa_result *results, uint8_t *match, int32_t match_stride);
 
-/* Legacy per-call shape: ONE raw fill (mode = BBMSA_FILL_LIMITED_RAW or BBMSA_FILL_UNLIMITED_RAW) that also writes the
- * three score planes into the caller's `packed` array exactly where the reference's native code leaves them
+/* Legacy per-call shape: ONE raw fill (mode = BBMSA_FILL_LIMITED_RAW or BBMSA_FILL_UNLIMITED_RAW) whose three score planes end up
+ * in the caller's `packed` array exactly where the reference's native code leaves them
  * (state * (maxRows+1)*(maxColumns+1) + row * (maxColumns+1) + col; jni/MultiStateAligner11tsJNI.c:124-127, :707-812), so
  * that the unmodified Java score2 / traceback2 (current/align2/MultiStateAligner11tsJNI.java:376-658) can read them.  This
- * is what a drop-in Java_align2_MultiStateAligner11tsJNI_fill*JNI symbol calls; it copies
- * 12 bytes per matrix cell back per call and is slow by construction.  `*iterations` is incremented. */
+ * is what a drop-in Java_align2_MultiStateAligner11tsJNI_fill*JNI symbol calls.  The context must
+ * have been created with BBMSA_LEGACY_ONLY; it may be shared by any number of threads, and should be: calls that arrive while
+ * another is on the device are combined into one launch (one wavefront per fill), so throughput grows with the number of
+ * calling threads.
+ *   bbmsa_fill_submit   blocks until the fill has run and its planes sit in the context's pinned staging area; writes
+ *                       result5 (result[0..4] of the native fill; [4] only for the limited fill) and INCREMENTS *iterations;
+ *   bbmsa_fill_collect  copies the planes of that fill (rows 1..rows, columns 1..columns) into `packed`, and -- limited fill --
+ *                       vertLimit[0..rows] / horizLimit[0..columns] as the native code leaves them (jni/...c:413-438); any of
+ *                       the three may be NULL.  Pure memcpy: safe inside a JNI critical region.  Every successful submit must
+ *                       be collected exactly once (the staging area is reused when its last fill has been collected);
+ *   bbmsa_fill_packed   = submit + collect. */
+typedef struct bbmsa_ticket {
+    int32_t batch, slot;
+    int64_t gen;             /* < 0: nothing to collect */
+    int32_t rows, columns;
+} bbmsa_ticket;
+int bbmsa_fill_submit(bbmsa_ctx *ctx, const uint8_t *read, int32_t read_len, const uint8_t *ref, int32_t ref_len,
+                      int32_t refStartLoc, int32_t refEndLoc, int32_t minScore, int32_t mode,
+                      int32_t *result5, int64_t *iterations, bbmsa_ticket *ticket);
+int bbmsa_fill_collect(bbmsa_ctx *ctx, bbmsa_ticket *ticket, int32_t *packed, int32_t *vertLimit, int32_t *horizLimit);
 int bbmsa_fill_packed(bbmsa_ctx *ctx, const uint8_t *read, int32_t read_len, const uint8_t *ref, int32_t ref_len,
                       int32_t refStartLoc, int32_t refEndLoc, int32_t minScore, int32_t mode,
                       int32_t *result5, int64_t *iterations, int32_t *packed);
+/* stats6: calls served, device batches launched, fills the wavefront kernel handed to the one-thread kernel; nanoseconds the
+ * leaders spent in the wavefront pass (upload .. first synchronisation), in the hand-over pass, and waiting for collectors */
+int bbmsa_legacy_stats(bbmsa_ctx *ctx, int64_t *stats6);
 
 /* Gapped reference windows: job i is MSA.fillAndScoreLimited(read, ref, refStartLoc, refEndLoc, minScore, gaps)
  * (current/align2/MSA.java:103-134) for a SiteScore that carries a gap array.  When gaps[i].ngaps > 0 the library

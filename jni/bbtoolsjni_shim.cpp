@@ -11,8 +11,10 @@
 // Two layers.  The bbjni_* functions (extern "C", plain pointers) hold everything that is not JNI marshalling and are tested
 // through ctypes and through the mock JNIEnv of jni/mock_jni_test.cpp.  The Java_* functions only move data across the JNI
 // boundary, and they never wait for the GPU while a GetPrimitiveArrayCritical region is open (a critical region blocks the
-// garbage collector for every other mapping thread): inputs are copied out with Get<Type>ArrayRegion, the fill
-// runs into a per-thread staging matrix, and one short critical region copies the touched rows into `packed`.
+// garbage collector for every other mapping thread): inputs are copied out with Get<Type>ArrayRegion (of the reference
+// only the window), the fill runs into the library's pinned staging area (bbmsa_fill_submit: calls of all mapping threads that
+// arrive together share one launch), and one short critical region copies the fill's rectangle into `packed` (bbmsa_fill_collect,
+// a memcpy).
 //
 // Compiled against <jni.h> when a JDK is installed, otherwise against jni/jni_min.h (this image has no JDK).
 #if __has_include(<jni.h>)
@@ -23,6 +25,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "bbmap_amd.h"
@@ -32,22 +35,24 @@ namespace {
 
 struct MsaSlot { int maxRows, maxColumns, bandwidth; float ratio; bbmsa_ctx *ctx; };
 struct BandSlot { int width; bbband_ctx *ctx; };
-// one set of contexts per mapping thread, like one MSA / BandedAligner object per thread in BBMap
-thread_local std::vector<MsaSlot> t_msa;
+// MSA contexts are process-wide, one per (maxRows, maxColumns, band): every mapping thread's MSA object of that shape shares it, which
+// is what lets the library combine their calls.  BandedAligner contexts stay one per thread, like the objects in BBMap.
+std::mutex g_msaMu;
+std::vector<MsaSlot> g_msa;
 thread_local std::vector<BandSlot> t_band;
-thread_local std::vector<int32_t> t_stage;       // staging copy of `packed`
 thread_local char t_err[320] = "";
 
 bbmsa_ctx *msa_ctx(int maxRows, int maxColumns, int bandwidth, float ratio) {
-    for (const MsaSlot &s : t_msa)
+    std::lock_guard<std::mutex> g(g_msaMu);
+    for (const MsaSlot &s : g_msa)
         if (s.maxRows == maxRows && s.maxColumns == maxColumns && s.bandwidth == bandwidth && s.ratio == ratio) return s.ctx;
     bbmsa_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.device = 0; cfg.maxRows = maxRows; cfg.maxColumns = maxColumns; cfg.bandwidth = bandwidth; cfg.bandwidthRatio = ratio;
-    cfg.reserved[2] = BBMSA_SCHEME_11TS | BBMSA_LEGACY_ONLY;      // per-call fills only: no batch buffers, one scratch matrix
+    cfg.reserved[2] = BBMSA_SCHEME_11TS | BBMSA_LEGACY_ONLY;      // per-call fills only: staging for two batches of calls, no batch buffers
     bbmsa_ctx *ctx = nullptr;
     if (bbmsa_create(&cfg, &ctx) != BBMAP_OK) return nullptr;
-    t_msa.push_back(MsaSlot{maxRows, maxColumns, bandwidth, ratio, ctx});
+    g_msa.push_back(MsaSlot{maxRows, maxColumns, bandwidth, ratio, ctx});
     return ctx;
 }
 bbband_ctx *band_ctx(int maxWidth) {
@@ -66,19 +71,36 @@ bbband_ctx *band_ctx(int maxWidth) {
 extern "C" {
 
 // jni/MultiStateAligner11tsJNI.c fillUnlimited (:100-117) / fillLimitedX (:361-382) with their own plain signature, minus the
-// score tables (the kernels carry them).  `packed` is the Java class's matrix (3 x (maxRows+1) x (maxColumns+1) ints); only the
-// rows the fill touches are written.  result: 4 ints (unlimited) or 5 (limited); *iterations is incremented.  0 = ok.
-int bbjni_fill(int limited, const uint8_t *read, int readLen, const uint8_t *ref, int refLen, int refStartLoc, int refEndLoc,
-               int minScore, int32_t *result, int64_t *iterations, int32_t *packed, int maxRows, int maxColumns,
-               int bandwidth, float bandwidthRatio) {
+// score tables (the kernels carry them), in two halves.  bbjni_fill_submit runs the fill (blocking; calls from other threads that
+// arrive meanwhile share the launch) and returns result (4 ints unlimited, 5 limited), increments *iterations and leaves a ticket;
+// bbjni_fill_collect copies the fill's rectangle into `packed` (the Java class's matrix, 3 x (maxRows+1) x (maxColumns+1) ints; rows
+// 1..readLen, columns 1..columns only) and, limited fill, vertLimit[0..readLen] / horizLimit[0..columns] (:413-438).  0 = ok.
+int bbjni_fill_submit(int limited, const uint8_t *read, int readLen, const uint8_t *ref, int refLen, int refStartLoc, int refEndLoc,
+                      int minScore, int32_t *result, int64_t *iterations, int maxRows, int maxColumns, int bandwidth,
+                      float bandwidthRatio, bbmsa_ctx **ctxOut, bbmsa_ticket *ticket) {
     bbmsa_ctx *ctx = msa_ctx(maxRows, maxColumns, limited ? bandwidth : 0, limited ? bandwidthRatio : 0.0f);
     if (!ctx) return BBMAP_E_HIP;
     int32_t r5[5] = {0, 0, 0, 0, 0};
-    const int rc = bbmsa_fill_packed(ctx, read, readLen, ref, refLen, refStartLoc, refEndLoc, minScore,
-                                     limited ? BBMSA_FILL_LIMITED_RAW : BBMSA_FILL_UNLIMITED_RAW, r5, iterations, packed);
+    const int rc = bbmsa_fill_submit(ctx, read, readLen, ref, refLen, refStartLoc, refEndLoc, minScore,
+                                     limited ? BBMSA_FILL_LIMITED_RAW : BBMSA_FILL_UNLIMITED_RAW, r5, iterations, ticket);
     if (rc != BBMAP_OK) return rc;
     for (int i = 0; i < (limited ? 5 : 4); i++) result[i] = r5[i];
+    *ctxOut = ctx;
     return BBMAP_OK;
+}
+int bbjni_fill_collect(bbmsa_ctx *ctx, bbmsa_ticket *ticket, int32_t *packed, int32_t *vertLimit, int32_t *horizLimit) {
+    return bbmsa_fill_collect(ctx, ticket, packed, vertLimit, horizLimit);
+}
+// both halves, for callers that own `packed` (ctypes, tests); vertLimit / horizLimit may be NULL
+int bbjni_fill(int limited, const uint8_t *read, int readLen, const uint8_t *ref, int refLen, int refStartLoc, int refEndLoc,
+               int minScore, int32_t *result, int64_t *iterations, int32_t *packed, int maxRows, int maxColumns,
+               int bandwidth, float bandwidthRatio) {
+    bbmsa_ctx *ctx = nullptr;
+    bbmsa_ticket t;
+    const int rc = bbjni_fill_submit(limited, read, readLen, ref, refLen, refStartLoc, refEndLoc, minScore, result, iterations,
+                                     maxRows, maxColumns, bandwidth, bandwidthRatio, &ctx, &t);
+    if (rc != BBMAP_OK) return rc;
+    return bbmsa_fill_collect(ctx, &t, packed, nullptr, nullptr);
 }
 
 // jni/BandedAlignerJNI.c alignForward / alignForwardRC / alignReverse / alignReverseRC (:123-585): direction = BBBAND_*.
@@ -104,9 +126,23 @@ int bbjni_banded(int direction, const uint8_t *query, int qLen, const uint8_t *r
 
 // frees the calling thread's contexts (a mapping thread that ends; tests)
 void bbjni_release_thread(void) {
-    for (MsaSlot &s : t_msa) bbmsa_destroy(s.ctx);
     for (BandSlot &s : t_band) bbband_destroy(s.ctx);
-    t_msa.clear(); t_band.clear(); t_stage.clear(); t_stage.shrink_to_fit();
+    t_band.clear();
+}
+// bbmsa_legacy_stats (calls, launches, hand-overs, three leader times in ns), summed over the process-wide MSA contexts
+void bbjni_legacy_stats(int64_t *stats6) {
+    std::lock_guard<std::mutex> g(g_msaMu);
+    for (int i = 0; i < 6; i++) stats6[i] = 0;
+    for (MsaSlot &s : g_msa) {
+        int64_t st[6] = {0, 0, 0, 0, 0, 0};
+        if (bbmsa_legacy_stats(s.ctx, st) == BBMAP_OK) for (int i = 0; i < 6; i++) stats6[i] += st[i];
+    }
+}
+// frees the process-wide MSA contexts; no fill may be in flight (tests, library unload)
+void bbjni_release_all(void) {
+    std::lock_guard<std::mutex> g(g_msaMu);
+    for (MsaSlot &s : g_msa) bbmsa_destroy(s.ctx);
+    g_msa.clear();
 }
 
 }  // extern "C"
@@ -120,7 +156,8 @@ void throw_runtime(JNIEnv *env, const char *what) {
 
 // shared by the two fills; `limited` selects fillLimitedX
 void fill_common(JNIEnv *env, bool limited, jbyteArray read, jbyteArray ref, jint refStartLoc, jint refEndLoc, jint minScore,
-                 jintArray result, jlongArray iterations, jintArray packed, jint maxRows, jint maxColumns, jint bandwidth, jfloat ratio) {
+                 jintArray result, jlongArray iterations, jintArray packed, jint maxRows, jint maxColumns, jint bandwidth, jfloat ratio,
+                 jintArray vertLimit, jintArray horizLimit) {
     const jsize readLen = env->GetArrayLength(read), refLen = env->GetArrayLength(ref);
     // `ref` is the whole chromosome array; the fill reads ref[refStartLoc + col - 1] for col 1..columns only
     // (jni/MultiStateAligner11tsJNI.c:137-139, :427-438), so only that window leaves the JVM: the job is rebased to offset 0.
@@ -136,28 +173,30 @@ void fill_common(JNIEnv *env, bool limited, jbyteArray read, jbyteArray ref, jin
     env->GetByteArrayRegion(ref, refStartLoc, cols, rf.data());
     jlong it = 0;
     env->GetLongArrayRegion(iterations, 0, 1, &it);
-    const size_t plane = (size_t)(maxRows + 1) * (size_t)(maxColumns + 1);
-    if (t_stage.size() < 3 * plane) t_stage.resize(3 * plane);
     int32_t r5[5] = {0, 0, 0, 0, 0};
     int64_t it64 = it;
-    const int rc = bbjni_fill(limited ? 1 : 0, (const uint8_t *)rd.data(), readLen, (const uint8_t *)rf.data(), cols, 0, cols - 1,
-                              minScore, r5, &it64, t_stage.data(), maxRows, maxColumns, bandwidth, ratio);
+    bbmsa_ctx *ctx = nullptr;
+    bbmsa_ticket ticket;
+    const int rc = bbjni_fill_submit(limited ? 1 : 0, (const uint8_t *)rd.data(), readLen, (const uint8_t *)rf.data(), cols, 0, cols - 1,
+                                     minScore, r5, &it64, maxRows, maxColumns, bandwidth, ratio, &ctx, &ticket);
     if (rc != BBMAP_OK) {                                          // the reference calls exit(0) here (jni/...c:130-132)
         snprintf(t_err, sizeof t_err, "bbtoolsjni: fill failed (%d): %s", rc, bbmap_last_error());
         throw_runtime(env, t_err);
         return;
     }
-    // one short critical region: the rectangle the fill touched (rows 0..rows, columns 0..columns+1 of the three planes -- what
-    // score2 / traceback2 read, current/align2/MultiStateAligner11tsJNI.java:376-658) goes into the Java matrix; nothing in here blocks
-    const size_t rowInts = (size_t)maxColumns + 1, rowsTouched = (size_t)readLen + 1;
-    size_t width = (size_t)(refEndLoc - refStartLoc + 1) + 2;
-    if (width > rowInts) width = rowInts;
+    // one short critical region: the fill's rectangle (rows 1..rows, columns 1..columns of the three planes -- what score2 /
+    // traceback2 read besides the constructor's row 0 and column 0, current/align2/MultiStateAligner11tsJNI.java:376-658) goes from the
+    // pinned staging area into the Java matrix; nothing in here blocks or touches the GPU
+    std::vector<int32_t> vl, hl;
+    const bool wantLimits = limited && vertLimit && horizLimit && env->GetArrayLength(vertLimit) > readLen &&
+                            env->GetArrayLength(horizLimit) > cols;
+    if (wantLimits) { vl.resize((size_t)readLen + 1); hl.resize((size_t)cols + 1); }
     jint *jp = (jint *)env->GetPrimitiveArrayCritical(packed, nullptr);
-    if (jp) {
-        for (int s = 0; s < 3; s++)
-            for (size_t r = 0; r < rowsTouched; r++)
-                memcpy(jp + s * plane + r * rowInts, t_stage.data() + s * plane + r * rowInts, width * sizeof(int32_t));
-        env->ReleasePrimitiveArrayCritical(packed, jp, 0);
+    bbjni_fill_collect(ctx, &ticket, (int32_t *)jp, wantLimits ? vl.data() : nullptr, wantLimits ? hl.data() : nullptr);
+    if (jp) env->ReleasePrimitiveArrayCritical(packed, jp, 0);
+    if (wantLimits) {      // the native code fills these as a side effect (:413-438); Java only prints them, but they are its arrays
+        env->SetIntArrayRegion(vertLimit, 0, readLen + 1, (const jint *)vl.data());
+        env->SetIntArrayRegion(horizLimit, 0, cols + 1, (const jint *)hl.data());
     }
     env->SetIntArrayRegion(result, 0, limited ? 5 : 4, (const jint *)r5);
     it = it64;
@@ -210,16 +249,17 @@ JNIEXPORT void JNICALL Java_align2_MultiStateAligner11tsJNI_fillUnlimitedJNI(
     JNIEnv *env, jobject, jbyteArray read, jbyteArray ref, jint refStartLoc, jint refEndLoc, jintArray result,
     jlongArray iterationsUnlimited, jintArray packed, jintArray /*POINTSoff_SUB_ARRAY*/, jintArray /*POINTSoff_INS_ARRAY*/,
     jint maxRows, jint maxColumns) {
-    fill_common(env, false, read, ref, refStartLoc, refEndLoc, 0, result, iterationsUnlimited, packed, maxRows, maxColumns, 0, 0.0f);
+    fill_common(env, false, read, ref, refStartLoc, refEndLoc, 0, result, iterationsUnlimited, packed, maxRows, maxColumns, 0, 0.0f,
+                nullptr, nullptr);
 }
 
 // ([B[BIII[I[J[I[I[IIIIF[I[I[B[I)V -- MSA.bandwidth / bandwidthRatio arrive per call and select the context
 JNIEXPORT void JNICALL Java_align2_MultiStateAligner11tsJNI_fillLimitedXJNI(
     JNIEnv *env, jobject, jbyteArray read, jbyteArray ref, jint refStartLoc, jint refEndLoc, jint minScore, jintArray result,
     jlongArray iterationsLimited, jintArray packed, jintArray, jintArray, jint maxRows, jint maxColumns, jint bandwidth,
-    jfloat bandwidthRatio, jintArray /*vertLimit*/, jintArray /*horizLimit*/, jbyteArray /*baseToNumber*/, jintArray /*INS_ARRAY_C*/) {
+    jfloat bandwidthRatio, jintArray vertLimit, jintArray horizLimit, jbyteArray /*baseToNumber*/, jintArray /*INS_ARRAY_C*/) {
     fill_common(env, true, read, ref, refStartLoc, refEndLoc, minScore, result, iterationsLimited, packed, maxRows, maxColumns,
-                bandwidth, bandwidthRatio);
+                bandwidth, bandwidthRatio, vertLimit, horizLimit);
 }
 
 JNIEXPORT jint JNICALL Java_align2_BandedAlignerJNI_alignForwardJNI(

@@ -1,24 +1,31 @@
 // Exercises the Java_* entry points of libbbtoolsjni.so against a mock JNIEnv (no JVM in this image): arrays are plain
 // buffers behind jobject handles, the function table carries the calls the shim makes, and the mock FAILS the test if a
 // critical region is open while any other JNI call is made or while more than one region is open (the JNI
-// specification forbids blocking inside a critical region).  Usage: mock_jni_test merge | gpu   (exit code 0 = pass)
+// specification forbids blocking inside a critical region).  Usage: mock_jni_test merge | gpu | threads [N]   (exit code 0 = pass)
+// `threads`: N mapping threads (default 32), each with its own arrays like one MSA object per thread, call the two fill symbols
+// concurrently; every result and every plane must equal what the same call gave alone, and the calls/s of 1 and N threads are
+// printed.
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "jni_min.h"
 #include "bbmerge_overlap.h"
 
 struct _jobject { void *data; int len; int elem; };
-static int g_critical = 0, g_violations = 0, g_thrown = 0;
-static size_t g_maxRegionBytes = 0;      // largest Get<Type>ArrayRegion copy seen
+static thread_local int g_critical = 0;  // open critical regions of the calling thread
+static std::atomic<int> g_violations{0}, g_thrown{0};
+static std::atomic<size_t> g_maxRegionBytes{0};      // largest Get<Type>ArrayRegion copy seen
 static void touch() { if (g_critical) g_violations++; }
 
 static jclass mFindClass(JNIEnv *, const char *) { touch(); static _jobject cls = {nullptr, 0, 0}; return &cls; }
 static jint mThrowNew(JNIEnv *, jclass, const char *msg) { touch(); g_thrown++; fprintf(stderr, "thrown: %s\n", msg); return 0; }
 static jsize mGetArrayLength(JNIEnv *, jarray a) { touch(); return a->len; }
-template <class T> static void getRegion(jarray a, jsize s, jsize l, T *b) { touch(); if (sizeof(T) * (size_t)l > g_maxRegionBytes) g_maxRegionBytes = sizeof(T) * (size_t)l; memcpy(b, (T *)a->data + s, sizeof(T) * (size_t)l); }
+template <class T> static void getRegion(jarray a, jsize s, jsize l, T *b) { touch(); if (sizeof(T) * (size_t)l > g_maxRegionBytes.load()) g_maxRegionBytes = sizeof(T) * (size_t)l; memcpy(b, (T *)a->data + s, sizeof(T) * (size_t)l); }
 template <class T> static void setRegion(jarray a, jsize s, jsize l, const T *b) { touch(); memcpy((T *)a->data + s, b, sizeof(T) * (size_t)l); }
 static void mGetByte(JNIEnv *, jbyteArray a, jsize s, jsize l, jbyte *b) { getRegion(a, s, l, b); }
 static void mGetInt(JNIEnv *, jintArray a, jsize s, jsize l, jint *b) { getRegion(a, s, l, b); }
@@ -39,6 +46,8 @@ jint Java_jgi_BBMergeOverlapper_mateByOverlapRatioJNI_1WithQualities(JNIEnv *, j
 jint Java_jgi_BBMergeOverlapper_mateByOverlapRatioJNI(JNIEnv *, jclass, jbyteArray, jbyteArray, jintArray, jint, jint, jint, jint, jfloat, jfloat, jfloat, jfloat, jfloat);
 int bbjni_fill(int, const uint8_t *, int, const uint8_t *, int, int, int, int, int32_t *, int64_t *, int32_t *, int, int, int, float);
 void bbjni_release_thread(void);
+void bbjni_release_all(void);
+void bbjni_legacy_stats(int64_t *);
 }
 
 #define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
@@ -135,8 +144,105 @@ static int test_gpu(JNIEnv *env) {
         CHECK(e == 2 && rv[0] == 19 && rv[1] == 18 && rv[2] == 19 && rv[3] == 2 && rv[4] == 1);
     }
     bbjni_release_thread();
+    bbjni_release_all();
     CHECK(g_violations == 0 && g_critical == 0 && g_thrown == 0);
     printf("mock JNI: fills and the banded symbol through the JNI layer equal the plain layer, one short critical region per fill\n");
+    return 0;
+}
+
+
+// N mapping threads against the process-wide context.  A "call" is what BBMap issues per site: fillLimitedX (or fillUnlimited)
+// on a 150-base read against a window with the mapper's padding.
+struct Call { std::vector<jbyte> rd; int a, b, minScore; bool limited; jint res[5]; jlong it; unsigned long long sum; std::vector<jint> vl, hl; };
+
+static unsigned long long rect_sum(const std::vector<jint> &packed, size_t plane, int maxColumns, int rows, int cols) {
+    unsigned long long h = 1469598103934665603ull;
+    for (int s = 0; s < 3; s++)
+        for (int r = 1; r <= rows; r++)
+            for (int c = 1; c <= cols; c++) { h ^= (unsigned)packed[s * plane + (size_t)r * (maxColumns + 1) + c]; h *= 1099511628211ull; }
+    return h;
+}
+
+static int run_calls(JNIEnv *env, std::vector<jbyte> &ref, std::vector<Call> &calls, size_t first, size_t step, int maxRows, int maxColumns,
+                     bool record, int *failed) {
+    const size_t plane = (size_t)(maxRows + 1) * (maxColumns + 1);
+    std::vector<jint> packed(3 * plane, 0), vl((size_t)maxRows + 1), hl((size_t)maxColumns + 1);
+    for (size_t i = first; i < calls.size(); i += step) {
+        Call &c = calls[i];
+        jint res[5] = {0, 0, 0, 0, 0}; jlong it[1] = {0};
+        const int rlen = (int)c.rd.size(), cols = c.b - c.a + 1;
+        _jobject jrd{c.rd.data(), rlen, 1}, jrf{ref.data(), (int)ref.size(), 1}, jres{res, 5, 4}, jit{it, 1, 8}, jpk{packed.data(), (int)packed.size(), 4};
+        _jobject jvl{vl.data(), maxRows + 1, 4}, jhl{hl.data(), maxColumns + 1, 4};
+        if (c.limited) Java_align2_MultiStateAligner11tsJNI_fillLimitedXJNI(env, nullptr, &jrd, &jrf, c.a, c.b, c.minScore, &jres, &jit, &jpk, nullptr, nullptr, maxRows, maxColumns, 0, 0.0f, &jvl, &jhl, nullptr, nullptr);
+        else Java_align2_MultiStateAligner11tsJNI_fillUnlimitedJNI(env, nullptr, &jrd, &jrf, c.a, c.b, &jres, &jit, &jpk, nullptr, nullptr, maxRows, maxColumns);
+        const unsigned long long sum = rect_sum(packed, plane, maxColumns, rlen, cols);
+        if (record) {
+            memcpy(c.res, res, sizeof res); c.it = it[0]; c.sum = sum;
+            if (c.limited) { c.vl.assign(vl.begin(), vl.begin() + rlen + 1); c.hl.assign(hl.begin(), hl.begin() + cols + 1); }
+        } else {
+            bool ok = memcmp(c.res, res, (c.limited ? 5 : 4) * sizeof(jint)) == 0 && c.it == it[0] && c.sum == sum;
+            if (ok && c.limited) ok = memcmp(c.vl.data(), vl.data(), (size_t)(rlen + 1) * 4) == 0 && memcmp(c.hl.data(), hl.data(), (size_t)(cols + 1) * 4) == 0;
+            if (!ok) { (*failed)++; fprintf(stderr, "call %zu differs from its solo run\n", i); }
+        }
+    }
+    return 0;
+}
+
+static int test_threads(JNINativeInterface_ *tbl, int nthreads) {
+    const int maxRows = 601, maxColumns = 2000;          // the MSA shape BBMap's mapping threads create (ALIGN_ROWS 601)
+    unsigned seed = 23;
+    std::vector<jbyte> ref(200000);
+    for (auto &x : ref) x = "ACGT"[rnd(seed) & 3];
+    const int ncalls = 4096;
+    std::vector<Call> calls((size_t)ncalls);
+    for (int i = 0; i < ncalls; i++) {
+        Call &c = calls[(size_t)i];
+        const int st = 1000 + (int)(rnd(seed) % 190000), len = 150;
+        c.rd.assign(ref.begin() + st, ref.begin() + st + len + 8);
+        for (int k = 0; k < (int)(rnd(seed) % 4); k++) c.rd[(size_t)(rnd(seed) % (unsigned)len)] = "ACGT"[rnd(seed) & 3];
+        if (i % 5 == 1) c.rd.erase(c.rd.begin() + 70, c.rd.begin() + 70 + 1 + (int)(rnd(seed) % 6));
+        if (i % 7 == 2) c.rd[(size_t)(rnd(seed) % (unsigned)len)] = 'N';
+        c.rd.resize((size_t)len);
+        c.a = st - 8 - (int)(rnd(seed) % 8); c.b = st + len + 8 + (int)(rnd(seed) % 24);
+        if (i % 1024 == 5) c.b = c.a + len - 5;          // a window narrower than the read (chromosome ends only, in BBMap): handed to the one-thread kernel
+        c.limited = (i % 6) != 0;
+        c.minScore = (int)(0.56f * (70 + 100 * (len - 1)));
+    }
+    JNIEnv_ env; env.functions = tbl;
+    int failed = 0;
+    // solo: one call at a time, recorded (this is also the single-thread rate)
+    auto t0 = std::chrono::steady_clock::now();
+    run_calls(&env, ref, calls, 0, 1, maxRows, maxColumns, true, &failed);
+    const double solo = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    int64_t st0[6]; bbjni_legacy_stats(st0);
+    // together
+    std::vector<std::thread> th;
+    std::vector<int> fails((size_t)nthreads, 0);
+    t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < nthreads; t++)
+        th.emplace_back([&, t] {
+            JNIEnv_ e; e.functions = tbl;
+            run_calls(&e, ref, calls, (size_t)t, (size_t)nthreads, maxRows, maxColumns, false, &fails[(size_t)t]);
+            if (g_critical != 0) fails[(size_t)t]++;
+        });
+    for (auto &x : th) x.join();
+    const double together = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int f : fails) failed += f;
+    int64_t st1[6]; bbjni_legacy_stats(st1);
+    CHECK(failed == 0);
+    CHECK(g_violations == 0 && g_thrown == 0);
+    CHECK(st0[0] == ncalls && st0[1] == ncalls);                       // alone: one launch per call
+    CHECK(st1[0] == 2 * ncalls && st1[2] > 0);
+    if (nthreads >= 8) CHECK(st1[1] - st0[1] < ncalls / 2);             // together: calls were combined
+    printf("mock JNI legacy fills (150-base reads, MSA 601 x 2000): 1 thread %.0f calls/s; %d threads %.0f calls/s in %lld launches "
+           "(%.1f calls per launch); %lld of %d calls went to the one-thread kernel; all equal to their solo runs\n",
+           ncalls / solo, nthreads, ncalls / together, (long long)(st1[1] - st0[1]), (double)ncalls / (double)(st1[1] - st0[1]),
+           (long long)(st1[2] - st0[2]), ncalls);
+    printf("  leader time per launch, solo: wavefront pass %.0f us, hand-over pass %.0f us per handed fill; together: wavefront pass %.0f us, "
+           "hand-over %.0f us per handed fill, waiting for collectors %.0f us\n", st0[3] / 1e3 / st0[1], st0[2] ? st0[4] / 1e3 / st0[2] : 0.0,
+           (st1[3] - st0[3]) / 1e3 / (st1[1] - st0[1]), (st1[2] - st0[2]) ? (st1[4] - st0[4]) / 1e3 / (st1[2] - st0[2]) : 0.0,
+           (st1[5] - st0[5]) / 1e3 / (st1[1] - st0[1]));
+    bbjni_release_all();
     return 0;
 }
 
@@ -149,5 +255,6 @@ int main(int argc, char **argv) {
     tbl.GetPrimitiveArrayCritical = mGetCritical; tbl.ReleasePrimitiveArrayCritical = mReleaseCritical;
     JNIEnv_ env; env.functions = &tbl;
     if (argc > 1 && !strcmp(argv[1], "gpu")) return test_gpu(&env);
+    if (argc > 1 && !strcmp(argv[1], "threads")) return test_threads(&tbl, argc > 2 ? atoi(argv[2]) : 32);
     return test_merge(&env);
 }

@@ -92,3 +92,12 @@ def test_bbmerge_natives_equal_the_oracle(shim):
 def test_mock_jnienv_fills_and_banded(shim):
     out = subprocess.run([os.path.join(PKG, "mock_jni_test"), "gpu"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr + out.stdout
+
+
+@pytest.mark.gpu
+def test_mock_jnienv_32_mapping_threads_share_launches(shim):
+    """32 threads call the two fill symbols concurrently: every result, plane and limit vector equals the solo run,
+    no JNI call inside a critical region, and calls are combined into far fewer launches; prints the calls/s of 1 and 32 threads."""
+    out = subprocess.run([os.path.join(PKG, "mock_jni_test"), "threads", "32"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    print(out.stdout)

@@ -219,20 +219,8 @@ def test_gapped_reference_jobs():
     assert nonnull > 30
 
 
-def test_legacy_packed_matrix_feeds_the_java_walkers():
-    """bbmsa_fill_packed: the planes land in the Java layout; score2 / traceback2 (the oracle's restatement of the Java
-    walkers, which read `packed`) run on OUR matrix and must give what they give on the oracle's own fill."""
-    import ctypes as C
-    import random
-    import numpy as np
-    from oracle.oracle import OracleMSA
-    rng = random.Random(91)
-    maxRows, maxCols = 160, 300
-    ctx = M.MSAContext(maxRows=maxRows, maxColumns=maxCols)
-    ref = bytes(rng.choice(b"ACGT") for _ in range(3000))
-    n_int = 3 * (maxRows + 1) * (maxCols + 1)
-    done = 0
-    for i in range(24):
+def _legacy_cases(rng, ref, n):
+    for i in range(n):
         L = rng.choice([60, 100, 150])
         st = rng.randrange(50, 2500)
         rd = bytearray(ref[st:st + L + 10])
@@ -243,17 +231,63 @@ def test_legacy_packed_matrix_feeds_the_java_walkers():
             del rd[L // 2:L // 2 + rng.randint(1, 6)]
         rd = bytes(rd[:L])
         a, b = st - 4, st + L + 8
+        if i % 11 == 7:
+            b = a + L - 6                                   # narrower than the read: handed to the one-thread kernel
         limited = i % 4 != 3
-        ms = int(0.5 * (70 + 100 * (L - 1)))
-        om = OracleMSA(maxRows, maxCols)
+        yield rd, a, b, limited, int(0.5 * (70 + 100 * (L - 1)))
+
+
+@pytest.mark.parametrize("band", [(0, 0.0), (40, 0.18)])
+def test_legacy_packed_matrix_feeds_the_java_walkers(band):
+    """bbmsa_fill_submit / _collect: the planes land in the Java layout.  Three checks per fill: (1) every cell the oracle's
+    restatement of the native fill WROTE holds the same int on our side (score, time bits and the subfloor of visited-but-bad cells);
+    (2) score2 / traceback2 (the oracle's restatement of the Java walkers, which read `packed`) run on OUR matrix and give what they
+    give on the oracle's own; (3) vertLimit / horizLimit come back as the native code leaves them."""
+    import ctypes as C
+    import random
+    import numpy as np
+    from oracle.oracle import OracleMSA
+    rng = random.Random(91)
+    maxRows, maxCols = 160, 300
+    ctx = M.MSAContext(maxRows=maxRows, maxColumns=maxCols, bandwidth=band[0], bandwidthRatio=band[1], legacy=True)
+    ref = bytes(rng.choice(b"ACGT") for _ in range(3000))
+    n_int = 3 * (maxRows + 1) * (maxCols + 1)
+    MARK = 0x5a5a5a5a
+    done = 0
+    for rd, a, b, limited, ms in _legacy_cases(rng, ref, 48):
+        om = OracleMSA(maxRows, maxCols, bandwidth=band[0], bandwidthRatio=band[1])
+        view = np.ctypeslib.as_array(om.s.packed, shape=(3, maxRows + 1, maxCols + 1))
+        pristine = view.copy()                              # row 0 / column 0 as the constructor leaves them
+        view[:, 1:, 1:] = MARK
         if limited:
             exp, exp_it = om.fill_limited_raw(rd, ref, a, b, ms)
         else:
             exp, exp_it = om.fill_unlimited_raw(rd, ref, a, b)
             exp = exp + [0]
-        packed = np.zeros(n_int, np.int32)
-        got, it = ctx.fill_packed(rd, ref, a, b, ms, limited, packed)
+        packed = pristine.copy().reshape(-1)
+        got, it, vl, hl = ctx.fill_packed(rd, ref, a, b, ms, limited, packed, limits=True)
         assert got[:4] == exp[:4] and (not limited or got[4] == exp[4]) and it == exp_it
+        rows, cols = len(rd), b - a + 1
+        ours = packed.reshape(3, maxRows + 1, maxCols + 1)
+        o, g = view[:, 1:rows + 1, 1:cols + 1], ours[:, 1:rows + 1, 1:cols + 1]
+        wrote = o != MARK
+        assert wrote.sum() > rows                           # (the oracle did fill something)
+        # "not a score": subfloor (pruned, below the limit, or a row-end sentinel) and the BADoff the native fill spreads over the last
+        # row first (:398-403).  Nothing reads the time bits of such a cell, and the native code itself strips them wherever a
+        # sentinel lands on a computed cell; we keep subfloor there.  Every other cell -- every real score and its time -- is exact.
+        maxGain = (rows - 1) * 100 + 70
+        subfloor = ((ms << 11) - (maxGain << 11) - 5 * (100 << 11)) if limited else -2 * (maxGain << 11)
+        badoff = (-(1 << 20) + 2000) << 11
+        dead = wrote & (((o & ~2047) == subfloor) | (o == badoff))
+        live = wrote & ~dead
+        assert live.sum() > rows
+        assert (g[live] == o[live]).all()
+        assert (((g[dead] & ~2047) == subfloor) | (g[dead] == badoff)).all()
+        assert (ours[:, 0, :] == pristine[:, 0, :]).all() and (ours[:, :, 0] == pristine[:, :, 0]).all()
+        assert (ours[:, rows + 1:, :] == pristine[:, rows + 1:, :]).all() and (ours[:, 1:, cols + 1:] == pristine[:, 1:, cols + 1:]).all()
+        if limited:
+            assert vl.tolist() == np.ctypeslib.as_array(om.s.vertLimit, shape=(maxRows + 1,))[:rows + 1].tolist()
+            assert hl.tolist() == np.ctypeslib.as_array(om.s.horizLimit, shape=(maxCols + 1,))[:cols + 1].tolist()
         if limited and exp[4] == 1:
             continue
         want_score = om.score(rd, ref, a, b, exp[0], exp[1], exp[2])
@@ -263,7 +297,46 @@ def test_legacy_packed_matrix_feeds_the_java_walkers():
         assert om.score(rd, ref, a, b, got[0], got[1], got[2]) == want_score
         assert om.traceback(rd, ref, a, b, got[0], got[1], got[2]) == want_tb
         done += 1
-    assert done > 12
+    st = ctx.legacy_stats()
+    assert st["calls"] == 48 and st["launches"] == 48 and st["handed_on"] >= 4
+    assert done > 24
+    ctx.close()
+
+
+def test_legacy_calls_from_many_threads_share_launches():
+    """The per-call entry is thread-safe on ONE context and combines calls that arrive together: 16 threads x 24 fills give what the
+    same fills gave alone, in far fewer launches than calls."""
+    import random
+    import threading
+    import numpy as np
+    rng = random.Random(17)
+    maxRows, maxCols = 160, 300
+    ctx = M.MSAContext(maxRows=maxRows, maxColumns=maxCols, legacy=True)
+    ref = bytes(rng.choice(b"ACGT") for _ in range(3000))
+    cases = list(_legacy_cases(rng, ref, 16 * 24))
+    n_int = 3 * (maxRows + 1) * (maxCols + 1)
+
+    def run(idx, out):
+        packed = np.zeros(n_int, np.int32)
+        for i in idx:
+            rd, a, b, limited, ms = cases[i]
+            packed[:] = 0
+            got, it = ctx.fill_packed(rd, ref, a, b, ms, limited, packed)
+            out[i] = (got[:4 + limited], it, hash(packed.tobytes()))
+    solo = {}
+    run(range(len(cases)), solo)
+    before = ctx.legacy_stats()
+    together = {}
+    th = [threading.Thread(target=run, args=(range(t, len(cases), 16), together)) for t in range(16)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    after = ctx.legacy_stats()
+    assert together == solo
+    assert after["calls"] - before["calls"] == len(cases)
+    assert after["launches"] - before["launches"] < len(cases)          # some calls shared a launch (ctypes releases the GIL in the call)
+    ctx.close()
 
 
 def test_wide_pass_takes_windows_beyond_the_first_column_buffer():
