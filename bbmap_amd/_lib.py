@@ -18,7 +18,7 @@ EXPORTS = [
     "bbband_create", "bbband_destroy", "bbband_align_batch_device", "bbband_align_batch",
     "bbband_align_quadruple_batch", "bbband_align_quadruple_progressive_batch", "bbband_align_double_batch",
     "bbidx_create", "bbidx_destroy", "bbidx_find_batch_device", "bbidx_find_batch", "bbidx_find_batch_device_rc", "bbidx_last_stats", "bbidx_set_kernel", "bbidx_set_max_read_len", "bbidx_build", "bbidx_get_params", "bbidx_export_block",
-    "bbmap_default_config", "bbmap_create", "bbmap_destroy", "bbmap_map_batch_device", "bbmap_get_output", "bbmap_get_overflow_output", "bbmap_last_stats", "bbmap_pack_sites_device",
+    "bbmap_default_config", "bbmap_create", "bbmap_destroy", "bbmap_map_batch_device", "bbmap_map_batch", "bbmap_get_output", "bbmap_get_overflow_output", "bbmap_last_stats", "bbmap_pack_sites_device",
     "bbmap_copy_to_host", "bbidx_get_chrom_table",
     "bbpipe_revcomp_device", "bbpipe_quick_rescue_device",
     "bbidx_build_profile", "bbkeys_default_config", "bbkeys_make", "bbkeys_make_batch", "bbmap_default_config_profile",

@@ -1046,6 +1046,8 @@ struct bbmap_ctx {
     int tierRc; char tierErr[320];
     long long overAfterBegin;       // reads flagged by the probe (counters[3] after begin_kernel)
     struct BatchArgs { int64_t n_reads; const bbidx_read *reads; uint8_t *bases; int64_t minus_delta; const int8_t *baseScores; const int32_t *keyinfo; } batch;
+    // bbmap_map_batch (host buffers in, packed site lists out): device copies the context keeps between calls, grown on demand
+    struct HostIO { void *p[7]; size_t cap[7]; } hio;      // reads, bases (both strands), base scores, keyinfo, counts, offsets, packed
 };
 
 static thread_local char g_merr[320];
@@ -1088,6 +1090,7 @@ extern "C" void bbmap_destroy(bbmap_ctx *c) {
     if (c->tierThread.joinable()) c->tierThread.join();
     if (c->tier) bbmap_destroy(c->tier);
     if (c->d_packTmp) (void)hipFree(c->d_packTmp);
+    for (int i = 0; i < 7; i++) if (c->hio.p[i]) (void)hipFree(c->hio.p[i]);
     if (c->tierStream) (void)hipStreamDestroy(c->tierStream);
     if (c->dpStream) (void)hipStreamDestroy(c->dpStream);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
@@ -1586,6 +1589,75 @@ extern "C" int bbmap_pack_sites_device(bbmap_ctx *c, void *stream_, int64_t n_re
     hipLaunchKernelGGL(bbmapper::pack_sites_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, c->d_ms, c->d_mcount, (const long long *)offsets, n,
                        c->cfg.max_sites, (long long)packed_cap, packed);
     MHIP(hipGetLastError());
+    return BBMAP_OK;
+}
+
+// Host-buffer form of the batch call, for a host that owns no device memory (the JNI glue, jni/hip_glue.c): uploads the batch,
+// maps it, packs the site lists and copies them back.  Lists of reads the overflow tier mapped are appended behind the packed ones.
+static int hio_grow(bbmap_ctx *c, int i, size_t need) {
+    if (need <= c->hio.cap[i]) return BBMAP_OK;
+    if (c->hio.p[i]) { (void)hipFree(c->hio.p[i]); c->hio.p[i] = nullptr; c->hio.cap[i] = 0; }
+    need += need / 4 + 256;
+    MHIP(hipMalloc(&c->hio.p[i], need));
+    c->hio.cap[i] = need;
+    return BBMAP_OK;
+}
+extern "C" int bbmap_map_batch(bbmap_ctx *c, int64_t n_reads, const bbidx_read *reads, const uint8_t *bases, int64_t bases_bytes,
+                               const int8_t *baseScores, const int32_t *keyinfo, int64_t keyinfo_ints, int32_t *nsites_out,
+                               int64_t *offsets_out, bbmap_msite *sites_out, int64_t sites_cap, int64_t *total_out) {
+    if (!c) return mfail(BBMAP_E_ARG, "bbmap_map_batch: null context");
+    if (n_reads < 0 || n_reads > c->cfg.max_reads) return mfail(BBMAP_E_ARG, "bbmap_map_batch: more reads than the context was made for");
+    if (total_out) *total_out = 0;
+    if (n_reads == 0) return BBMAP_OK;
+    if (!reads || !bases || !baseScores || !keyinfo || !nsites_out || !offsets_out || (sites_cap > 0 && !sites_out) || sites_cap < 0 ||
+        bases_bytes < 0 || keyinfo_ints < 0)
+        return mfail(BBMAP_E_ARG, "bbmap_map_batch: bad argument");
+    for (int64_t r = 0; r < n_reads; r++) {
+        const bbidx_read &rd = reads[r];
+        if (rd.len < 0 || rd.bases_off < 0 || rd.bases_off + rd.len > bases_bytes)
+            return mfail(BBMAP_E_ARG, "bbmap_map_batch: a read lies outside the bases buffer");
+        if (rd.nkeys < 0 || rd.keys_off < 0 || rd.keys_off + 2LL * rd.nkeys > keyinfo_ints)
+            return mfail(BBMAP_E_ARG, "bbmap_map_batch: a read's key offsets and scores lie outside keyinfo");
+    }
+    MHIP(hipSetDevice(c->cfg.device));
+    const size_t nb = (size_t)bases_bytes;
+    MTRY(hio_grow(c, 0, (size_t)n_reads * sizeof(bbidx_read)));
+    MTRY(hio_grow(c, 1, 2 * nb + 16));
+    MTRY(hio_grow(c, 2, nb + 16));
+    MTRY(hio_grow(c, 3, (size_t)keyinfo_ints * 4 + 16));
+    MTRY(hio_grow(c, 4, (size_t)(n_reads + 1) * 4));
+    MTRY(hio_grow(c, 5, (size_t)(n_reads + 1) * 8));
+    MTRY(hio_grow(c, 6, (size_t)(sites_cap > 0 ? sites_cap : 1) * sizeof(bbmap_msite)));
+    MHIP(hipMemcpy(c->hio.p[0], reads, (size_t)n_reads * sizeof(bbidx_read), hipMemcpyHostToDevice));
+    MHIP(hipMemcpy(c->hio.p[1], bases, nb, hipMemcpyHostToDevice));
+    MHIP(hipMemcpy(c->hio.p[2], baseScores, nb, hipMemcpyHostToDevice));
+    MHIP(hipMemcpy(c->hio.p[3], keyinfo, (size_t)keyinfo_ints * 4, hipMemcpyHostToDevice));
+    MTRY(bbmap_map_batch_device(c, nullptr, n_reads, (const bbidx_read *)c->hio.p[0], (uint8_t *)c->hio.p[1], (int64_t)nb,
+                                (const int8_t *)c->hio.p[2], (const int32_t *)c->hio.p[3]));
+    MTRY(bbmap_pack_sites_device(c, nullptr, n_reads, (int32_t *)c->hio.p[4], (int64_t *)c->hio.p[5], (bbmap_msite *)c->hio.p[6], sites_cap));
+    MHIP(hipMemcpy(nsites_out, c->d_mcount, (size_t)n_reads * 4, hipMemcpyDeviceToHost));      // counts, or the flags (-1, -2, -3)
+    MHIP(hipMemcpy(offsets_out, c->hio.p[5], (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost));
+    long long total = offsets_out[n_reads];
+    const long long have = total < sites_cap ? total : sites_cap;
+    if (have > 0) MHIP(hipMemcpy(sites_out, c->hio.p[6], (size_t)have * sizeof(bbmap_msite), hipMemcpyDeviceToHost));
+    bbmap_overflow_output ov;
+    MTRY(bbmap_get_overflow_output(c, &ov));
+    if (ov.n_reads > 0) {
+        std::vector<int32_t> ids((size_t)ov.n_reads), tn((size_t)ov.n_reads);
+        MHIP(hipMemcpy(ids.data(), ov.read_ids, (size_t)ov.n_reads * 4, hipMemcpyDeviceToHost));
+        MHIP(hipMemcpy(tn.data(), ov.out.nsites, (size_t)ov.n_reads * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < ov.n_reads; i++) {
+            const int32_t r = ids[(size_t)i];
+            if (r < 0 || r >= n_reads || nsites_out[r] != BBMAP_NSITES_IN_TIER) continue;
+            nsites_out[r] = tn[(size_t)i];
+            offsets_out[r] = total;
+            if (tn[(size_t)i] <= 0) continue;
+            if (total + tn[(size_t)i] <= sites_cap)
+                MHIP(hipMemcpy(sites_out + total, ov.out.sites + i * (int64_t)ov.out.cap, (size_t)tn[(size_t)i] * sizeof(bbmap_msite), hipMemcpyDeviceToHost));
+            total += tn[(size_t)i];
+        }
+    }
+    if (total_out) *total_out = total;
     return BBMAP_OK;
 }
 

@@ -562,6 +562,16 @@ void bbmap_destroy(bbmap_ctx *ctx);
 int bbmap_map_batch_device(bbmap_ctx *ctx, void *stream, int64_t n_reads, const bbidx_read *reads, uint8_t *bases,
                            int64_t minus_delta, const int8_t *baseScores, const int32_t *keyinfo);
 int bbmap_get_output(bbmap_ctx *ctx, bbmap_output *out);
+/* Host-buffer form, for a host that owns no device memory (the JNI glue, jni/hip_glue.c: Java cannot allocate HBM).  bases holds the
+ * plus strands only (bases_bytes bytes, baseScores the same length; both required).  The call uploads the batch into device
+ * buffers the context keeps, maps it as bbmap_map_batch_device does and returns the site lists without their empty slots:
+ * read r has nsites_out[r] sites at sites_out[offsets_out[r] ...] -- or nsites_out[r] = BBMAP_NSITES_OVERFLOW /
+ * BBMAP_NSITES_MATE_OVERFLOW when even the overflow tier could not hold its list.  offsets_out has n_reads + 1 entries.  Lists
+ * the overflow tier produced are appended behind the others.  *total_out = records produced; records beyond sites_cap are not
+ * written (call again with a larger array).  The fill logs stay on the device (bbmap_get_output). */
+int bbmap_map_batch(bbmap_ctx *ctx, int64_t n_reads, const bbidx_read *reads, const uint8_t *bases, int64_t bases_bytes,
+                    const int8_t *baseScores, const int32_t *keyinfo, int64_t keyinfo_ints, int32_t *nsites_out,
+                    int64_t *offsets_out, bbmap_msite *sites_out, int64_t sites_cap, int64_t *total_out);
 /* The overflow tier's results for the last batch: n_reads = 0 when no read needed it.  Tier read i is read read_ids[i] of the
  * batch (ascending; pairs keep their two mates adjacent); `out` is laid out like the main output with the tier's own cap, and its
  * job logs number the reads 0..n_reads-1 in tier order. */

@@ -1,7 +1,9 @@
 // Exercises the Java_* entry points of libbbtoolsjni.so against a mock JNIEnv (no JVM in this image): arrays are plain
 // buffers behind jobject handles, the function table carries the calls the shim makes, and the mock FAILS the test if a
 // critical region is open while any other JNI call is made or while more than one region is open (the JNI
-// specification forbids blocking inside a critical region).  Usage: mock_jni_test merge | gpu | threads [N]   (exit code 0 = pass)
+// specification forbids blocking inside a critical region).  Usage: mock_jni_test merge | gpu | threads [N] | glue   (exit code 0 = pass)
+// `glue`: the natives of jni/hip_glue.c (the Java classes under jni/java/align2/) with direct-buffer arguments: the batched aligner,
+// the index probe and the whole mapper flow through the JNI layer equal the same calls on the C ABI.
 // `threads`: N mapping threads (default 32), each with its own arrays like one MSA object per thread, call the two fill symbols
 // concurrently; every result and every plane must equal what the same call gave alone, and the calls/s of 1 and N threads are
 // printed.
@@ -15,6 +17,7 @@
 
 #include "jni_min.h"
 #include "bbmerge_overlap.h"
+#include "bbmap_amd.h"
 
 struct _jobject { void *data; int len; int elem; };
 static thread_local int g_critical = 0;  // open critical regions of the calling thread
@@ -34,6 +37,11 @@ static void mGetFloat(JNIEnv *, jfloatArray a, jsize s, jsize l, jfloat *b) { ge
 static void mSetInt(JNIEnv *, jintArray a, jsize s, jsize l, const jint *b) { setRegion(a, s, l, b); }
 static void mSetLong(JNIEnv *, jlongArray a, jsize s, jsize l, const jlong *b) { setRegion(a, s, l, b); }
 static void mSetFloat(JNIEnv *, jfloatArray a, jsize s, jsize l, const jfloat *b) { setRegion(a, s, l, b); }
+static jobject mGetObjectArrayElement(JNIEnv *, jobjectArray a, jsize i) { touch(); return ((jobject *)a->data)[i]; }
+static void mDeleteLocalRef(JNIEnv *, jobject) { touch(); }
+static void *mGetDirectBufferAddress(JNIEnv *, jobject b) { touch(); return b->data; }
+static jlong mGetDirectBufferCapacity(JNIEnv *, jobject b) { touch(); return b->len; }
+static void mSetByte(JNIEnv *, jbyteArray a, jsize s, jsize l, const jbyte *b) { setRegion(a, s, l, b); }
 static void *mGetCritical(JNIEnv *, jarray a, jboolean *) { if (g_critical) g_violations++; g_critical++; return a->data; }
 static void mReleaseCritical(JNIEnv *, jarray, void *, jint) { g_critical--; }
 
@@ -44,6 +52,18 @@ jint Java_align2_BandedAlignerJNI_alignForwardJNI(JNIEnv *, jobject, jbyteArray,
 jint Java_jgi_BBMergeOverlapper_mateByOverlapJNI(JNIEnv *, jclass, jbyteArray, jbyteArray, jbyteArray, jbyteArray, jfloatArray, jfloatArray, jintArray, jint, jint, jint, jint, jint, jint, jint);
 jint Java_jgi_BBMergeOverlapper_mateByOverlapRatioJNI_1WithQualities(JNIEnv *, jclass, jbyteArray, jbyteArray, jbyteArray, jbyteArray, jfloatArray, jfloatArray, jintArray, jint, jint, jint, jint, jfloat, jfloat, jfloat);
 jint Java_jgi_BBMergeOverlapper_mateByOverlapRatioJNI(JNIEnv *, jclass, jbyteArray, jbyteArray, jintArray, jint, jint, jint, jint, jfloat, jfloat, jfloat, jfloat, jfloat);
+// jni/hip_glue.c
+jlong Java_align2_MultiStateAligner11tsHIP_create(JNIEnv *, jclass, jint, jint, jint, jint, jfloat, jint);
+void Java_align2_MultiStateAligner11tsHIP_destroy(JNIEnv *, jclass, jlong);
+void Java_align2_MultiStateAligner11tsHIP_alignBatch(JNIEnv *, jclass, jlong, jint, jobject, jobject, jint, jobject, jint, jobject, jobject, jint);
+jlong Java_align2_BBIndexHIP_build(JNIEnv *, jclass, jint, jint, jint, jint, jobjectArray);
+void Java_align2_BBIndexHIP_destroy(JNIEnv *, jclass, jlong);
+void Java_align2_BBIndexHIP_setMaxReadLen(JNIEnv *, jclass, jlong, jint);
+void Java_align2_BBIndexHIP_findBatch(JNIEnv *, jclass, jlong, jint, jobject, jobject, jobject, jint, jobject, jint, jobject, jint, jobject);
+jlong Java_align2_BBMapHIP_create(JNIEnv *, jclass, jlong, jint, jboolean, jint, jint, jint);
+void Java_align2_BBMapHIP_destroy(JNIEnv *, jclass, jlong);
+jlong Java_align2_BBMapHIP_mapBatch(JNIEnv *, jclass, jlong, jint, jobject, jobject, jobject, jint, jobject, jint, jobject, jobject, jobject, jint);
+jint Java_align2_BBMapHIP_lastError(JNIEnv *, jclass, jbyteArray);
 int bbjni_fill(int, const uint8_t *, int, const uint8_t *, int, int, int, int, int32_t *, int64_t *, int32_t *, int, int, int, float);
 void bbjni_release_thread(void);
 void bbjni_release_all(void);
@@ -246,6 +266,139 @@ static int test_threads(JNINativeInterface_ *tbl, int nthreads) {
     return 0;
 }
 
+// The natives behind jni/java/align2/*.java.  Every bulk argument is a "direct buffer" (a plain allocation behind a handle here).
+static int test_glue(JNIEnv *env) {
+    unsigned seed = 5;      // (bases from bits 22-23 of the generator: its low bits repeat every 1,024 draws)
+    // ---- MultiStateAligner11tsHIP.alignBatch == bbmsa_align_batch
+    {
+        const int maxRows = 200, maxColumns = 600, n = 96;
+        std::vector<uint8_t> ref(20000), reads;
+        for (auto &x : ref) x = (uint8_t)"ACGT"[(rnd(seed) >> 14) & 3];
+        std::vector<bbmsa_job> jobs((size_t)n);
+        for (int i = 0; i < n; i++) {
+            const int st = 500 + (int)(rnd(seed) % 18000), len = 100 + (int)(rnd(seed) % 51);
+            std::vector<uint8_t> rd(ref.begin() + st, ref.begin() + st + len + 8);
+            for (int k = 0; k < (int)(rnd(seed) % 4); k++) rd[rnd(seed) % (unsigned)len] = (uint8_t)"ACGT"[(rnd(seed) >> 14) & 3];
+            if (i % 4 == 1) rd.erase(rd.begin() + 50, rd.begin() + 50 + 1 + (int)(rnd(seed) % 5));
+            rd.resize((size_t)len);
+            bbmsa_job &j = jobs[(size_t)i];
+            j.read_off = (int64_t)reads.size(); j.ref_off = 0; j.read_len = len; j.ref_len = (int)ref.size();
+            j.refStartLoc = st - 6; j.refEndLoc = st + len + 12; j.minScore = (int)(0.56f * (70 + 100 * (len - 1)));
+            j.flags = BBMSA_FILL_AND_SCORE_LIMITED | BBMSA_DO_TRACEBACK;
+            reads.insert(reads.end(), rd.begin(), rd.end());
+        }
+        const int stride = 1024;
+        std::vector<bbmsa_result> res((size_t)n), res2((size_t)n);
+        std::vector<uint8_t> match((size_t)n * stride, 0), match2((size_t)n * stride, 0);
+        memset(res.data(), 0, res.size() * sizeof(bbmsa_result)); memset(res2.data(), 0, res2.size() * sizeof(bbmsa_result));
+        const jlong h = Java_align2_MultiStateAligner11tsHIP_create(env, nullptr, 0, maxRows, maxColumns, 0, 0.0f, 0);
+        CHECK(h != 0 && g_thrown == 0);
+        _jobject bj{jobs.data(), (int)(jobs.size() * sizeof(bbmsa_job)), 1}, br{reads.data(), (int)reads.size(), 1}, bf{ref.data(), (int)ref.size(), 1};
+        _jobject bo{res.data(), (int)(res.size() * sizeof(bbmsa_result)), 1}, bm{match.data(), (int)match.size(), 1};
+        Java_align2_MultiStateAligner11tsHIP_alignBatch(env, nullptr, h, n, &bj, &br, (jint)reads.size(), &bf, (jint)ref.size(), &bo, &bm, stride);
+        CHECK(g_thrown == 0);
+        CHECK(bbmsa_align_batch((bbmsa_ctx *)(intptr_t)h, n, jobs.data(), reads.data(), (int64_t)reads.size(), ref.data(), (int64_t)ref.size(),
+                                res2.data(), match2.data(), stride) == BBMAP_OK);
+        CHECK(memcmp(res.data(), res2.data(), res.size() * sizeof(bbmsa_result)) == 0 && match == match2);
+        int scored = 0;
+        for (auto &r : res) scored += r.score_len > 0 && r.match_len > 0;
+        CHECK(scored > n / 2);
+        // a buffer that is too small is refused with an exception, nothing runs
+        _jobject small{res.data(), 16, 1};
+        Java_align2_MultiStateAligner11tsHIP_alignBatch(env, nullptr, h, n, &bj, &br, (jint)reads.size(), &bf, (jint)ref.size(), &small, &bm, stride);
+        CHECK(g_thrown == 1);
+        g_thrown = 0;
+        Java_align2_MultiStateAligner11tsHIP_destroy(env, nullptr, h);
+    }
+    // ---- BBIndexHIP.build / findBatch and BBMapHIP.mapBatch == the C ABI; reads come home to their origins
+    {
+        const int glen = 300000, nreads = 400, L = 150;
+        std::vector<jbyte> chrom((size_t)glen);
+        for (auto &x : chrom) x = "ACGT"[(rnd(seed) >> 14) & 3];
+        _jobject chromArr{chrom.data(), glen, 1};
+        jobject arr[2] = {nullptr, &chromArr};
+        _jobject outer{arr, 2, 8};
+        const jlong ix = Java_align2_BBIndexHIP_build(env, nullptr, 0, BBIDX_PROFILE_BBMAP, 13, -1, &outer);
+        CHECK(ix != 0 && g_thrown == 0);
+        Java_align2_BBIndexHIP_setMaxReadLen(env, nullptr, ix, L);
+        bbkeys_config kc;
+        CHECK(bbkeys_default_config(BBIDX_PROFILE_BBMAP, &kc) == BBMAP_OK);
+        kc.k = 13;
+        std::vector<uint8_t> bases((size_t)nreads * L);
+        std::vector<int8_t> bscores((size_t)nreads * L);
+        std::vector<bbidx_read> recs((size_t)nreads);
+        std::vector<int32_t> keyinfo;
+        std::vector<int> origin((size_t)nreads);
+        for (int r = 0; r < nreads; r++) {
+            const int st = 1000 + (int)(rnd(seed) % (unsigned)(glen - 3000));
+            origin[(size_t)r] = st;
+            uint8_t *b = bases.data() + (size_t)r * L;
+            memcpy(b, chrom.data() + st, (size_t)L);
+            for (int k = 0; k < (int)(rnd(seed) % 4); k++) b[rnd(seed) % L] = (uint8_t)"ACGT"[(rnd(seed) >> 14) & 3];
+            int32_t offs[64], ks[64];
+            const int nk = bbkeys_make(&kc, b, nullptr, L, offs, ks, 64, bscores.data() + (size_t)r * L);
+            CHECK(nk > 0);
+            recs[(size_t)r] = bbidx_read{(int64_t)r * L, (int64_t)keyinfo.size(), L, nk};
+            keyinfo.insert(keyinfo.end(), offs, offs + nk);
+            keyinfo.insert(keyinfo.end(), ks, ks + nk);
+        }
+        const int maxSites = 32;
+        std::vector<bbidx_site> sites((size_t)nreads * maxSites), sites2((size_t)nreads * maxSites);
+        std::vector<int32_t> ns((size_t)nreads, -9), ns2((size_t)nreads, -9);
+        memset(sites.data(), 0, sites.size() * sizeof(bbidx_site)); memset(sites2.data(), 0, sites2.size() * sizeof(bbidx_site));
+        _jobject bR{recs.data(), (int)(recs.size() * sizeof(bbidx_read)), 1}, bB{bases.data(), (int)bases.size(), 1}, bS{bscores.data(), (int)bscores.size(), 1};
+        _jobject bK{keyinfo.data(), (int)(keyinfo.size() * 4), 1}, bO{sites.data(), (int)(sites.size() * sizeof(bbidx_site)), 1}, bN{ns.data(), (int)(ns.size() * 4), 1};
+        Java_align2_BBIndexHIP_findBatch(env, nullptr, ix, nreads, &bR, &bB, &bS, (jint)bases.size(), &bK, (jint)keyinfo.size(), &bO, maxSites, &bN);
+        CHECK(g_thrown == 0);
+        CHECK(bbidx_find_batch((bbidx_ctx *)(intptr_t)ix, nreads, recs.data(), bases.data(), bscores.data(), (int64_t)bases.size(), keyinfo.data(),
+                               (int64_t)keyinfo.size(), sites2.data(), maxSites, ns2.data()) == BBMAP_OK);
+        CHECK(ns == ns2);
+        for (int r = 0; r < nreads; r++)
+            for (int s2 = 0; s2 < ns[(size_t)r]; s2++)
+                CHECK(memcmp(&sites[(size_t)r * maxSites + s2], &sites2[(size_t)r * maxSites + s2], sizeof(bbidx_site)) == 0);
+        // the whole flow
+        const jlong mp = Java_align2_BBMapHIP_create(env, nullptr, ix, BBIDX_PROFILE_BBMAP, 0, nreads, L, maxSites);
+        CHECK(mp != 0 && g_thrown == 0);
+        const int cap = 8 * nreads;
+        std::vector<bbmap_msite> ms((size_t)cap);
+        std::vector<int32_t> mn((size_t)nreads, -9);
+        std::vector<int64_t> mo((size_t)nreads + 1, -9);
+        _jobject bMN{mn.data(), (int)(mn.size() * 4), 1}, bMO{mo.data(), (int)(mo.size() * 8), 1}, bMS{ms.data(), (int)(ms.size() * sizeof(bbmap_msite)), 1};
+        const jlong total = Java_align2_BBMapHIP_mapBatch(env, nullptr, mp, nreads, &bR, &bB, &bS, (jint)bases.size(), &bK, (jint)keyinfo.size(), &bMN, &bMO, &bMS, cap);
+        if (!(g_thrown == 0 && total > 0 && total <= cap)) fprintf(stderr, "mapBatch: thrown %d total %lld cap %d\n", (int)g_thrown, (long long)total, cap);
+        CHECK(g_thrown == 0 && total > 0 && total <= cap);
+        int home = 0, perfect = 0;
+        for (int r = 0; r < nreads; r++) {
+            CHECK(mn[(size_t)r] >= 0 && mo[(size_t)r] >= 0 && mo[(size_t)r] + mn[(size_t)r] <= total);
+            if (mn[(size_t)r] == 0) continue;
+            const bbmap_msite &t = ms[(size_t)mo[(size_t)r]];                       // lists are sorted: the first site is the best
+            home += t.chrom == 1 && t.strand == 0 && t.start == origin[(size_t)r] && t.stop == origin[(size_t)r] + L - 1;
+            perfect += t.perfect != 0;
+        }
+        CHECK(home >= nreads * 97 / 100 && perfect > nreads / 20);
+        // the same batch straight through the C ABI gives the same records
+        std::vector<bbmap_msite> ms2((size_t)cap);
+        std::vector<int32_t> mn2((size_t)nreads, -9);
+        std::vector<int64_t> mo2((size_t)nreads + 1, -9);
+        int64_t total2 = 0;
+        CHECK(bbmap_map_batch((bbmap_ctx *)(intptr_t)mp, nreads, recs.data(), bases.data(), (int64_t)bases.size(), bscores.data(), keyinfo.data(),
+                              (int64_t)keyinfo.size(), mn2.data(), mo2.data(), ms2.data(), cap, &total2) == BBMAP_OK);
+        CHECK(total2 == total && mn == mn2 && mo == mo2);
+        for (int64_t i = 0; i < total; i++)          // (match_job is an index into the fill log, whose order is the device's: not compared)
+            CHECK(memcmp(&ms[(size_t)i], &ms2[(size_t)i], offsetof(bbmap_msite, match_job)) == 0);
+        // an error surfaces as an exception and its text is readable through lastError
+        const jlong bad = Java_align2_BBMapHIP_mapBatch(env, nullptr, mp, nreads + 1, &bR, &bB, &bS, (jint)bases.size(), &bK, (jint)keyinfo.size(), &bMN, &bMO, &bMS, cap);
+        CHECK(bad == 0 && g_thrown == 1);
+        g_thrown = 0;
+        Java_align2_BBMapHIP_destroy(env, nullptr, mp);
+        Java_align2_BBIndexHIP_destroy(env, nullptr, ix);
+        printf("mock JNI glue: %d of %d reads mapped to their origin (%d perfect), %lld site records\n", home, nreads, perfect, (long long)total);
+    }
+    CHECK(g_violations == 0 && g_critical == 0 && g_thrown == 0);
+    printf("mock JNI glue: alignBatch, findBatch and mapBatch through the JNI layer equal the C ABI; direct buffers only, no critical region\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
     JNINativeInterface_ tbl;
     memset(&tbl, 0, sizeof tbl);
@@ -253,8 +406,11 @@ int main(int argc, char **argv) {
     tbl.GetByteArrayRegion = mGetByte; tbl.GetIntArrayRegion = mGetInt; tbl.GetLongArrayRegion = mGetLong; tbl.GetFloatArrayRegion = mGetFloat;
     tbl.SetIntArrayRegion = mSetInt; tbl.SetLongArrayRegion = mSetLong; tbl.SetFloatArrayRegion = mSetFloat;
     tbl.GetPrimitiveArrayCritical = mGetCritical; tbl.ReleasePrimitiveArrayCritical = mReleaseCritical;
+    tbl.GetObjectArrayElement = mGetObjectArrayElement; tbl.DeleteLocalRef = mDeleteLocalRef; tbl.SetByteArrayRegion = mSetByte;
+    tbl.GetDirectBufferAddress = mGetDirectBufferAddress; tbl.GetDirectBufferCapacity = mGetDirectBufferCapacity;
     JNIEnv_ env; env.functions = &tbl;
     if (argc > 1 && !strcmp(argv[1], "gpu")) return test_gpu(&env);
+    if (argc > 1 && !strcmp(argv[1], "glue")) return test_glue(&env);
     if (argc > 1 && !strcmp(argv[1], "threads")) return test_threads(&tbl, argc > 2 ? atoi(argv[2]) : 32);
     return test_merge(&env);
 }
