@@ -19,7 +19,7 @@ START_PAD = 8000
 BASES = np.frombuffer(b"ACGT", np.uint8)
 
 
-def make_reference(length, seed, pad=START_PAD, repeat_frac=0.0, families=2000):
+def make_reference(length, seed, pad=START_PAD, repeat_frac=0.0, families=2000, lead_n=0):
     """Uniform ACGT of `length` bases between N pads.  repeat_frac > 0 adds the repeat model of SURVEY.md 8(d): that share of
     the sequence is overwritten with copies of `families` repeat families (300-6000 bp, each copy diverged 1-15 %), so that
     k-mer list lengths are skewed like a real genome's (long lists, greedy trimming, many candidate sites)."""
@@ -44,13 +44,15 @@ def make_reference(length, seed, pad=START_PAD, repeat_frac=0.0, families=2000):
             placed += n
     ref = np.full(length + 2 * pad, ord("N"), np.uint8)
     ref[pad:pad + length] = body
+    if lead_n > 0:            # an undefined stretch at the chromosome's start (chr21: 6.6 Mbp of N before the first base)
+        ref[pad:pad + min(lead_n, length)] = ord("N")
     return ref
 
 
 def make_reads_and_jobs(ref, n_reads, read_len=150, seed=2, pad=START_PAD, align_pad=4,
                         min_ratio=0.56, perfect_frac=0.5, flags=FILL_AND_SCORE_LIMITED | DO_TRACEBACK,
                         chunk=131072, max_del=40, max_ins=12, long_del_frac=0.0, long_del=(300, 800), starts=None,
-                        hard_frac=0.0, del_model="short"):
+                        hard_frac=0.0, del_model="short", lo=0):
     """Returns (reads_blob uint8[n*read_len... variable], jobs structured array, truth dict).  starts: read start
     coordinates to use instead of drawing them; hard_frac: share of the reads that additionally get 8-12 % substitutions
     (mates the index probe tends to miss and the paired rescue has to find).  del_model: "short" = geometric lengths capped at
@@ -62,9 +64,10 @@ def make_reads_and_jobs(ref, n_reads, read_len=150, seed=2, pad=START_PAD, align
     if del_model == "randomreads":
         max_del = 400
     reach = max(max_del, long_del[1] if long_del_frac > 0 else 0)
-    start = rng.integers(pad, pad + body - read_len - reach - 8, size=n, dtype=np.int64)
+    # lo: reads start at or after pad + lo (the reference's leading N-run: the generator draws from defined sequence)
+    start = rng.integers(pad + lo, pad + body - read_len - reach - 8, size=n, dtype=np.int64)
     if starts is not None:
-        start = np.clip(np.asarray(starts, np.int64), pad, pad + body - read_len - reach - 9)
+        start = np.clip(np.asarray(starts, np.int64), pad + lo, pad + body - read_len - reach - 9)
     imperfect = rng.random(n) >= perfect_frac
     # event draws (only applied to imperfect reads)
     n_snp = np.where(imperfect & (rng.random(n) < 0.4), rng.integers(1, 4, size=n), 0)
@@ -148,7 +151,8 @@ def revcomp_rows(reads2d):
     return _COMP[reads2d[:, ::-1]]
 
 
-def make_pairs(ref, n_pairs, read_len=150, seed=3, pad=START_PAD, hard_frac=0.03, middle=(-100, 100), del_model="short"):
+def make_pairs(ref, n_pairs, read_len=150, seed=3, pad=START_PAD, hard_frac=0.03, middle=(-100, 100), del_model="short",
+               perfect_frac=0.5, lo=0):
     """Synthetic read pairs as randomreads.sh makes them (current/align2/RandomReads3.java:1726-1727 mateMiddleMin/Max = -100/100,
     mates on opposite strands): the unsequenced middle between the mates is triangular on [-100, 100] (negative = the mates
     overlap), each mate carries the mutated mix of make_reads_and_jobs, a share hard_frac of the mates is additionally riddled
@@ -158,10 +162,10 @@ def make_pairs(ref, n_pairs, read_len=150, seed=3, pad=START_PAD, hard_frac=0.03
     rng = np.random.Generator(np.random.PCG64(seed))
     body = len(ref) - 2 * pad
     mid = np.rint(rng.triangular(middle[0], 0.5 * (middle[0] + middle[1]), middle[1], size=n_pairs)).astype(np.int64)
-    left = rng.integers(pad, pad + body - 2 * read_len - middle[1] - 64 - (400 if del_model == "randomreads" else 0), size=n_pairs, dtype=np.int64)
+    left = rng.integers(pad + lo, pad + body - 2 * read_len - middle[1] - 64 - (400 if del_model == "randomreads" else 0), size=n_pairs, dtype=np.int64)
     right = left + read_len + mid
-    ra, _, ta = make_reads_and_jobs(ref, n_pairs, read_len=read_len, seed=seed * 7919 + 1, pad=pad, starts=left, hard_frac=hard_frac, del_model=del_model)
-    rb, _, tb = make_reads_and_jobs(ref, n_pairs, read_len=read_len, seed=seed * 7919 + 2, pad=pad, starts=right, hard_frac=hard_frac, del_model=del_model)
+    ra, _, ta = make_reads_and_jobs(ref, n_pairs, read_len=read_len, seed=seed * 7919 + 1, pad=pad, starts=left, hard_frac=hard_frac, del_model=del_model, perfect_frac=perfect_frac, lo=lo)
+    rb, _, tb = make_reads_and_jobs(ref, n_pairs, read_len=read_len, seed=seed * 7919 + 2, pad=pad, starts=right, hard_frac=hard_frac, del_model=del_model, perfect_frac=perfect_frac, lo=lo)
     ra = ra.reshape(n_pairs, read_len)
     rb = revcomp_rows(rb.reshape(n_pairs, read_len))              # the right-hand mate is read from the other strand
     flip = rng.random(n_pairs) < 0.5                               # fragment from the minus strand: mate 1 is the right-hand one

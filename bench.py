@@ -35,11 +35,14 @@ HG38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345
         135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
         46709983, 50818468, 156040895, 57227415]
 
+LEAD_N = {"chr21": [6600000]}      # undefined bases at the start of each chromosome (chr21's 6.6 Mbp leading N-run)
+
 WORKLOADS = {
     # name: (chromosome lengths, paired, description)
     "hg38": (HG38, True, "configs[3], one GPU's shard: synthetic hg38-shaped reference (24 chromosomes with the GRCh38 lengths, "
                          "%d bp, 10 %% repeat families, seeds 38+i)" % sum(HG38)),
-    "chr21": ([46709983], True, "configs[2]: synthetic chr21-sized reference (46709983 bp, 10 % repeat families, seed 38)"),
+    "chr21": ([46709983], True, "configs[2]: synthetic chr21-sized reference (46709983 bp of which the first 6.6 Mbp are N as on the real "
+                                "chromosome, 10 % repeat families, seed 38)"),
     "ecoli": ([4641652], False, "configs[1]: synthetic E. coli K-12 sized reference (4641652 bp, seed 38)"),
 }
 
@@ -81,7 +84,8 @@ def shared_reference(name, lens, repeat_frac, local_rank, world_local):
 
     def generate():
         fam = max(50, 2000 // len(lens))
-        return [W.make_reference(n, seed=38 + i, repeat_frac=repeat_frac, families=fam) for i, n in enumerate(lens)]
+        lead = LEAD_N.get(name, [0] * len(lens))
+        return [W.make_reference(n, seed=38 + i, repeat_frac=repeat_frac, families=fam, lead_n=lead[i]) for i, n in enumerate(lens)]
     if world_local <= 1:
         return generate(), None
     total = sum(n + 2 * W.START_PAD for n in lens)
@@ -114,8 +118,11 @@ def shared_reference(name, lens, repeat_frac, local_rank, world_local):
 DEL_MODEL = "randomreads"      # deletions as sh/randomreads.sh draws them (1..400 bases); "short" = rounds 1-2's cap of 40
 
 
-def make_batch(chroms, n_reads, paired, seed):
-    """n_reads reads (n_reads / 2 pairs) drawn from the chromosomes in proportion to their lengths."""
+def make_batch(chroms, n_reads, paired, seed, read_set="mutated", lead=None):
+    """n_reads reads (n_reads / 2 pairs) drawn from the chromosomes in proportion to their lengths.  read_set: "mutated" = the
+    reference generator's commented-out stress mix (snp .4 / ins .2 / del .2 / n .2 of the imperfect half, perfect .5,
+    current/align2/RandomReads3.java:74-79) plus 3 % hard mates; "default" = sh/randomreads.sh's defaults, every rate 0: reads are
+    exact copies of the reference (its quality-driven substitution errors are not modelled: the reads carry no qualities)."""
     from bbmap_amd import workload as W
     L = 150
     units = n_reads // 2 if paired else n_reads
@@ -123,13 +130,15 @@ def make_batch(chroms, n_reads, paired, seed):
     share = np.floor(units * lens / lens.sum()).astype(np.int64)
     share[0] += units - share.sum()
     parts = []
+    pf, hard = (0.5, 0.03) if read_set == "mutated" else (1.0, 0.0)
     for i, (c, m) in enumerate(zip(chroms, share)):
         if m <= 0:
             continue
+        lo = lead[i] if lead else 0
         if paired:
-            parts.append(W.make_pairs(c, int(m), read_len=L, seed=seed + 7 * i, del_model=DEL_MODEL)[0].reshape(-1, 2 * L))
+            parts.append(W.make_pairs(c, int(m), read_len=L, seed=seed + 7 * i, del_model=DEL_MODEL, perfect_frac=pf, hard_frac=hard, lo=lo)[0].reshape(-1, 2 * L))
         else:
-            parts.append(W.make_reads_and_jobs(c, int(m), read_len=L, seed=seed + 7 * i, del_model=DEL_MODEL)[0].reshape(-1, L))
+            parts.append(W.make_reads_and_jobs(c, int(m), read_len=L, seed=seed + 7 * i, del_model=DEL_MODEL, perfect_frac=pf, lo=lo)[0].reshape(-1, L))
     allp = np.concatenate(parts)
     perm = np.random.Generator(np.random.PCG64(seed)).permutation(len(allp))      # mix the chromosomes within the batch
     return np.ascontiguousarray(allp[perm]).reshape(-1)
@@ -512,6 +521,7 @@ def pacbio_main(args):
                        "dp_gcups_visited": (cells / (ms["ms_slow"] * 1e-3) / 1e9) if cells and ms["ms_slow"] > 0 else 0.0,
                        "probe_list_entries_per_step": int(ps[0] + ps[1]), "probe_extend_calls_per_step": int(ps[2]), "probe_stats_raw": [int(x) for x in ps],
                        "stage_ms": {key[3:]: round(v, 3) for key, v in ms.items()}, "index_build_s_gpu": t_ix, "parity": parity},
+            "default_read_set": default_res,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": dom, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(dom_bytes), "kernels": kern,
                          "note": "both kernels are instruction-bound integer work (heap merge of ~1,400 lists; ~180 VALU per DP cell): the HBM "
@@ -549,7 +559,8 @@ def main():
     ap.add_argument("--max-sites", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=600)
-    ap.add_argument("--stream-steps", type=int, default=3, help="steps of the PCIe-inclusive streaming region (0 = skip it)")
+    ap.add_argument("--stream-steps", type=int, default=10, help="steps of the PCIe-inclusive streaming region (0 = skip it)")
+    ap.add_argument("--default-set-steps", type=int, default=3, help="steps timed on the 'default' (unmutated) read set after the main region (0 = skip)")
     args = ap.parse_args()
 
     if args.workload == "pacbio_dp":
@@ -582,7 +593,8 @@ def main():
     chroms, shm_path = shared_reference(args.workload, lens, repeat_frac, local_rank, world_local)
     log("reference ready")
     # every rank draws its own shard of reads (same generator, different stream); the index is replicated per GPU
-    reads = make_batch(chroms, n, paired, D.shard_seed(4, rank))
+    lead = LEAD_N.get(args.workload)
+    reads = make_batch(chroms, n, paired, D.shard_seed(4, rank), lead=lead)
     log("reads ready")
     # Key offsets and scores as quickMap makes them for a read without qualities (AbstractMapThread.java:659-728 through the product's
     # bbkeys_make): all key error probabilities 0, density window floor 1.5 -> 18 keys for 150 bases, every key score
@@ -610,12 +622,13 @@ def main():
     t_ix = time.perf_counter() - t_ix
     log("index built")
     oi, cpu = None, None
-    if rank == 0 and (args.parity_sample > 0 or (world == 1 and not args.no_cpu_baseline)):
+    # the CPU baseline runs on rank 0 whatever the world size, before the ranks' barrier (the others wait there)
+    if rank == 0 and (args.parity_sample > 0 or not args.no_cpu_baseline):
         oi = oracle_index(di, chroms, k)
         if paired:
             oi.s.p.quitAfterTwoPerfects = 0
         log("index exported")
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(oi, reads, L, paired, offsets, key_scores)
         log("cpu baseline done")
 
@@ -650,7 +663,7 @@ def main():
     stream_res = None
     if args.stream_steps > 0:
         # the PCIe-inclusive rate: distinct batches, uploads and downloads inside the timed region (reported beside `value`)
-        reads_b = make_batch(chroms, n, paired, D.shard_seed(5, rank))
+        reads_b = make_batch(chroms, n, paired, D.shard_seed(5, rank), lead=lead)
         if dist is not None:
             dist.barrier()
         try:
@@ -678,6 +691,37 @@ def main():
         parity = parity_sample(mp, out, oi, reads, L, paired, offsets, key_scores, min(n, args.parity_sample))
         if parity["mismatches"]:
             raise SystemExit("parity check failed: %s" % parity)
+    # ---- the "default" read set (randomreads.sh defaults: unmutated reads) beside the mutated one: a second, shorter timed region
+    default_res = None
+    if args.default_set_steps > 0:
+        reads_d = make_batch(chroms, n, paired, D.shard_seed(6, rank), read_set="default", lead=lead)
+        mp.load_reads(reads_d)
+        mp.step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        td = time.perf_counter()
+        for _ in range(args.default_set_steps):
+            mp.step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        d_el = time.perf_counter() - td
+        if dist is not None:
+            d_el = D.max_over_ranks(d_el, dist, red_dev)
+        std = mp.stats()
+        od = mp.fetch(with_match=False)
+        topd = od["sites"][:, 0]
+        default_res = {"value": n * world * args.default_set_steps / d_el, "unit": "reads/s", "steps": args.default_set_steps,
+                       "ms_per_step": 1e3 * d_el / args.default_set_steps,
+                       "mapped_fraction": float(((od["nsites"] > 0) & (topd["slowScore"] >= minScore)).mean()),
+                       "perfect_fraction": float(((od["nsites"] > 0) & (topd["perfect"] != 0)).mean()),
+                       "fills_per_step": int(std["fills"] + std["gapped_fills"]), "rescue_scans_per_step": int(std["rescue_scans"]),
+                       "stage_ms": {key[3:]: round(float(v), 3) for key, v in std.items() if key.startswith("ms_")},
+                       "what": "same reference and batch size, reads as sh/randomreads.sh makes them by default (every mutation rate 0; "
+                               "seed 6); stage_ms of the last step"}
+        del reads_d, od
+        log("default read set done")
     if rank == 0:
         from bbmap_amd import workload as W2
         total_reads = n * world * args.steps
@@ -697,7 +741,7 @@ def main():
         dom_ms, dom_bytes = kern[dom]["ms"], kern[dom]["algorithmic_bytes"]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_r03.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
@@ -713,11 +757,14 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "%s; k=%d index built on the device, resident in HBM; %d x %d-bp %s per GPU and step (seed 4, "
-                                   "mutated mix, 3 %% hard mates); per step: index probe (BBIndex.findAdvanced) -> %sungapped scores -> "
+                                   "mutated mix with deletions of 1..400 bases, 3 %% hard mates); per step: index probe (BBIndex.findAdvanced) -> %sungapped scores -> "
                                    "scoreSlow DP + traceback in rounds%s" % (
                                        desc, k, n // 2 if paired else n, L, "read pairs (2 x 150, opposite strands, insert 200-400)" if paired
                                        else "single-ended reads", "mate pairing + list trimming -> " if paired else "list trimming -> ",
-                                       " -> rescue (quickRescue scan + slowRescue DP) for unpaired mates" if paired else ""),
+                                       (" -> rescue (quickRescue scan + slowRescue DP) for unpaired mates" if paired else "") +
+                                       ".  Not carried over from a real run: the adaptive state DYNAMIC_INSERT_LENGTH keeps per mapping thread "
+                                       "(AVERAGE_PAIR_DIST follows the pairs seen so far, BBMapThread.java:1307-1309; here it stays at its initial "
+                                       "100) and the 'mating is not working' switch that turns pairing off after many unpaired reads"),
                        "reads_per_gpu_per_step": n, "read_len": L, "paired": paired, "keys_per_read": nkeys, "max_sites": args.max_sites,
                        "fills_per_step": st["fills"] + st["gapped_fills"], "fills_second_context": st["gapped_fills"],
                        "refills_per_step": st["refills"], "scoreslow_rounds": st["rounds"], "fills_ahead_dropped_per_step": st["fills_dropped"],
@@ -736,6 +783,7 @@ def main():
                 "what": "two distinct batches alternating; batch i+1 uploaded from pinned host memory and batch i's results (packed site "
                         "lists, per-read counts, both fill logs with traceback strings) downloaded to pinned host memory on a second "
                         "stream while a batch is mapped; per GPU bytes"},
+            "default_read_set": default_res,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": dom, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(dom_bytes), "kernels": kern},
