@@ -1331,6 +1331,16 @@ static void add_dp_ms(bbmap_ctx *c, bool plain, bool gapped) {
     float k3[3];
     if (plain && bbmsa_last_kernel_ms3(c->msa, k3) == BBMAP_OK) { c->stats.ms_dp_narrow += k3[0]; c->stats.ms_dp_wave += k3[1]; c->stats.ms_dp_generic += k3[2]; }
     if (gapped && bbmsa_last_kernel_ms3(c->msaGapped, k3) == BBMAP_OK) c->stats.ms_dp_gapped += k3[0] + k3[1] + k3[2];
+    static const bool show = getenv("BBMAP_DP_COUNTS") != nullptr;      // where the fills of a launch sequence ended up (experiments)
+    if (show) {
+        int64_t n4[4];
+        if (plain && bbmsa_last_counts(c->msa, n4) == BBMAP_OK)
+            fprintf(stderr, "dp counts plain : narrow finished %lld, narrow handed on %lld, wavefront list %lld, to the wide/generic pass %lld\n",
+                    (long long)n4[0], (long long)n4[1], (long long)n4[2], (long long)n4[3]);
+        if (gapped && bbmsa_last_counts(c->msaGapped, n4) == BBMAP_OK)
+            fprintf(stderr, "dp counts second: narrow finished %lld, narrow handed on %lld, wavefront list %lld, to the wide/generic pass %lld\n",
+                    (long long)n4[0], (long long)n4[1], (long long)n4[2], (long long)n4[3]);
+    }
 }
 
 static void tier_start_async(bbmap_ctx *c, long long found);
