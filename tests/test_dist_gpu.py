@@ -22,18 +22,38 @@ def _free_port():
     return p
 
 
-def _map(reads, ref):
+def _lists(out):
+    """per read: (nsites, records) with the overflow tier's lists folded in (nsites == -3 in the main list points there)"""
+    tier = out.get("overflow")
+    where = {}
+    if tier is not None:
+        where = {int(r): i for i, r in enumerate(tier["read_ids"])}
+    res = []
+    for r in range(len(out["nsites"])):
+        n = int(out["nsites"][r])
+        if n == -3:
+            i = where[r]
+            n = int(tier["nsites"][i])
+            res.append((n, tier["sites"][i][:max(0, n)].copy()))
+        else:
+            res.append((n, out["sites"][r][:max(0, n)].copy()))
+    return res
+
+
+def _map(reads, ref, max_sites=32):
     from bbmap_amd.index import DeviceIndex
     from bbmap_amd.mapper import Mapper
     from bbmap_amd import workload as W
     di = DeviceIndex.build([ref], k=K)
     offs = W.make_offsets(L, K, 1.9)
-    mp_ = Mapper(di, reads.size // L, L, offs, [100 * K] * len(offs), paired=True, max_sites=32)
+    mp_ = Mapper(di, reads.size // L, L, offs, [100 * K] * len(offs), paired=True, max_sites=max_sites)
     mp_.load_reads(reads)
     mp_.step()
     out = mp_.fetch(with_match=False)
+    st = mp_.stats()
     mp_.close()
     di.close()
+    out["stats"] = st
     return out
 
 
@@ -44,7 +64,7 @@ def _data():
     return ref, reads
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, max_sites=32):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from bbmap_amd import dist as D
@@ -52,9 +72,12 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ref, reads = _data()
     lo, hi = D.shard_range(PAIRS, rank, world)                       # this rank's pairs
-    out = _map(reads.reshape(-1, 2 * L)[lo:hi].reshape(-1), ref)
+    out = _map(reads.reshape(-1, 2 * L)[lo:hi].reshape(-1), ref, max_sites)
     dist.barrier()
-    q.put((rank, lo, hi, out["nsites"].copy(), out["sites"].copy()))
+    if max_sites == 32:
+        q.put((rank, lo, hi, out["nsites"].copy(), out["sites"].copy()))
+    else:
+        q.put((rank, lo, hi, _lists(out), int(out["stats"]["reads_reprobed"])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,3 +104,30 @@ def test_two_ranks_equal_one_process():
             for r in range(len(nsites)):
                 n = max(0, int(nsites[r]))
                 assert (sites[f][r, :n] == whole["sites"][f][r, :n]).all(), (f, r)
+
+
+def test_two_ranks_equal_one_process_with_the_overflow_tier():
+    """The same with 4 slots per read, so that on every rank some lists outgrow their slots and are mapped by that rank's overflow
+    tier: the lists a host would read (main list, or the tier's through read_ids) are the single process's, whichever rank and
+    whichever tier produced them."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, 4)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda g: g[0])
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref, reads = _data()
+    whole = _map(reads, ref, 4)
+    assert all(g[4] > 0 for g in got) and whole["stats"]["reads_reprobed"] == sum(g[4] for g in got)     # every rank's tier had work
+    lists = got[0][3] + got[1][3]
+    want = _lists(whole)
+    assert len(lists) == len(want) == 2 * PAIRS
+    for r, ((n, s), (wn, ws)) in enumerate(zip(lists, want)):
+        assert n == wn, r
+        for f in s.dtype.names:
+            if f not in ("match_job", "reserved"):
+                assert (s[f] == ws[f]).all(), (f, r)
