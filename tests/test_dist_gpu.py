@@ -57,8 +57,12 @@ def _map(reads, ref, max_sites=32):
     return out
 
 
-def _data():
+def _data(repeats=False):
     from bbmap_amd import workload as W
+    if repeats:        # 60 % of the sequence in 3 repeat families: many reads have more candidate sites than slots
+        ref = W.make_reference(200000, seed=11, pad=2000, repeat_frac=0.6, families=3)
+        reads, _ = W.make_pairs(ref, PAIRS, read_len=L, seed=10, pad=2000, hard_frac=0.05)
+        return ref, reads
     ref = W.make_reference(150000, seed=31, pad=2000, repeat_frac=0.1)
     reads, _ = W.make_pairs(ref, PAIRS, read_len=L, seed=9, pad=2000, hard_frac=0.1)
     return ref, reads
@@ -70,7 +74,7 @@ def _worker(rank, world, port, q, max_sites=32):
     from bbmap_amd import dist as D
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ref, reads = _data()
+    ref, reads = _data(repeats=max_sites != 32)
     lo, hi = D.shard_range(PAIRS, rank, world)                       # this rank's pairs
     out = _map(reads.reshape(-1, 2 * L)[lo:hi].reshape(-1), ref, max_sites)
     dist.barrier()
@@ -120,9 +124,9 @@ def test_two_ranks_equal_one_process_with_the_overflow_tier():
     for p in ps:
         p.join(timeout=120)
         assert p.exitcode == 0
-    ref, reads = _data()
+    ref, reads = _data(repeats=True)
     whole = _map(reads, ref, 4)
-    assert all(g[4] > 0 for g in got) and whole["stats"]["reads_reprobed"] == sum(g[4] for g in got)     # every rank's tier had work
+    assert all(g[4] > 0 for g in got) and whole["stats"]["reads_reprobed"] == sum(g[4] for g in got), ([g[4] for g in got], whole["stats"])     # every rank's tier had work
     lists = got[0][3] + got[1][3]
     want = _lists(whole)
     assert len(lists) == len(want) == 2 * PAIRS
