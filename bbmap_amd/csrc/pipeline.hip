@@ -59,7 +59,7 @@ struct RescueParams {
 constexpr int RESC_WAVES = 4, RESC_MAXLEN = 608;
 
 __global__ __launch_bounds__(64 * RESC_WAVES) void quick_rescue_kernel(const RescueParams P) {
-    __shared__ uint8_t rdbuf[RESC_WAVES][RESC_MAXLEN];
+    __shared__ __attribute__((aligned(16))) uint8_t rdbuf[RESC_WAVES][RESC_MAXLEN];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long long jx = (long long)blockIdx.x * RESC_WAVES + wave;
     if (jx >= P.njobs) return;                                   // whole wave; the kernel has no block-level barrier
@@ -86,7 +86,32 @@ __global__ __launch_bounds__(64 * RESC_WAVES) void quick_rescue_kernel(const Res
         if (!__ballot(valid)) break;
         const int cap = minMM;
         int mm = 0, contig = 0, cur = 0;
-        for (int j = 0; j < len; j++) {
+        // four bases per step: one LDS dword of the read against one (unaligned) dword of the reference; a lane that has passed
+        // its mismatch cap may run up to three bases further than the byte-wise loop would, but its counts are discarded anyway
+        const int len4 = len & ~3;
+        int j = 0;
+        for (; j < len4; j += 4) {
+            const bool on = valid && mm <= cap;
+            if (!__ballot(on)) break;
+            const unsigned c4 = *(const unsigned *)(rd + j);
+            if (on) {
+                unsigned r4;
+                __builtin_memcpy(&r4, ref + start + j, 4);
+                unsigned x = c4 ^ r4;                                                  // a zero byte = equal bases
+                const unsigned isN = c4 ^ 0x4e4e4e4eu;                                   // a zero byte = the read base is 'N'
+                const unsigned nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;            // 0x80 per mismatching byte
+                const unsigned nn = ~((((isN & 0x7f7f7f7fu) + 0x7f7f7f7fu) | isN)) & 0x80808080u;     // 0x80 per 'N' of the read
+                const unsigned bad = nz | nn;
+                if (bad == 0) cur += 4;
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (bad & (0x80u << (8 * q))) { mm++; contig = max(contig, cur); cur = 0; } else cur++;
+                    }
+                }
+            }
+        }
+        for (; j < len; j++) {
             const bool on = valid && mm <= cap;
             if (!__ballot(on)) break;
             const int c = rd[j];
