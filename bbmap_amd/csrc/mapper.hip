@@ -1329,7 +1329,8 @@ static int run_fills(bbmap_ctx *c, hipStream_t stream, const uint8_t *bases, lon
 
 static void add_dp_ms(bbmap_ctx *c, bool plain, bool gapped) {
     float k3[3];
-    if (plain && bbmsa_last_kernel_ms3(c->msa, k3) == BBMAP_OK) { c->stats.ms_dp_narrow += k3[0]; c->stats.ms_dp_wave += k3[1]; c->stats.ms_dp_generic += k3[2]; }
+    if (plain && bbmsa_last_kernel_ms3(c->msa, k3) == BBMAP_OK) { c->stats.ms_dp_narrow += k3[0]; c->stats.ms_dp_wave += k3[1]; c->stats.ms_dp_generic += k3[2];
+                                                                 if (k3[1] > c->stats.ms_dp_wave_max) c->stats.ms_dp_wave_max = k3[1]; }
     if (gapped && bbmsa_last_kernel_ms3(c->msaGapped, k3) == BBMAP_OK) c->stats.ms_dp_gapped += k3[0] + k3[1] + k3[2];
     static const bool show = getenv("BBMAP_DP_COUNTS") != nullptr;      // where the fills of a launch sequence ended up (experiments)
     if (show) {

@@ -39,7 +39,8 @@ class bbmap_stats(C.Structure):
                                          "rescue_scans", "rescue_fills", "rounds", "fills_dropped")] + \
                [(n, C.c_float) for n in ("ms_probe", "ms_begin", "ms_score", "ms_slow", "ms_finish", "ms_rescue", "ms_total",
                                          "ms_dp_narrow", "ms_dp_wave", "ms_dp_generic", "ms_dp_gapped", "ms_quick_rescue")] + \
-               [("probe_stats", C.c_int64 * 5), ("reads_reprobed", C.c_int64), ("ms_overflow", C.c_float), ("log_growths", C.c_float)]
+               [("probe_stats", C.c_int64 * 5), ("reads_reprobed", C.c_int64), ("ms_overflow", C.c_float), ("log_growths", C.c_float),
+                ("ms_dp_wave_max", C.c_float), ("reserved_f", C.c_float)]
 
 
 class bbmap_overflow_output(C.Structure):

@@ -540,6 +540,9 @@ typedef struct bbmap_stats {
     int64_t reads_reprobed;        /* reads the overflow tier mapped (pairs count both mates); fills etc. above include the tier's */
     float ms_overflow;             /* the overflow tier's whole pass (included in ms_total) */
     float log_growths;             /* times a fill log had to grow during the batch (the logs start at jobsPerRead entries per read) */
+    float ms_dp_wave_max;          /* the longest single wavefront-kernel pass of the plain DP context in the batch (round 1's, as a rule);
+                                    * ms_dp_wave is the sum over all rounds and rescue passes */
+    float reserved_f;
 } bbmap_stats;
 
 typedef struct bbmap_ctx bbmap_ctx;
