@@ -521,7 +521,6 @@ def pacbio_main(args):
                        "dp_gcups_visited": (cells / (ms["ms_slow"] * 1e-3) / 1e9) if cells and ms["ms_slow"] > 0 else 0.0,
                        "probe_list_entries_per_step": int(ps[0] + ps[1]), "probe_extend_calls_per_step": int(ps[2]), "probe_stats_raw": [int(x) for x in ps],
                        "stage_ms": {key[3:]: round(v, 3) for key, v in ms.items()}, "index_build_s_gpu": t_ix, "parity": parity},
-            "default_read_set": default_res,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": dom, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(dom_bytes), "kernels": kern,
                          "note": "both kernels are instruction-bound integer work (heap merge of ~1,400 lists; ~180 VALU per DP cell): the HBM "
@@ -790,7 +789,11 @@ def main():
             "default_read_set": default_res,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": dom, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(dom_bytes), "kernels": kern},
+                         "kernel": dom, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(dom_bytes), "kernels": kern,
+                         "note": ("latency-bound gather kernel: 34 % of the VALU issue rate, waves waiting 53 % of their cycles at 5 waves per SIMD "
+                                  "(profiles/r03_hg38_pmc_summary.txt); HBM is not what limits it" if dom == "probe_wave_kernel" else
+                                  "integer DP: VALU-bound (82 % of the VALU issue rate while it runs, profiles/r03_hg38_pmc_summary.txt); its "
+                                  "algorithmic bytes are a few hundred per fill, so an HBM fraction says nothing about it")},
         }
         if cpu is not None:
             out_json["cpu_baseline"] = cpu
