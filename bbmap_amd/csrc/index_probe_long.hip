@@ -84,18 +84,30 @@ typedef int vJM __attribute__((ext_vector_type(32)));   // JM ints in registers;
 static_assert(JM == 32, "vJM holds JM values");
 
 // LDS of one wave (77 KB: two waves per CU)
+// A wave's LDS, laid out at launch for the longest read and the most keys of THE BATCH (Q.maxLen / Q.maxKeys, found by a pre-pass):
+// the block size in LDS decides how many wavefronts a CU holds (one per block), and this kernel is latency-bound -- 6,000-base
+// pieces with 1,400 keys take 48 KB instead of the 77 KB of the largest shape (6,016 / 2,047), three blocks per CU instead of two.
+// The read's bases (both strands) and base scores are NOT mirrored in LDS: they are read from global memory where they lie
+// (plus strand and scores: the caller's buffers; minus strand: the rc output, or the wave's workspace), in coalesced chunks by
+// the few functions that need them (extendScore, setPerfect, the key extraction, calcAffineScore).
 struct Lds {
-    int loc[LMAX];
-    int val[KMAX];           // every list's current value (kept after it ran out): what the scoring functions index by column
-    int nb[NB][KMAX];        // look-ahead entries, already adjusted by the key's offset
-    uint8_t st[KMAX];        // bits 0-1 look-ahead entries consumed, bits 2-3 valid look-ahead entries, bit 7 they reach the list's end
-    short ksc[KMAX];         // the list's key score (<= 100 k) and offset (< 6016)
-    short off[KMAX];
-    uint8_t base[2][LMAX + 8];
-    int8_t bsc[LMAX + 8];
-    int gaps[BBIDX_MAX_GAPS];
-    int ngaps;
+    int *loc;                // [LM] location array
+    int *val;                // [KM] every list's current value (kept after it ran out): what the scoring functions index by column
+    int *nb[NB];             // [KM] look-ahead entries, already adjusted by the key's offset
+    uint8_t *st;             // [KM] bits 0-1 look-ahead entries consumed, bits 2-3 valid look-ahead entries, bit 7 they reach the list's end
+    short *ksc;              // [KM] the list's key score (<= 100 k) and offset (< 6016)
+    short *off;
+    const uint8_t *base[2];  // global memory: the read, plus and minus strand
+    const int8_t *bsc;       // global memory: base scores
+    int *gaps;               // [BBIDX_MAX_GAPS]
+    int *ngapsP;
 };
+__host__ __device__ inline int lds_km(int maxKeys) { int k = (maxKeys + 1 + 63) & ~63; return k > KMAX ? KMAX : k; }
+__host__ __device__ inline int lds_lm(int maxLen) { int l = (maxLen + 15) & ~15; return l > LMAX ? LMAX : l; }
+__host__ __device__ inline int lds_bytes(int maxKeys, int maxLen) {
+    const int KM = lds_km(maxKeys), LM = lds_lm(maxLen);
+    return 4 * LM + 4 * KM * (1 + NB) + 2 * KM * 2 + KM + 4 * (BBIDX_MAX_GAPS + 4);
+}
 
 struct U {
     const DevIndex *ix;
@@ -514,10 +526,10 @@ __device__ __forceinline__ int makeGapArrayL(const U &u, Lds &S, int minLoc, int
                 for (int i = 1, j = 1; i < n; i++) if (locArray[i] - locArray[i - 1] > minGap) { S.gaps[j] = locArray[i - 1]; S.gaps[j + 1] = locArray[i]; j += 2; }
             }
         }
-        S.ngaps = len;
+        *S.ngapsP = len;
     }
     wsync();
-    return __builtin_amdgcn_readfirstlane(S.ngaps);
+    return __builtin_amdgcn_readfirstlane(*S.ngapsP);
 }
 
 // SiteScore.setPerfect (current/stream/SiteScore.java:239-292), order-independent form as in index_probe_wave.hip
@@ -895,7 +907,19 @@ __device__ inline int base_num_fast(int b) { return base_num(b); }
 
 template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(const LongParams Q) {
     extern __shared__ __align__(16) unsigned char ldsRaw[];
-    Lds &S = *reinterpret_cast<Lds *>(ldsRaw);
+    Lds S;
+    {
+        const int KM = lds_km(Q.maxKeys), LM = lds_lm(Q.maxLen);
+        int *w = reinterpret_cast<int *>(ldsRaw);
+        S.loc = w; w += LM;
+        S.val = w; w += KM;
+        for (int j = 0; j < NB; j++) { S.nb[j] = w; w += KM; }
+        S.gaps = w; w += BBIDX_MAX_GAPS;
+        S.ngapsP = w; w += 4;
+        S.ksc = reinterpret_cast<short *>(w); S.off = S.ksc + KM;
+        S.st = reinterpret_cast<uint8_t *>(S.off + KM);
+        S.base[0] = S.base[1] = nullptr; S.bsc = nullptr;
+    }
     const Params &P = Q.P;
     const int lane = threadIdx.x & 63;
     const DevIndex &ix = P.ix;
@@ -938,19 +962,23 @@ template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(cons
             const int8_t *qP = P.baseScores + rr.bases_off;
             const int *koff = P.keyinfo + rr.keys_off, *kscore = koff + n;
             int sumBS = 0; bool undefinedBase = false;
+            // minus strand: into the caller's rc buffer when there is one, else into the wave's workspace (slots 8-9); this wave reads
+            // it back through other lanes, hence the release / acquire pair below
+            uint8_t *rcG = P.rcOut ? P.rcOut + rr.bases_off : reinterpret_cast<uint8_t *>(ws + 8 * KMAX);
+            uint8_t *stage = reinterpret_cast<uint8_t *>(S.loc);     // the plus strand for the key extraction below (loc is not in use yet)
             for (int i = lane; i < blen; i += 64) {
                 const int b = bP[i], q = qP[i];
-                S.base[0][i] = (uint8_t)b; S.base[1][blen - 1 - i] = (uint8_t)complement_extended(b); S.bsc[i] = (int8_t)q;
+                rcG[blen - 1 - i] = (uint8_t)complement_extended(b);
+                stage[i] = (uint8_t)b;
                 sumBS += q;
                 if (base_num(b) < 0 || b >= 128) undefinedBase = true;
             }
             sumBS = wsum(sumBS);
             const bool fullyDefined = __ballot(undefinedBase) == 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             wsync();
-            if (P.rcOut) {
-                uint8_t *rc = P.rcOut + rr.bases_off;
-                for (int i = lane; i < blen; i += 64) rc[i] = S.base[1][i];
-            }
+            S.base[0] = bP; S.base[1] = rcG; S.bsc = qP;
             // KeyRing.makeKeys; COUNTS of every key
             bool badOrder = false;
             for (int j = 0; j * 64 < n; j++) {
@@ -958,7 +986,7 @@ template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(cons
                 if (l < n) {
                     const int off = koff[l];
                     int key = 0;
-                    for (int q = off; q < off + p.k; q++) { const int x = base_num(S.base[0][q]); if (x < 0) { key = -1; break; } key = (key << 2) | x; }
+                    for (int q = off; q < off + p.k; q++) { const int x = base_num(stage[q]); if (x < 0) { key = -1; break; } key = (key << 2) | x; }
                     keyW[l] = key; origW[l] = key; offW[l] = off; kscW[l] = kscore[l];
                     lenW[l] = key >= 0 ? ix.counts[key] : 0;
                     if (l > 0 && off < koff[l - 1]) badOrder = true;
@@ -1133,34 +1161,72 @@ template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(cons
 }  // namespace bbidxl
 
 // Workspace and launch.  `ws` = blocks * WS_ARRAYS * KMAX ints (bbidx_long_workspace_ints per block).
-long long bbidx_long_workspace_ints_per_block() { return (long long)bbidxl::WS_ARRAYS * bbidxl::KMAX; }
-int bbidx_long_lds_bytes() { return (int)sizeof(bbidxl::Lds); }
+namespace bbidxl {
+// the batch's longest read and largest key count, into queue[8..9] (zeroed by the caller with the rest of the queue words)
+__global__ void long_maxima_kernel(const bbidx_read *reads, long long n, unsigned int *out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int len = 0, nk = 0;
+    if (i < n) { len = reads[i].len; nk = reads[i].nkeys; }
+    for (int d = 32; d >= 1; d >>= 1) { len = max(len, __shfl_xor(len, d, 64)); nk = max(nk, __shfl_xor(nk, d, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], (unsigned)max(len, 0)); atomicMax(&out[1], (unsigned)max(nk, 0)); }
+}
+}  // namespace bbidxl
 
+long long bbidx_long_workspace_ints_per_block() { return (long long)bbidxl::WS_ARRAYS * bbidxl::KMAX; }
+int bbidx_long_lds_bytes() { return bbidxl::lds_bytes(bbidxl::KMAX - 1, bbidxl::LMAX); }      // the largest shape
+
+static const void *long_kernel_fn(int profile) {
+    return profile ? (const void *)bbidxl::probe_long_kernel<bbidxl::ProfPacBio> : (const void *)bbidxl::probe_long_kernel<bbidxl::ProfBBMap>;
+}
+static int g_longCUs = 0;
+constexpr int LONG_MAX_BLOCKS_PER_CU = 8;
+
+// blocks the workspace has to be sized for: the most any launch uses
 int bbidx_long_blocks(int profile) {
-    static int cached[2] = {0, 0};
-    if (cached[profile ? 1 : 0]) return cached[profile ? 1 : 0];
-    const void *fn = profile ? (const void *)bbidxl::probe_long_kernel<bbidxl::ProfPacBio> : (const void *)bbidxl::probe_long_kernel<bbidxl::ProfBBMap>;
-    const int lds = bbidx_long_lds_bytes();
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
-    int per = 0, dev = 0, numCUs = 256;
-    hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, 64, (size_t)lds) != hipSuccess || per < 1) per = 1;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) numCUs = prop.multiProcessorCount;
-    cached[profile ? 1 : 0] = numCUs * per;
-    return cached[profile ? 1 : 0];
+    static bool ready[2] = {false, false};
+    if (!ready[profile ? 1 : 0]) {
+        if (hipFuncSetAttribute(long_kernel_fn(profile), hipFuncAttributeMaxDynamicSharedMemorySize, bbidx_long_lds_bytes()) != hipSuccess) return 0;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        g_longCUs = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_longCUs = prop.multiProcessorCount;
+        ready[profile ? 1 : 0] = true;
+    }
+    return g_longCUs * LONG_MAX_BLOCKS_PER_CU;
 }
 
 int bbidx_launch_long(const bbidx::Params &P, hipStream_t stream, int profile, int *ws, int blocks) {
+    static thread_local char msg[256];
+    // the batch's maxima size the LDS layout, and with it the number of resident wavefronts (one host round trip; the kernel runs
+    // for milliseconds per read)
+    unsigned int mx[2] = {0, 0};
+    {
+        const long long n = P.nreads;
+        hipLaunchKernelGGL(bbidxl::long_maxima_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P.reads, n, P.queue + 8);
+        if (hipMemcpyAsync(mx, P.queue + 8, sizeof mx, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+            snprintf(msg, sizeof msg, "probe_long_kernel: reading the batch's maxima failed: %s", hipGetErrorString(hipGetLastError()));
+            bbmap_set_error(msg);
+            return BBMAP_E_HIP;
+        }
+    }
     bbidxl::LongParams Q;
-    Q.P = P; Q.ws = ws; Q.maxKeys = bbidxl::KMAX - 1; Q.maxLen = bbidxl::LMAX;
-    long long nb = P.nreads < blocks ? P.nreads : blocks;
+    Q.P = P; Q.ws = ws;
+    Q.maxKeys = (int)mx[1] < bbidxl::KMAX - 1 ? (int)mx[1] : bbidxl::KMAX - 1;          // reads beyond the largest shape are declined (-2)
+    Q.maxLen = (int)mx[0] < bbidxl::LMAX ? (int)mx[0] : bbidxl::LMAX;
+    if (Q.maxKeys < 1) Q.maxKeys = 1;
+    if (Q.maxLen < 16) Q.maxLen = 16;
+    const int lds = bbidxl::lds_bytes(Q.maxKeys, Q.maxLen);
+    int per = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, long_kernel_fn(profile), 64, (size_t)lds) != hipSuccess || per < 1) per = 1;
+    if (per > LONG_MAX_BLOCKS_PER_CU) per = LONG_MAX_BLOCKS_PER_CU;
+    long long nb = (long long)(g_longCUs > 0 ? g_longCUs : 256) * per;
+    if (nb > blocks) nb = blocks;
+    if (nb > P.nreads) nb = P.nreads;
     if (nb < 1) nb = 1;
-    const int lds = bbidx_long_lds_bytes();
     if (profile) hipLaunchKernelGGL(bbidxl::probe_long_kernel<bbidxl::ProfPacBio>, dim3((unsigned)nb), dim3(64), lds, stream, Q);
     else hipLaunchKernelGGL(bbidxl::probe_long_kernel<bbidxl::ProfBBMap>, dim3((unsigned)nb), dim3(64), lds, stream, Q);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        static thread_local char msg[256];
         snprintf(msg, sizeof msg, "probe_long_kernel launch failed: %s", hipGetErrorString(e));
         bbmap_set_error(msg);
         return BBMAP_E_HIP;

@@ -13,8 +13,8 @@
 // in HBM, and the walk reads it back cooperatively, 64 diagonal cells per step, across strip borders.
 // The score-pruned window of fillLimitedX is reproduced exactly as in msa_fill_fast.hip: cells outside
 // a row's window read as `subfloor`, over-computing provably-pruned cells changes nothing, and the visited-cell count is
-// recovered from the rows' first / last good columns.  Banded fills and windows more than two columns narrower than the read
-// are handed to the one-job-per-thread kernel (msa_fill_generic.hip), as the wavefront kernel does.
+// recovered from the rows' first / last good columns.  Banded fills are handed to the one-job-per-thread kernel
+// (msa_fill_generic.hip); windows narrower than the read are taken here.
 #include "msa_common.h"
 
 namespace bbmsa {
@@ -128,7 +128,11 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
             }
             continue;
         }
-        if (banded || columns < rows - 2) {                         // the generic kernel takes these
+        // (Windows narrower than the read need no special case here: the per-plane priority of the "still needed" penalties --
+        // deletions first in the match and insertion planes, insertions first in the deletion plane -- is spelled out per cell below.
+        // Round 2 handed them to the one-thread kernel as the 11ts wavefront kernel does, whose single penalty table cannot hold
+        // both: a 6,000-base piece with a few more inserted than deleted bases then cost 12 s on one thread.)
+        if (banded) {                                               // the generic kernel takes these
             if (lane == 0) { const unsigned k = atomicAdd(p.slow_count, 1u); p.slow_list[k] = (int)j; }
             continue;
         }
@@ -541,8 +545,12 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
 
 constexpr int kStripR = 8;           // rows per lane: strips of 512 rows
 template __global__ void msa_fill_strip_kernel<Scheme9PacBio, kStripR>(const StripParams);
-
+// (Round 3: a 2-rows-per-lane instantiation for launches with few jobs was measured and dropped: a lone 6,000 x 6,100 fill takes
+// 370 ms at R = 8 and 411 ms at R = 2 -- per step about 1 us of fixed cost plus 0.5 us per row of the lane's serial chain, so fewer
+// rows per lane only multiply the steps.  A lone fill is bound by its dependent instruction chain (one wavefront issues an
+// instruction every ~8 cycles); only spreading the strips of one job over several wavefronts would shorten it.)
 int strip_rows_per_lane() { return kStripR; }
 const void *strip_kernel_pacbio() { return (const void *)msa_fill_strip_kernel<Scheme9PacBio, kStripR>; }
+
 
 }  // namespace bbmsa

@@ -397,7 +397,8 @@ def pacbio_main(args):
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     genome = args.pacbio_genome
     lens = WORKLOADS[genome][0]
-    n = args.reads if args.reads != 2000000 else 2048                  # pieces per GPU and step
+    n = args.reads if args.reads != 2000000 else 8192                  # pieces per GPU and step (4,096 reads of 10 kb: large enough that the
+                                                                       # late scoreSlow rounds, a lone fill's latency each, stay a small share)
     n -= n % 2
     world_local = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     chroms, shm_path = shared_reference(genome, lens, 0.0 if genome == "ecoli" else 0.1, local_rank, world_local)

@@ -105,7 +105,7 @@ typedef struct bbmsa_config {
 /* Scoring schemes.  11ts: align2.MultiStateAligner11ts[JNI] (jni/MultiStateAligner11tsJNI.c:18-98), maxRows <= 640,
  * maxColumns <= 4096.  9PacBio: align2.MultiStateAligner9PacBio (current/align2/MultiStateAligner9PacBio.java:2359-2439:
  * 9 time bits, its own point values and barriers, column 0 as its constructor fills it), maxRows <= 6100,
- * maxColumns <= 8192; this round every 9PacBio job runs in the one-job-per-thread kernel. */
+ * maxColumns <= 8192: the strip-tiled wavefront kernel (banded fills: the one-job-per-thread kernel). */
 #define BBMSA_SCHEME_11TS 0
 #define BBMSA_SCHEME_9PACBIO 1
 /* OR-ed into reserved[2]: a context for bbmsa_fill_submit / _collect / _packed only (what the per-call JNI symbols use, ONE per

@@ -176,7 +176,25 @@ def test_pacbio_full_size_reads_cross_many_strips():
     check(probs[2:4], M.FILL_UNLIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK, maxRows=6019, maxColumns=7600)
 
 
-def test_pacbio_fill_dies_inside_a_strip_and_narrow_windows_go_to_the_generic_kernel():
+def test_pacbio_windows_narrower_than_the_read():
+    """A read with more inserted than deleted bases spans fewer reference bases than it has rows: cells then need deletions AND
+    insertions to finish, and each plane applies its own priority (jni-less class: MultiStateAligner9PacBio.fillLimited).  The strip
+    kernel takes these windows itself (the one-thread kernel needs seconds for a 6,000-base piece)."""
+    rng = random.Random(29)
+    genome = rand_seq(rng, 9000)
+    probs = []
+    for i, (L, short) in enumerate([(1400, 3), (1400, 40), (1400, 300), (900, 12), (2600, 90), (700, 699 - 60)]):
+        rd = _pacbio_read(rng, genome, 1000, L, 0.12)
+        a = 1000 - 8
+        b = a + len(rd) - 1 - short                                    # columns = rows - short
+        maxq = 90 + 100 * (len(rd) - 1)
+        probs.append((rd, genome, a, b, int(maxq * (0.15 if i % 2 else 0.3))))
+    check(probs, M.FILL_AND_SCORE_LIMITED | M.DO_TRACEBACK, maxRows=2700, maxColumns=3000)
+    check(probs, M.FILL_LIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK, maxRows=2700, maxColumns=3000)
+    check(probs[:4], M.FILL_UNLIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK, maxRows=2700, maxColumns=3000)
+
+
+def test_pacbio_fill_dies_inside_a_strip_and_a_narrow_window():
     rng = random.Random(23)
     genome = rand_seq(rng, 6000)
     junk = rand_seq(rng, 1500)                       # unrelated read: the limited fill runs out of good cells early
