@@ -201,3 +201,12 @@ def test_mock_jnienv_32_mapping_threads_share_launches(shim):
     out = subprocess.run([os.path.join(PKG, "mock_jni_test"), "threads", "32"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr + out.stdout
     print(out.stdout)
+
+
+@pytest.mark.gpu
+def test_mock_jnienv_threads_with_a_tiny_batch_capacity(shim):
+    """The same with room for only 3 calls per device batch (BBMSA_LEGACY_BATCH): callers that find the open batch full wait for the
+    next one, or take the full one to the device themselves -- every call still gets its own result."""
+    env = dict(os.environ, BBMSA_LEGACY_BATCH="3")
+    out = subprocess.run([os.path.join(PKG, "mock_jni_test"), "threads", "12"], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr + out.stdout
