@@ -46,6 +46,9 @@ struct bbmsa_ctx {
     long long stripDwords, stripSlotDwords;
     int *d_stripBoundary;
     uint8_t *d_stripTmp;
+    // pipelined form of the strip kernel for launches with few jobs: pipeK wavefronts per job, pipeSlots jobs at a time
+    int pipeK, pipeSlots, pipeJobsMax;
+    int *d_pipeBoundary, *d_pipeSync;
 };
 
 

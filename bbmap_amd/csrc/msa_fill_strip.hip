@@ -38,6 +38,11 @@ struct StripParams {
     int maxRows, maxColumns;
     int bandwidth;
     float bandwidthRatio;
+    // pipelined form (PIPE): the strips of ONE job run in pipeK wavefronts (blocks slot * pipeK + w), strip w a few dozen columns
+    // behind strip w - 1; boundary rows per strip and the hand-shake words live in these two buffers
+    int pipeK, pipeSlots;
+    int *pipeBoundary;            // per slot: pipeK x 3 x (maxColumns + 2) ints
+    int *pipeSync;                // per slot: PIPE_SYNC_INTS(pipeK) ints, zeroed before the launch
 };
 
 namespace {
@@ -68,7 +73,13 @@ __device__ __forceinline__ uint8_t ld_agent_u8(const uint8_t *p) { return __hip_
 
 }  // namespace
 
-template <class S, int R>
+// hand-shake words of a slot: [0] jobs finished; then per strip: columns of its last row published, first good column of that row so
+// far (-1: none), last good column (final), state (0 running, 1 done, 2 done and dead: the row has no good cell, 3 failed), first row
+// not entered, visited cells (2 ints)
+__host__ __device__ constexpr int pipe_sync_ints(int K) { return 8 + 8 * K; }
+constexpr int PIPE_SPIN_LIMIT = 1 << 21;      // ~3 s of polling: a wave that waits longer gives the job to the one-thread kernel
+
+template <class S, int R, bool PIPE>
 __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p) {
     extern __shared__ int lds[];
     int *colHl = lds;                                                // [c] = horizLimit[c] + ONE
@@ -77,17 +88,47 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
                                                                      // score <= L  <=>  p < L + ONE for bounds that are multiples of ONE
     constexpr int STRIP = 64 * R;
     const int lane = threadIdx.x;
-    const long long slot = blockIdx.x;
+    const int K = PIPE ? p.pipeK : 1;
+    const long long slot = PIPE ? blockIdx.x / K : blockIdx.x;
+    const int w = PIPE ? (int)(blockIdx.x % K) : 0;                  // this wave's strip
     unsigned *dirSlot = p.dirbuf + slot * p.dir_slot_dwords;
-    int *bnd = p.boundary + slot * 6LL * (p.maxColumns + 2);
+    int *bnd = PIPE ? p.pipeBoundary + slot * (long long)K * 3 * (p.maxColumns + 2) : p.boundary + slot * 6LL * (p.maxColumns + 2);
     uint8_t *tmp = p.tmpbuf + slot * (long long)(p.maxRows + p.maxColumns + 8);
     const long long total = job_count(p.njobs, p.njobs_dev);
+    int *sync = PIPE ? p.pipeSync + slot * (long long)pipe_sync_ints(K) : nullptr;
+    int *syProg = nullptr, *syFirst = nullptr, *syLast = nullptr, *syState = nullptr, *syNoEnter = nullptr, *syIters = nullptr;
+    if (PIPE) {
+        syProg = sync + 8; syFirst = sync + 8 + K; syLast = sync + 8 + 2 * K; syState = sync + 8 + 3 * K; syNoEnter = sync + 8 + 4 * K;
+        syIters = sync + 8 + 5 * K;                                  // (two ints per strip)
+    }
+    // polls a hand-shake word until pred(value); false after PIPE_SPIN_LIMIT polls
+    auto wait_ge = [&](const int *word, int need) -> bool {
+        for (int spin = 0; spin < PIPE_SPIN_LIMIT; spin++) {
+            if (ld_agent(word) >= need) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); return true; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        return false;
+    };
 
-    for (;;) {
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(p.queue, 1u);
-        const long long j = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        if (j >= total) break;
+    for (long long kjob = 0;; kjob++) {
+        long long j;
+        if (PIPE) {
+            j = slot + kjob * p.pipeSlots;
+            if (j >= total) break;
+            if (!wait_ge(sync, (int)kjob)) break;                    // the slot's previous job is finished by all its waves
+        } else {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(p.queue, 1u);
+            j = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (j >= total) break;
+        }
+        auto job_finished = [&]() {                                   // PIPE: lets the slot's waves go on to its next job
+            if (PIPE) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_store(sync, (int)kjob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
 
         // ------------------------------------------------------------------ job setup (as msa_fill_fast.hip)
         const bbmsa_job jb = p.jobs[j];
@@ -118,7 +159,7 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
         }
         const bool banded = limited && halfband > 0;
         if (!shapeOK) {
-            if (lane == 0) {
+            if (lane == 0 && w == 0) {
                 bbmsa_result r;
                 for (int i = 0; i < 5; i++) r.result[i] = 0;
                 r.status = BBMSA_ST_BAD_SHAPE; r.iterations = 0;
@@ -126,6 +167,7 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
                 r.score_len = 0; r.match_len = 0; r.fill_kind = 0; r.columns = columns;
                 p.results[j] = r;
             }
+            if (w == 0) job_finished();
             continue;
         }
         // (Windows narrower than the read need no special case here: the per-plane priority of the "still needed" penalties --
@@ -133,7 +175,8 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
         // Round 2 handed them to the one-thread kernel as the 11ts wavefront kernel does, whose single penalty table cannot hold
         // both: a 6,000-base piece with a few more inserted than deleted bases then cost 12 s on one thread.)
         if (banded) {                                               // the generic kernel takes these
-            if (lane == 0) { const unsigned k = atomicAdd(p.slow_count, 1u); p.slow_list[k] = (int)j; }
+            if (lane == 0 && w == 0) { const unsigned k = atomicAdd(p.slow_count, 1u); p.slow_list[k] = (int)j; }
+            if (w == 0) job_finished();
             continue;
         }
 
@@ -179,13 +222,23 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
         int lastColStart = 1, lastHasGood = 0;
         int bestM = 0, bestD = 0, bestI = 0, bestMc = -1, bestDc = -1, bestIc = -1;
 
-        for (int s = 0; s < nstrips; s++) {
+        bool failed = false;                                          // PIPE: a hand-shake timed out
+        bool deadAbove = false;                                       // PIPE: the strip above ended without a good cell in its last row
+        if (PIPE && w >= nstrips) continue;                           // fewer strips than waves: nothing to do for this job
+        for (int s = PIPE ? w : 0; s < (PIPE ? w + 1 : nstrips); s++) {
             const int rowBase = s * STRIP;                            // rows rowBase+1 .. rowBase+STRIP
             const int r0 = rowBase + lane * R + 1;
             unsigned *dir = dirSlot + (long long)s * p.dir_strip_dwords;
-            const int *bIn = bnd + (s & 1) * 3 * (p.maxColumns + 2);          // boundary row written by strip s-1
-            int *bOut = bnd + ((s + 1) & 1) * 3 * (p.maxColumns + 2);
             const int W = p.maxColumns + 2;
+            // boundary row written by strip s-1 / for strip s+1: ping-pong in the sequential form, one row set per strip when pipelined
+            const int *bIn = PIPE ? bnd + (long long)(s > 0 ? s - 1 : 0) * 3 * W : bnd + (s & 1) * 3 * W;
+            int *bOut = PIPE ? bnd + (long long)s * 3 * W : bnd + ((s + 1) & 1) * 3 * W;
+            int fgPrev = -1;                                          // PIPE: first good column of the row above, as far as it is published
+            if (PIPE) {
+                if (lane == 63) { const int v = S::col0(min(rowBase + STRIP, rows)); bOut[0] = v; bOut[W] = v; bOut[2 * W] = v; }
+                if (lane == 0) __hip_atomic_store(syFirst + s, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (s > 0 && !wait_ge(syProg + s - 1, min(64, columns))) { failed = true; break; }
+            }
 
             int call1[R], vlimP[R], delForce[R], insHiForce[R], mPrev[R];
             bool rowValid[R];
@@ -242,6 +295,13 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
 
             for (int t = 1; t <= steps; t++) {
                 if (s > 0 && ((t - 1) & 63) == 0) {                   // columns t .. t+63 of the previous strip's last row
+                    if (PIPE) {
+                        if (t <= columns && !wait_ge(syProg + s - 1, min(t + 63, columns))) { failed = true; break; }
+                        fgPrev = ld_agent(syFirst + s - 1);
+                        const int stAbove = ld_agent(syState + s - 1);
+                        if (stAbove == 3) { failed = true; break; }
+                        if (stAbove == 2 && limited) { deadAbove = true; break; }      // nothing below that row is ever entered
+                    }
                     const int cc = min(t + lane, columns);
                     bufM = ld_agent(bIn + cc); bufD = ld_agent(bIn + W + cc); bufI = ld_agent(bIn + 2 * W + cc);
                 }
@@ -266,7 +326,8 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
                             // lane 0 is at column t: entry (t - 1) & 63 of the buffered boundary columns
                             const int src = (t - 1) & 63;
                             upM = __builtin_amdgcn_readlane(bufM, src); upD = __builtin_amdgcn_readlane(bufD, src); upI = __builtin_amdgcn_readlane(bufI, src);
-                            upMin = (bMin >= 0 && c >= bMin) ? bMin : -1;
+                            if (PIPE) upMin = (fgPrev >= 0 && c >= fgPrev) ? fgPrev : -1;
+                            else upMin = (bMin >= 0 && c >= bMin) ? bMin : -1;
                         }
                     }
                     int dgM = svM, dgD = svD, dgI = svI;
@@ -352,6 +413,16 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
                     if (lastLane && inRange) {                        // the strip's last row: next strip's boundary
                         bOut[c] = pM[R - 1]; bOut[W + c] = pD[R - 1]; bOut[2 * W + c] = pI[R - 1];
                     }
+                    if (PIPE && s + 1 < nstrips) {                    // publish the row 64 columns at a time (and its end)
+                        const int c63 = t - 63;
+                        if (c63 >= 1 && c63 <= columns && ((c63 & 63) == 0 || c63 == columns)) {
+                            const int fg = __builtin_amdgcn_readlane(minGood[R - 1], 63);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if (lane == 0) __hip_atomic_store(syFirst + s, fg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                            if (lane == 0) __hip_atomic_store(syProg + s, c63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
                     {   // last row of the read: first strict maximum per plane, ascending column
                         int lm = pM[0], ld = pD[0], li = pI[0];
 #pragma unroll
@@ -376,7 +447,19 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
 #pragma unroll
                 for (int k = 0; k < R; k++) dir[o + (long long)k * 64] = dacc[k];
             }
-            if (lastLane) { const int v = S::col0(min(rowBase + STRIP, rows)); bOut[0] = v; bOut[W] = v; bOut[2 * W] = v; }
+            if (!PIPE && lastLane) { const int v = S::col0(min(rowBase + STRIP, rows)); bOut[0] = v; bOut[W] = v; bOut[2 * W] = v; }
+            if (PIPE && failed) break;
+            if (PIPE && deadAbove) {                                  // not one row of this strip is entered
+#pragma unroll
+                for (int k = 0; k < R; k++) { minGood[k] = -1; maxGood[k] = -2; }
+            }
+            if (PIPE) {                                               // the row above, final: first / last good column
+                if (s > 0) {
+                    if (!wait_ge(syState + s - 1, 1)) { failed = true; break; }
+                    if (ld_agent(syState + s - 1) == 3) { failed = true; break; }
+                    bMin = ld_agent(syFirst + s - 1); bMax = ld_agent(syLast + s - 1);
+                } else { bMin = 1; bMax = columns; }
+            }
 
             // ---- row extents of this strip -> iterations, first row not entered (jni/...c:441-449, :660-661)
             {
@@ -414,7 +497,47 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the boundary row is in L2 before the next strip reads it
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
             __builtin_amdgcn_wave_barrier();
-            if (limited && noEnterRow <= rows) break;                // the fill died inside this strip: no row below is entered
+            if (PIPE) {                                               // this strip's share of the bookkeeping, then "done"
+                if (lane == 0) {
+                    __hip_atomic_store(syFirst + s, bMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(syLast + s, bMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(syNoEnter + s, noEnterRow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(syIters + 2 * s, (int)(iters & 0xffffffffLL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(syIters + 2 * s + 1, (int)(iters >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) {
+                    __hip_atomic_store(syProg + s, columns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(syState + s, (limited && bMin < 0) ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (!PIPE && limited && noEnterRow <= rows) break;       // the fill died inside this strip: no row below is entered
+        }
+        if (PIPE) {
+            if (failed) {                                             // tell the waves below, and let the last one hand the job on
+                if (lane == 0) __hip_atomic_store(syState + w, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (w != nstrips - 1) continue;                           // only the wave of the last strip goes on to the result
+            if (!failed) {
+                // every strip is done (a strip finishes only after the one above it): first row not entered, visited cells
+                int g = INT_MAX; long long its = 0;
+                if (lane < nstrips) {
+                    g = ld_agent(syNoEnter + lane);
+                    its = (long long)(unsigned)ld_agent(syIters + 2 * lane) | ((long long)ld_agent(syIters + 2 * lane + 1) << 32);
+                }
+                const unsigned long long finite = __ballot(g != INT_MAX);
+                const int sstar = finite ? __builtin_ctzll(finite) : 64;     // strips below the first one with an unentered row add nothing
+                if (lane > sstar) its = 0;
+                for (int d = 32; d >= 1; d >>= 1) { g = min(g, __shfl_xor(g, d, 64)); its += __shfl_xor(its, d, 64); }
+                noEnterRow = g; iters = its;
+            }
+            // the hand-shake words go back to zero for the slot's next job (its other waves are waiting for job_finished)
+            for (int i = lane; i < 8 * K; i += 64) __hip_atomic_store(sync + 8 + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (failed) {
+                if (lane == 0) { const unsigned k = atomicAdd(p.slow_count, 1u); p.slow_list[k] = (int)j; }
+                job_finished();
+                continue;
+            }
         }
         if (!limited) iters = (long long)rows * columns;
 
@@ -540,17 +663,21 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
             p.results[j] = r;
         }
         __builtin_amdgcn_wave_barrier();
+        job_finished();
     }
 }
 
 constexpr int kStripR = 8;           // rows per lane: strips of 512 rows
-template __global__ void msa_fill_strip_kernel<Scheme9PacBio, kStripR>(const StripParams);
+template __global__ void msa_fill_strip_kernel<Scheme9PacBio, kStripR, false>(const StripParams);
+template __global__ void msa_fill_strip_kernel<Scheme9PacBio, kStripR, true>(const StripParams);
 // (Round 3: a 2-rows-per-lane instantiation for launches with few jobs was measured and dropped: a lone 6,000 x 6,100 fill takes
 // 370 ms at R = 8 and 411 ms at R = 2 -- per step about 1 us of fixed cost plus 0.5 us per row of the lane's serial chain, so fewer
 // rows per lane only multiply the steps.  A lone fill is bound by its dependent instruction chain (one wavefront issues an
 // instruction every ~8 cycles); only spreading the strips of one job over several wavefronts would shorten it.)
 int strip_rows_per_lane() { return kStripR; }
-const void *strip_kernel_pacbio() { return (const void *)msa_fill_strip_kernel<Scheme9PacBio, kStripR>; }
+const void *strip_kernel_pacbio() { return (const void *)msa_fill_strip_kernel<Scheme9PacBio, kStripR, false>; }
+const void *strip_kernel_pacbio_pipelined() { return (const void *)msa_fill_strip_kernel<Scheme9PacBio, kStripR, true>; }
+int strip_pipe_sync_ints(int K) { return pipe_sync_ints(K); }
 
 
 }  // namespace bbmsa

@@ -19,9 +19,12 @@ struct StripParams {            // msa_fill_strip.hip
     long long njobs; const unsigned int *njobs_dev; unsigned int *queue; unsigned int *dirbuf;
     long long dir_slot_dwords, dir_strip_dwords; int *boundary; uint8_t *tmpbuf; int *slow_list; unsigned int *slow_count;
     int match_stride; int maxRows, maxColumns; int bandwidth; float bandwidthRatio;
+    int pipeK, pipeSlots; int *pipeBoundary; int *pipeSync;
 };
 int strip_rows_per_lane();
 const void *strip_kernel_pacbio();
+const void *strip_kernel_pacbio_pipelined();
+int strip_pipe_sync_ints(int K);
 const void *fast_kernel_for(int R, bool banded);
 template <class S> __global__ void msa_fill_generic_kernel(const GenericParams p);
 __global__ void msa_fill_narrow_kernel(const NarrowParams p);
@@ -130,6 +133,24 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
             long long dirBudget = (long long)env_int("BBMSA_STRIP_DIR_MB", 32768) << 20;
             while (c->stripBlocks > c->numCUs && (long long)c->stripBlocks * c->stripSlotDwords * 4 > dirBudget) c->stripBlocks -= c->numCUs;
             while (c->stripBlocks > 1 && (long long)c->stripBlocks * c->stripSlotDwords * 4 > dirBudget) c->stripBlocks /= 2;
+            {   // the pipelined form for launches with few jobs: the strips of one job in `strips` wavefronts
+                const void *kp = bbmsa::strip_kernel_pacbio_pipelined();
+                if (c->stripLds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, c->stripLds));
+                int perP = 0;
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perP, kp, 64, c->stripLds));
+                if (perP < 1) perP = 1;
+                if (perP > 8) perP = 8;
+                c->pipeK = strips;
+                c->pipeSlots = (c->numCUs * perP) / strips;                  // every wavefront of every slot is resident: the hand-shakes need it
+                if (c->pipeSlots > c->stripBlocks) c->pipeSlots = c->stripBlocks;
+                if (c->pipeSlots > 256) c->pipeSlots = 256;
+                c->pipeJobsMax = env_int("BBMSA_STRIP_PIPE_JOBS", 512);      // launches with at most this many jobs take the pipelined form
+                if (strips < 2 || c->pipeSlots < 1) c->pipeJobsMax = 0;
+                if (c->pipeJobsMax > 0) {
+                    HIP_TRY(hipMalloc(&c->d_pipeBoundary, (size_t)((long long)c->pipeSlots * strips * 3 * (cfg->maxColumns + 2) * 4)));
+                    HIP_TRY(hipMalloc(&c->d_pipeSync, (size_t)((long long)c->pipeSlots * bbmsa::strip_pipe_sync_ints(strips) * 4)));
+                }
+            }
             HIP_TRY(hipMalloc(&c->d_dir, (size_t)((long long)c->stripBlocks * c->stripSlotDwords * 4)));
             HIP_TRY(hipMalloc(&c->d_stripBoundary, (size_t)((long long)c->stripBlocks * 6 * (cfg->maxColumns + 2) * 4)));
             HIP_TRY(hipMalloc(&c->d_stripTmp, (size_t)((long long)c->stripBlocks * (cfg->maxRows + cfg->maxColumns + 8))));
@@ -254,6 +275,8 @@ extern "C" void bbmsa_destroy(bbmsa_ctx *c) {
     if (c->d_gjobs) (void)hipFree(c->d_gjobs);
     if (c->d_stripBoundary) (void)hipFree(c->d_stripBoundary);
     if (c->d_stripTmp) (void)hipFree(c->d_stripTmp);
+    if (c->d_pipeBoundary) (void)hipFree(c->d_pipeBoundary);
+    if (c->d_pipeSync) (void)hipFree(c->d_pipeSync);
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
@@ -300,7 +323,16 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
         sp.match_stride = match_stride; sp.maxRows = c->cfg.maxRows; sp.maxColumns = c->cfg.maxColumns;
         sp.bandwidth = c->cfg.bandwidth; sp.bandwidthRatio = c->cfg.bandwidthRatio;
         long long sblocks = n_jobs < c->stripBlocks ? n_jobs : c->stripBlocks;
+        sp.pipeK = 0; sp.pipeSlots = 0; sp.pipeBoundary = nullptr; sp.pipeSync = nullptr;
         void *sargs[] = {&sp};
+        if (!n_jobs_dev && c->pipeJobsMax > 0 && n_jobs <= c->pipeJobsMax) {
+            // few jobs (the late scoreSlow rounds of mapPacBio): a lone 6,000 x 6,100 fill is one wavefront's dependent chain, 370 ms;
+            // with its strips pipelined over `pipeK` wavefronts it is ~50
+            const long long slots = n_jobs < c->pipeSlots ? n_jobs : c->pipeSlots;
+            sp.pipeK = c->pipeK; sp.pipeSlots = (int)slots; sp.pipeBoundary = c->d_pipeBoundary; sp.pipeSync = c->d_pipeSync;
+            HIP_TRY(hipMemsetAsync(c->d_pipeSync, 0, (size_t)(slots * bbmsa::strip_pipe_sync_ints(c->pipeK) * 4), stream));
+            HIP_TRY(hipLaunchKernel(bbmsa::strip_kernel_pacbio_pipelined(), dim3((unsigned)(slots * c->pipeK)), dim3(64), sargs, (size_t)c->stripLds, stream));
+        } else
         HIP_TRY(hipLaunchKernel(bbmsa::strip_kernel_pacbio(), dim3((unsigned)sblocks), dim3(64), sargs, (size_t)c->stripLds, stream));
         HIP_TRY(hipEventRecord(c->ev[1], stream));
         bbmsa::GenericParams gp;

@@ -45,6 +45,15 @@ def pacbio_problems(seed, n, lo=60, hi=700):
     return out
 
 
+@pytest.fixture(autouse=True, params=["sequential", "pipelined"])
+def strip_form(request, monkeypatch):
+    """Every test runs under both forms of the strip kernel: one wavefront per job (what a full batch gets) and the strips of a job
+    pipelined over several wavefronts (what a launch with few jobs gets; BBMSA_STRIP_PIPE_JOBS is the job-count threshold, read when
+    the context is created)."""
+    monkeypatch.setenv("BBMSA_STRIP_PIPE_JOBS", "0" if request.param == "sequential" else "512")
+    return request.param
+
+
 def check(problems, flags, maxRows=800, maxColumns=1100):
     al = M.MultiStateAligner9PacBio(maxRows, maxColumns)
     got = al.align(problems, flags)
