@@ -37,7 +37,7 @@ namespace bbidxl {
 using namespace bbidx;
 using namespace wavep;
 
-constexpr int NB = 2;                       // look-ahead entries per list
+constexpr int NB = 2;                       // look-ahead entries per list (1 would make room for a fifth wavefront per CU: measured, 5.5 -> 7.1 s per 8,192 pieces)
 constexpr int KMAX = 2048;                  // lists per read the LDS arrays are sized for (BBIDX_PACBIO_MAX_KEYS + 1)
 constexpr int LMAX = BBIDX_PACBIO_MAX_READ_LEN;
 constexpr int WS_ARRAYS = 12;               // per-wave workspace: WS_ARRAYS x KMAX ints
@@ -91,7 +91,7 @@ static_assert(JM == 32, "vJM holds JM values");
 // (plus strand and scores: the caller's buffers; minus strand: the rc output, or the wave's workspace), in coalesced chunks by
 // the few functions that need them (extendScore, setPerfect, the key extraction, calcAffineScore).
 struct Lds {
-    int *loc;                // [LM] location array
+    unsigned short *loc;     // [LM] location array, as 16-bit offsets from U::locBase (ld_loc / st_loc); 0xFFFF = -1, 0xFFFE = -2
     int *val;                // [KM] every list's current value (kept after it ran out): what the scoring functions index by column
     int *nb[NB];             // [KM] look-ahead entries, already adjusted by the key's offset
     uint8_t *st;             // [KM] bits 0-1 look-ahead entries consumed, bits 2-3 valid look-ahead entries, bit 7 they reach the list's end
@@ -106,7 +106,7 @@ __host__ __device__ inline int lds_km(int maxKeys) { int k = (maxKeys + 1 + 63) 
 __host__ __device__ inline int lds_lm(int maxLen) { int l = (maxLen + 15) & ~15; return l > LMAX ? LMAX : l; }
 __host__ __device__ inline int lds_bytes(int maxKeys, int maxLen) {
     const int KM = lds_km(maxKeys), LM = lds_lm(maxLen);
-    return 4 * LM + 4 * KM * (1 + NB) + 2 * KM * 2 + KM + 4 * (BBIDX_MAX_GAPS + 4);
+    return 2 * LM + 4 * KM * (1 + NB) + 2 * KM * 2 + KM + 4 * (BBIDX_MAX_GAPS + 4);
 }
 
 struct U {
@@ -114,11 +114,18 @@ struct U {
     Codec c;
     int k, baseKeyHitScore, indelPenalty, maxPenalty, scoreZ1Key;
     int lane, blen;
+    int locBase;             // what the 16-bit entries of the location array are offsets from (set by extendScoreL per site)
     unsigned cPrescan, cWalk, cExtend, cRefBytes;
 #ifdef BBIDXL_TIMERS
     mutable unsigned long long tm[5];
 #endif
 };
+
+// The location array holds reference positions of key diagonals, all within [center - MAX_INDEL, center + MAX_INDEL2] of the site being
+// extended (and, in makeGapArray, those plus a base index): 16 bits as offsets from that lower bound halve its LDS, which decides how
+// many wavefronts a CU holds.
+__device__ __forceinline__ int ld_loc(const Lds &S, const U &u, int i) { const int r = S.loc[i]; return r >= 0xFFFE ? r - 0x10000 : r + u.locBase; }
+__device__ __forceinline__ void st_loc(const Lds &S, const U &u, int i, int v) { S.loc[i] = (unsigned short)(v < 0 ? v + 0x10000 : v - u.locBase); }
 
 // The lists of one (block, strand) cycle.  The heap stand-in works on registers: lane `lane` keeps the value, cursor and end of its
 // lists 64 j + lane in v[j] (every loop over j is fully unrolled, so the array never leaves the register file).
@@ -366,13 +373,13 @@ template <class PF> __device__ __forceinline__ int calcAffineScoreL(const U &u, 
     for (int base = 0; base < blen; base += 64) {
         const int p = base + lane;
         const bool valid = p < blen;
-        const int loc = valid ? S.loc[p] : 0;
-        const int prev = (valid && p > 0) ? S.loc[p - 1] : -1;
+        const int loc = valid ? ld_loc(S, u, p) : 0;
+        const int prev = (valid && p > 0) ? ld_loc(S, u, p - 1) : -1;
         const bool pos = valid && loc > 0, neg1 = valid && loc == -1;
         const u64 posM = __ballot(pos), n1M = __ballot(neg1);
         const u64 lt = lt_mask(lane);
         const u64 mlo = posM & lt;
-        const int lastLoc = mlo ? S.loc[base + hibit(mlo)] : carryLastLoc;
+        const int lastLoc = mlo ? ld_loc(S, u, base + hibit(mlo)) : carryLastLoc;
         int c = 0, ev = 0;                                   // ev: 1 equal, 2 restart, 3 indel
         if (pos) {
             const int bs = S.bsc[strand ? blen - 1 - p : p];
@@ -419,7 +426,8 @@ template <class PF> __device__ __forceinline__ int extendScoreL(U &u, Lds &S, co
     const int reflen = u.ix->chromArrLen[chrom];
     const uint8_t *rb = S.base[strand];
     u.cExtend += 1u;
-    for (int i = lane; i < blen; i += 64) S.loc[i] = -1;
+    u.locBase = centerLoc - p.maxIndel;                          // every diagonal in range lies at or above it
+    for (int i = lane; i < blen; i += 64) st_loc(S, u, i, -1);
     wsync();
     // backward from each key's last base; the first key in range runs through mismatches, the others stop at the first
     int keynum = 0;
@@ -437,20 +445,20 @@ template <class PF> __device__ __forceinline__ int extendScoreL(U &u, Lds &S, co
             if (keynum == 1) {
                 for (int base = 0; base <= c0; base += 64) {
                     const int q = base + lane;
-                    if (q <= c0 && rb[q] == ref[refbase + q]) S.loc[q] = refbase;
+                    if (q <= c0 && rb[q] == ref[refbase + q]) st_loc(S, u, q, refbase);
                 }
                 u.cRefBytes += (unsigned)(c0 + 1);
             } else {
                 for (int top = c0; top >= 0; top -= 64) {
                     const int q = top - lane;
                     const bool valid = q >= 0;
-                    const int old = valid ? S.loc[q] : 0;
+                    const int old = valid ? ld_loc(S, u, q) : 0;
                     const u64 Em = __ballot(valid && old == refbase);
                     if (Em & 1) break;                                              // already holds this site: nothing compared
                     const bool mm = valid && rb[q] != ref[refbase + q];
                     const u64 stopM = Em | __ballot(mm);
                     const int s = stopM ? __builtin_ctzll(stopM) : 64;
-                    if (valid && lane < s && (old < 0 || refbase == centerLoc)) S.loc[q] = refbase;
+                    if (valid && lane < s && (old < 0 || refbase == centerLoc)) st_loc(S, u, q, refbase);
                     u.cRefBytes += (unsigned)(min(s, min(64, top + 1)) + ((s < 64 && !((Em >> s) & 1)) ? 1 : 0));
                     if (s < 64) break;
                 }
@@ -473,7 +481,7 @@ template <class PF> __device__ __forceinline__ int extendScoreL(U &u, Lds &S, co
             for (int c = rl(offs, i) + k; c < blen; c += 64) {
                 const int q = c + lane;
                 const bool valid = q < blen && refbase + q < reflen;
-                const int old = valid ? S.loc[q] : -1;
+                const int old = valid ? ld_loc(S, u, q) : -1;
                 const bool A = valid && old >= 0;
                 const u64 Em = __ballot(valid && old == refbase);
                 if (Em & 1) break;
@@ -483,7 +491,7 @@ template <class PF> __device__ __forceinline__ int extendScoreL(U &u, Lds &S, co
                 const bool stop = valid && (old == refbase || (A && (mmBefore || mm)));
                 const u64 stopM = __ballot(stop) | ~validM;
                 const int s = stopM ? __builtin_ctzll(stopM) : 64;
-                if (valid && lane < s && !mm && (old < 0 || refbase == centerLoc)) S.loc[q] = refbase;
+                if (valid && lane < s && !mm && (old < 0 || refbase == centerLoc)) st_loc(S, u, q, refbase);
                 unsigned cnt = (unsigned)s;
                 if (s < 64 && ((validM >> s) & 1)) {
                     const bool Es = (Em >> s) & 1, As = (Am >> s) & 1;
@@ -497,7 +505,7 @@ template <class PF> __device__ __forceinline__ int extendScoreL(U &u, Lds &S, co
             wsync();
         }
     }
-    for (int i = lane; i < blen; i += 64) if (rb[i] == 'N') S.loc[i] = -2;
+    for (int i = lane; i < blen; i += 64) if (rb[i] == 'N') st_loc(S, u, i, -2);
     wsync();
     return uni(calcAffineScoreL<PF>(u, S, strand, p.kfilter));
 }
@@ -505,25 +513,27 @@ template <class PF> __device__ __forceinline__ int extendScoreL(U &u, Lds &S, co
 // BBIndex.makeGapArray :2837-2878 -- rare (a site spanning more than MINGAP + read length); one lane walks LDS
 __device__ __forceinline__ int makeGapArrayL(const U &u, Lds &S, int minLoc, int minGap) {
     if (u.lane == 0) {
-        int *locArray = S.loc;
+        // (the array is rewritten in place as the reference does; positions plus base indices still fit the 16-bit offsets)
+        auto LA = [&](int i) -> int { return ld_loc(S, u, i); };
+        auto SET = [&](int i, int v) { st_loc(S, u, i, v); };
         const int n = u.blen;
         int gaps = 0; bool doSort = false;
-        if (locArray[0] < 0) locArray[0] = minLoc;
+        if (LA(0) < 0) SET(0, minLoc);
         for (int i = 1; i < n; i++) {
-            if (locArray[i] < 0) locArray[i] = locArray[i - 1] + 1; else locArray[i] += i;
-            if (locArray[i] < locArray[i - 1]) doSort = true;
+            if (LA(i) < 0) SET(i, LA(i - 1) + 1); else SET(i, LA(i) + i);
+            if (LA(i) < LA(i - 1)) doSort = true;
         }
         if (doSort) {
-            for (int i = 1; i < n; i++) { const int v = locArray[i]; int j = i - 1; while (j >= 0 && locArray[j] > v) { locArray[j + 1] = locArray[j]; j--; } locArray[j + 1] = v; }
+            for (int i = 1; i < n; i++) { const int v = LA(i); int j = i - 1; while (j >= 0 && LA(j) > v) { SET(j + 1, LA(j)); j--; } SET(j + 1, v); }
         }
-        for (int i = 1; i < n; i++) if (locArray[i] - locArray[i - 1] > minGap) gaps++;
+        for (int i = 1; i < n; i++) if (LA(i) - LA(i - 1) > minGap) gaps++;
         int len = 0;
         if (gaps >= 1) {
             len = 2 + gaps * 2;
             if (len > BBIDX_MAX_GAPS) len = -1;
             else {
-                S.gaps[0] = locArray[0]; S.gaps[len - 1] = locArray[n - 1];
-                for (int i = 1, j = 1; i < n; i++) if (locArray[i] - locArray[i - 1] > minGap) { S.gaps[j] = locArray[i - 1]; S.gaps[j + 1] = locArray[i]; j += 2; }
+                S.gaps[0] = LA(0); S.gaps[len - 1] = LA(n - 1);
+                for (int i = 1, j = 1; i < n; i++) if (LA(i) - LA(i - 1) > minGap) { S.gaps[j] = LA(i - 1); S.gaps[j + 1] = LA(i); j += 2; }
             }
         }
         *S.ngapsP = len;
@@ -658,7 +668,7 @@ template <class PF> __device__ __forceinline__ void slowWalk3L(U &u, Lds &S, Lis
                     score = extendScoreL<PF>(u, S, L, strand, chrom, site);
                     locArrayValid = true;
                     int mn = INT_MAX, mx = INT_MIN;
-                    for (int i = lane; i < blen; i += 64) { const int x = S.loc[i]; if (x > -1) { mn = min(mn, x); mx = max(mx, x); } }
+                    for (int i = lane; i < blen; i += 64) { const int x = ld_loc(S, u, i); if (x > -1) { mn = min(mn, x); mx = max(mx, x); } }
                     mn = wmin(mn); mx = wmax(mx);
                     if (mn < 0 || mx < 0) score = -99999;
                     mapStart = u.c.toNumber(mn, chrom);
@@ -911,7 +921,7 @@ template <class PF> __global__ __launch_bounds__(64) void probe_long_kernel(cons
     {
         const int KM = lds_km(Q.maxKeys), LM = lds_lm(Q.maxLen);
         int *w = reinterpret_cast<int *>(ldsRaw);
-        S.loc = w; w += LM;
+        S.loc = reinterpret_cast<unsigned short *>(w); w += LM / 2;
         S.val = w; w += KM;
         for (int j = 0; j < NB; j++) { S.nb[j] = w; w += KM; }
         S.gaps = w; w += BBIDX_MAX_GAPS;
