@@ -30,6 +30,8 @@ import os
 extra = {}
 if os.environ.get("BBMAP_FASTCOLS"):
     extra["fastCols"] = int(os.environ["BBMAP_FASTCOLS"])
+if os.environ.get("BBMAP_TIPSEARCH"):                       # 0 switches findTipDeletions off (what part of the score kernel is it?)
+    extra["tipSearchDist"] = int(os.environ["BBMAP_TIPSEARCH"])
 mp = Mapper(di, n, 150, offs, ks, paired=paired, max_sites=max_sites, **extra)
 mp.load_reads(reads)
 for i in range(3):
