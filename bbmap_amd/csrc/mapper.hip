@@ -256,9 +256,17 @@ __device__ int tip_right(const uint8_t *bases, int len, const uint8_t *ref, int 
     if (tiplen < 4) return 0;
     searchDist = imin(searchDist, 30 * originalMismatches);
     const int last = imin(reflen - 1, originalStop + searchDist);
+    // The tip (byte j = bases[tipCoord - j]) against a sliding window of the reference (byte j = ref[start - j]): one reference byte
+    // enters per position and the mismatches of the first `tiplen` bytes are counted in one go -- the same count the byte loop
+    // reaches whenever it stays below minMismatches, which is all the comparison uses.
+    unsigned long long T = 0, Wd = 0;
+    for (int j = 0; j < 8; j++) T |= (unsigned long long)bases[tipCoord - j] << (8 * j);
+    for (int j = 1; j < 8; j++) Wd |= (unsigned long long)ref[originalStop + 1 - j] << (8 * (j - 1));      // the window of start - 1, about to shift
+    const unsigned long long keep = tiplen >= 8 ? 0x8080808080808080ull : ((1ull << (8 * tiplen)) - 1) & 0x8080808080808080ull;
     for (int start = originalStop + 1; start <= last && minMismatches > 0; start++) {
-        int mm = 0;
-        for (int j = 0; j < tiplen && mm < minMismatches; j++) if (bases[tipCoord - j] != ref[start - j]) mm++;
+        Wd = (Wd << 8) | ref[start];
+        const unsigned long long x = Wd ^ T;
+        const int mm = __builtin_popcountll((((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x) & keep);
         if (mm < minMismatches) { bestStart = start; minMismatches = mm; }
     }
     if (minMismatches > 2 || originalMismatches - minMismatches < 2) return 0;
@@ -277,9 +285,15 @@ __device__ int tip_left(const uint8_t *bases, const uint8_t *ref, int reflen, in
     if (tiplen < 4) return 0;
     searchDist = imin(searchDist, 16 + 16 * originalMismatches + 8 * tiplen);
     const int last = imax(0, originalStart - searchDist);
+    // as in tip_right: tip byte j = bases[j], window byte j = ref[start + j]; the window moves left one reference byte at a time
+    unsigned long long T = 0, Wd = 0;
+    for (int j = 0; j < 8; j++) T |= (unsigned long long)bases[j] << (8 * j);
+    for (int j = 1; j < 8; j++) Wd |= (unsigned long long)ref[originalStart - 1 + j] << (8 * (j - 1));     // the window of start + 1, about to shift
+    const unsigned long long keep = tiplen >= 8 ? 0x8080808080808080ull : ((1ull << (8 * tiplen)) - 1) & 0x8080808080808080ull;
     for (int start = originalStart - 1; start >= last && minMismatches > 0; start--) {
-        int mm = 0;
-        for (int j = 0; j < tiplen && mm < minMismatches; j++) if (bases[j] != ref[start + j]) mm++;
+        Wd = (Wd << 8) | ref[start];
+        const unsigned long long x = Wd ^ T;
+        const int mm = __builtin_popcountll((((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x) & keep);
         if (mm < minMismatches) { bestStart = start; minMismatches = mm; }
     }
     if (minMismatches > 2 || originalMismatches - minMismatches < 2) return 0;
