@@ -63,6 +63,9 @@ def _bind(L):
     L.bbmap_get_overflow_output.argtypes = [C.c_void_p, C.POINTER(bbmap_overflow_output)]
     L.bbmap_pack_sites_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.bbmap_pack_sites_device.restype = C.c_int
+    L.bbmap_map_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.bbmap_map_batch.restype = C.c_int
     for f in ("bbmap_default_config", "bbmap_create", "bbmap_map_batch_device", "bbmap_get_output", "bbmap_last_stats",
               "bbmap_get_overflow_output"):
         getattr(L, f).restype = C.c_int
@@ -168,6 +171,23 @@ class Mapper:
         _lib.check(self.L.bbmap_map_batch_device(self.h, C.c_void_p(stream), self.n, self.reads.data_ptr(), b.data_ptr(),
                                                  self.total_bytes, self.base_scores.data_ptr(), self.keyinfo.data_ptr()),
                    "bbmap_map_batch_device")
+
+    def map_batch_host(self, recs, bases, base_scores, keyinfo, sites_cap):
+        """bbmap_map_batch: host buffers in, packed site lists out (what the JNI glue calls).  Returns (nsites int32[n],
+        offsets int64[n + 1], records MSITE_DTYPE[min(total, sites_cap)], total)."""
+        recs = np.ascontiguousarray(recs, READ_DTYPE)
+        bases = np.ascontiguousarray(bases, np.uint8)
+        base_scores = np.ascontiguousarray(base_scores, np.int8)
+        keyinfo = np.ascontiguousarray(keyinfo, np.int32)
+        n = len(recs)
+        ns = np.zeros(n, np.int32)
+        offs = np.zeros(n + 1, np.int64)
+        sites = np.zeros(max(1, sites_cap), MSITE_DTYPE)
+        total = C.c_int64(0)
+        _lib.check(self.L.bbmap_map_batch(self.h, n, recs.ctypes.data, bases.ctypes.data, bases.size, base_scores.ctypes.data,
+                                          keyinfo.ctypes.data, keyinfo.size, ns.ctypes.data, offs.ctypes.data, sites.ctypes.data,
+                                          sites_cap, C.byref(total)), "bbmap_map_batch")
+        return ns, offs, sites[:min(total.value, sites_cap)], total.value
 
     def pack_sites(self, counts, offsets, packed):
         """The last step's site lists without their empty slots (bbmap_pack_sites_device), enqueued on the current stream:

@@ -210,3 +210,40 @@ def test_fill_logs_grow_instead_of_refusing_the_batch(paired):
     assert st["reads_overflowed"] == 0
     bad = compare(out, orc, n, paired=paired)
     assert not bad, "\n".join(bad[:20])
+
+
+def test_host_buffer_entry_returns_packed_lists_with_the_overflow_tier():
+    """bbmap_map_batch (what a host without device memory calls, e.g. the JNI glue): the same lists as the device-resident call, packed,
+    with the overflow tier's lists appended behind the others -- and a too small array reports how many records there are."""
+    ref, reads, L, k = _repeat_workload(True)
+    di = DeviceIndex.build([ref], k=k)
+    offs = O.make_offsets(L, k, 1.9)
+    ks = [100 * k] * len(offs)
+    n = reads.size // L
+    mp = Mapper(di, n, L, offs, ks, paired=True, max_sites=4)
+    mp.load_reads(reads)
+    mp.step()
+    out, st = mp.fetch(with_match=False), mp.stats()
+    assert st["reads_reprobed"] > 20 and st["reads_overflowed"] == 0
+    recs = np.zeros(n, np.dtype([("bases_off", "<i8"), ("keys_off", "<i8"), ("len", "<i4"), ("nkeys", "<i4")]))
+    recs["bases_off"] = np.arange(n, dtype=np.int64) * L
+    recs["len"] = L
+    recs["nkeys"] = len(offs)
+    keyinfo = np.array(list(offs) + list(ks), np.int32)
+    ns, po, sites, total = mp.map_batch_host(recs, reads, np.zeros(reads.size, np.int8), keyinfo, 64 * n)
+    assert total == len(sites) and (ns >= 0).all()
+    tier = out["overflow"]
+    where = {int(r): i for i, r in enumerate(tier["read_ids"])}
+    for r in range(n):
+        m = int(out["nsites"][r])
+        want = out["sites"][r][:max(m, 0)] if m != -3 else tier["sites"][where[r]][:int(tier["nsites"][where[r]])]
+        got = sites[po[r]:po[r] + ns[r]]
+        assert len(got) == len(want), r
+        for f in want.dtype.names:
+            if f not in ("match_job", "reserved"):
+                assert (got[f] == want[f]).all(), (r, f)
+    assert int(ns.max()) > 4                                   # (a list longer than the main capacity came through)
+    ns2, po2, sites2, total2 = mp.map_batch_host(recs, reads, np.zeros(reads.size, np.int8), keyinfo, 10)
+    assert total2 == total and len(sites2) == 10 and (ns2 == ns).all()
+    mp.close()
+    di.close()
