@@ -450,6 +450,7 @@ extern "C" int bbmsa_last_counts(bbmsa_ctx *c, int64_t *counts4) {
     unsigned h[16];
     HIP_TRY(hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
     counts4[0] = h[5]; counts4[1] = h[6]; counts4[2] = c->narrowBlocks > 0 ? h[4] : 0; counts4[3] = c->wideBlocks > 0 ? h[7] : h[1];
+    if (getenv("BBMAP_DP_COUNTS") && c->wideBlocks > 0) fprintf(stderr, "   (first pass handed %u jobs to the wide pass)\n", h[1]);
     return BBMAP_OK;
 }
 
