@@ -52,6 +52,8 @@ struct Settings {
     // min(POINTS_DEL, POINTS_INS - POINTS_MATCH2) of maxImperfectScore, and CLEARZONE1e = 2*MATCH2 - MATCH - SUB + 1
     // (AbstractMapThread.java:142)
     int ptsMatch, ptsMatch2, ptsSub, ptsSub2, ptsSub3, impDelta, clearzone1e;
+    int msaMaxColumns;          // columns of the reference's MSA instance (realign_new's padding rules read msa.maxColumns)
+    int finalStage;
 };
 
 struct SlowState {      // scoreSlow's loop state of one read
@@ -96,6 +98,12 @@ struct Dev {
     int pass;                   // rescue pass: 0 = mate 1 anchors, 1 = mate 2 anchors
     int plainColumns;           // widest window the first DP context takes
     int fillAhead;              // scoreSlow rounds: fill the sites behind the one in flight ahead of time
+    // the final alignment stage (mapper_final.h)
+    struct FinalRead *fin; bbmap_final *finalOut;
+    uint8_t *pool; long long poolUnits;         // match strings: bump-allocated in 4-byte units, counters[20] = units in use
+    const uint8_t *match, *gmatch; int matchStride, gmatchStride;
+                                // counters: [20] pool units in use, [21] largest allocation that failed, [22] allocations that failed, [23] final-stage
+                                // fills, [24] reads that need toLocalAlignment, [25] pool units those may take
 };
 
 __device__ inline int imin(int a, int b) { return a < b ? a : b; }
@@ -973,6 +981,8 @@ __global__ __launch_bounds__(128) void rescue_finish_kernel(const Dev D) {
     D.mcount[rl] = merge_duplicate_sites(sl, nl);
 }
 
+#include "mapper_final.h"
+
 // ---------------------------------------------------------------------------------------------- overflow tier
 // units (reads, or pairs in paired mode) whose site list did not fit: appended in any order, sorted on the host
 __global__ __launch_bounds__(128) void collect_overflow_kernel(const int *mcount, long long nunits, int paired, int *ids, unsigned *count) {
@@ -1038,6 +1048,7 @@ struct bbmap_ctx {
     int *d_chromMin;
     long long *d_chromOff;
     long long jobCap, gjobCap, rescCap;
+    bbmapper::FinalRead *d_fin; bbmap_final *d_final; uint8_t *d_pool; long long poolUnits, poolUsed, finalFills;
     int matchStride, gmatchStride, maxRows, plainColumns;
     unsigned *h_counters;           // pinned
     hipEvent_t ev[12];
@@ -1075,6 +1086,7 @@ extern "C" int bbmap_default_config_profile(int32_t profile, bbmap_config *c) {
     c->paired = 0; c->max_reads = 0; c->max_sites = 32;
     c->extraPadding = 10; c->maxPairDist = 32000; c->averagePairDist = 100; c->maxRescueDist = 1200; c->maxRescueMismatches = 32;
     c->maxTrimSitesToRetain = 800; c->trimList = 1; c->doRescue = 1; c->clearzone3 = 800; c->fastCols = 0; c->jobsPerRead = 0;
+    c->finalStage = profile == BBIDX_PROFILE_BBMAP ? 1 : 0;
     if (profile == BBIDX_PROFILE_PACBIO) {      // BBMapPacBio.setDefaults (BBMapPacBio.java:47-69), BBMapThreadPacBio.java:27-28
         c->max_read_len = 6016; c->minRatio = 0.46f; c->slowAlignPadding = 8; c->slowRescuePadding = 16; c->tipSearchDist = 15;
         c->alignColumns = 7600; c->msaMaxColumns = 7600;
@@ -1160,6 +1172,9 @@ static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *par
     if (pacbio) { S.ptsMatch = 90; S.ptsMatch2 = 100; S.ptsSub = -137; S.ptsSub2 = -49; S.ptsSub3 = -25; S.impDelta = -305; }   // min(-292, -205 - 100)
     else { S.ptsMatch = 70; S.ptsMatch2 = 100; S.ptsSub = -127; S.ptsSub2 = -51; S.ptsSub3 = -25; S.impDelta = -495; }          // min(-472, -395 - 100)
     S.clearzone1e = 2 * S.ptsMatch2 - S.ptsMatch - S.ptsSub + 1;
+    S.msaMaxColumns = cfg->msaMaxColumns;
+    if (cfg->finalStage && pacbio) return bail(mfail(BBMAP_E_ARG, "bbmap_create: the final alignment stage follows BBMapThread (BBIDX_PROFILE_BBMAP) only; set finalStage = 0 for BBIDX_PROFILE_PACBIO"));
+    S.finalStage = cfg->finalStage ? 1 : 0;
     // BBMap.java:434: `if(paired){BBIndex.QUIT_AFTER_TWO_PERFECTS=false;}` -- a static of the index class in the reference, so the
     // borrowed index context is switched the same way (and back for a single-ended mapper)
     index->dev.p.quitAfterTwoPerfects = cfg->paired ? 0 : 1;
@@ -1226,6 +1241,11 @@ static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *par
     DA(c->d_gjobs, c->gjobCap); DA(c->d_ggaps, c->gjobCap); DA(c->d_ginfo, c->gjobCap); DA(c->d_gresults, c->gjobCap); DA(c->d_gmatch, c->gjobCap * c->gmatchStride);
     DA(c->d_rjobs, c->rescCap); DA(c->d_rinfo, c->rescCap); DA(c->d_rres, c->rescCap); DA(c->d_rsite, c->rescCap);
     DA(c->d_pres, n / 2 + 1);
+    if (S.finalStage) {
+        // match strings of the final stage: one of the read's length per perfect read, about two per imperfect one; grows on demand
+        c->poolUnits = (n * (long long)(3 * (cfg->max_read_len + 16)) + 65536) / 4;
+        DA(c->d_fin, n); DA(c->d_final, n); DA(c->d_pool, c->poolUnits * 4);
+    }
     const int nch = index->dev.nchroms;
     DA(c->d_chromMin, nch + 1); DA(c->d_chromOff, nch + 1);
 #undef DA
@@ -1467,7 +1487,70 @@ static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const 
         }
     }
     MHIP(hipEventRecord(c->ev[6], stream));
+    // ---- the final alignment stage (mapper_final.h): policy, genMatchString in rounds, policy, toLocalAlignment
+    c->finalFills = 0; c->poolUsed = 0;
+    long long finalRounds = 0, finalLocal = 0;
+    if (c->S.finalStage) {
+        D.fin = c->d_fin; D.finalOut = c->d_final; D.pool = c->d_pool; D.poolUnits = c->poolUnits;
+        D.match = c->d_match; D.gmatch = c->d_gmatch; D.matchStride = c->matchStride; D.gmatchStride = c->gmatchStride;
+        hipLaunchKernelGGL(bbmapper::final_begin_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, D);
+        MHIP(hipGetLastError());
+        nActive = n_reads; first = true; cur = 0;
+        bool ranPlain = false, ranGapped = false;
+        for (int round = 0; nActive > 0; round++) {
+            if (round > 64 * c->cfg.max_sites + 64) return mfail(BBMAP_E_HIP, "bbmap_map_batch_device: the final stage does not come to an end (internal error)");
+            MHIP(hipMemsetAsync(c->d_counters + 2, 0, 4, stream));
+            MHIP(hipMemsetAsync(c->d_counters + 21, 0, 8, stream));
+            D.activeIn = first ? nullptr : c->d_active[cur]; D.nActiveIn = (int)nActive; D.activeOut = c->d_active[1 - cur];
+            hipLaunchKernelGGL(bbmapper::final_round_kernel, dim3((unsigned)((nActive + TB - 1) / TB)), dim3(TB), 0, stream, D);
+            MHIP(hipGetLastError());
+            MTRY(read_counters(c, stream));
+            add_dp_ms(c, ranPlain, ranGapped);
+            const long long asked = c->h_counters[0], gasked = c->h_counters[1];
+            const long long total = asked < c->jobCap ? asked : c->jobCap, gtotal = gasked < c->gjobCap ? gasked : c->gjobCap;
+            MTRY(run_fills(c, stream, bases, jobBase, total - jobBase, gBase, gtotal - gBase));
+            ranPlain = total > jobBase; ranGapped = gtotal > gBase;
+            jobBase = total; gBase = gtotal;
+            if (asked > c->jobCap || gasked > c->gjobCap) {
+                MTRY(grow_logs(c, stream, D, asked, gasked, total, gtotal));
+                D.match = c->d_match; D.gmatch = c->d_gmatch;
+            }
+            if (c->h_counters[22] > 0) {           // the match-string pool was full for some reads: they repeat their step next round
+                long long nu = c->poolUnits * 2, need = (long long)c->h_counters[20] + (long long)c->h_counters[22] * ((long long)c->h_counters[21] + 64);
+                if (nu < need) nu = need + need / 4;
+                if (nu > 0x7ffffff0LL) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: the final stage's match strings exceed 8 GB; map smaller batches");
+                std::vector<void *> dead;
+                MTRY(regrow(c, stream, &c->d_pool, (size_t)c->h_counters[20] * 4, (size_t)nu * 4, dead));
+                MHIP(hipStreamSynchronize(stream));
+                for (void *q : dead) (void)hipFree(q);
+                c->poolUnits = nu; D.pool = c->d_pool; D.poolUnits = nu;
+            }
+            nActive = c->h_counters[2];
+            cur = 1 - cur; first = false;
+            finalRounds++;
+        }
+        MHIP(hipStreamSynchronize(stream));
+        add_dp_ms(c, ranPlain, ranGapped);
+        MHIP(hipMemsetAsync(c->d_counters + 24, 0, 8, stream));
+        hipLaunchKernelGGL(bbmapper::final_end_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, D);
+        MHIP(hipGetLastError());
+        MTRY(read_counters(c, stream));
+        finalLocal = c->h_counters[24];
+        if ((long long)c->h_counters[20] + (long long)c->h_counters[25] + 64 > c->poolUnits) {      // room for toLocalAlignment's strings
+            const long long nu = (long long)c->h_counters[20] + (long long)c->h_counters[25] + 65536;
+            if (nu > 0x7ffffff0LL) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: the final stage's match strings exceed 8 GB; map smaller batches");
+            std::vector<void *> dead;
+            MTRY(regrow(c, stream, &c->d_pool, (size_t)c->h_counters[20] * 4, (size_t)nu * 4, dead));
+            MHIP(hipStreamSynchronize(stream));
+            for (void *q : dead) (void)hipFree(q);
+            c->poolUnits = nu; D.pool = c->d_pool; D.poolUnits = nu;
+        }
+        hipLaunchKernelGGL(bbmapper::final_local_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, D);
+        MHIP(hipGetLastError());
+    }
+    MHIP(hipEventRecord(c->ev[7], stream));
     MTRY(read_counters(c, stream));
+    c->finalFills = c->h_counters[23]; c->poolUsed = 4ll * c->h_counters[20];
     c->nJobs = c->h_counters[0]; c->nGapped = c->h_counters[1];
     bbmap_stats &st = c->stats;
     st.reads_overflowed = c->h_counters[3]; st.reads_without_site = c->h_counters[5];
@@ -1478,7 +1561,9 @@ static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const 
     (void)hipEventElapsedTime(&st.ms_slow, c->ev[3], c->ev[4]);
     (void)hipEventElapsedTime(&st.ms_finish, c->ev[4], c->ev[5]);
     (void)hipEventElapsedTime(&st.ms_rescue, c->ev[5], c->ev[6]);
-    (void)hipEventElapsedTime(&st.ms_total, c->ev[0], c->ev[6]);
+    (void)hipEventElapsedTime(&st.ms_final, c->ev[6], c->ev[7]);
+    (void)hipEventElapsedTime(&st.ms_total, c->ev[0], c->ev[7]);
+    st.final_fills = c->finalFills; st.final_rounds = finalRounds; st.final_local = finalLocal;
     c->ran = true;
     return BBMAP_OK;
 }
@@ -1539,6 +1624,7 @@ static int tier_finish(bbmap_ctx *c, hipStream_t stream) {
     st.reads_without_site += ts.reads_without_site;
     st.fills += ts.fills; st.gapped_fills += ts.gapped_fills; st.refills += ts.refills; st.rescue_scans += ts.rescue_scans;
     st.rescue_fills += ts.rescue_fills; st.fills_dropped += ts.fills_dropped;
+    st.final_fills += ts.final_fills; st.final_local += ts.final_local;
     if (getenv("BBMAP_TIER_DEBUG"))
         fprintf(stderr, "[bbmap tier] reads %lld: probe %.2f begin %.2f score %.2f slow %.2f (rounds %lld) finish %.2f rescue %.2f total %.2f\n",
                 tn, ts.ms_probe, ts.ms_begin, ts.ms_score, ts.ms_slow, (long long)ts.rounds, ts.ms_finish, ts.ms_rescue, ts.ms_total);
@@ -1704,6 +1790,53 @@ extern "C" int bbmap_get_output(bbmap_ctx *c, bbmap_output *o) {
     o->n_jobs = c->nJobs; o->n_gapped_jobs = c->nGapped;
     o->jobs = c->d_jobs; o->results = c->d_results; o->jobinfo = c->d_jinfo; o->match = c->d_match;
     o->gjobs = c->d_gjobs; o->gresults = c->d_gresults; o->gjobinfo = c->d_ginfo; o->gmatch = c->d_gmatch; o->ggaps = c->d_ggaps;
+    if (c->S.finalStage) { o->final = c->d_final; o->final_match = c->d_pool; o->final_match_bytes = c->poolUsed; o->n_final_fills = c->finalFills; }
+    return BBMAP_OK;
+}
+
+extern "C" int bbmap_set_average_pair_dist(bbmap_ctx *c, int32_t v) {
+    if (!c) return mfail(BBMAP_E_ARG, "bbmap_set_average_pair_dist: null context");
+    if (v < 0) return mfail(BBMAP_E_ARG, "bbmap_set_average_pair_dist: negative distance");
+    c->S.averagePairDist = v; c->cfg.averagePairDist = v;
+    if (c->tier) { c->tier->S.averagePairDist = v; c->tier->cfg.averagePairDist = v; }
+    return BBMAP_OK;
+}
+
+// The last batch's final records on the host, overflow tier included; match strings packed in read order.
+extern "C" int bbmap_get_final(bbmap_ctx *c, int64_t n_reads, bbmap_final *out, uint8_t *match_out, int64_t match_cap, int64_t *match_bytes) {
+    if (!c || !out) return mfail(BBMAP_E_ARG, "bbmap_get_final: null argument");
+    if (!c->S.finalStage) return mfail(BBMAP_E_ARG, "bbmap_get_final: the context runs without the final stage (bbmap_config.finalStage)");
+    if (!c->ran || n_reads != c->stats.reads) return mfail(BBMAP_E_ARG, "bbmap_get_final: n_reads is not the last batch's");
+    if (match_cap < 0 || (match_cap > 0 && !match_out)) return mfail(BBMAP_E_ARG, "bbmap_get_final: bad match buffer");
+    MHIP(hipSetDevice(c->cfg.device));
+    MHIP(hipMemcpy(out, c->d_final, (size_t)n_reads * sizeof(bbmap_final), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> pool((size_t)c->poolUsed + 4), tpool;
+    if (c->poolUsed > 0) MHIP(hipMemcpy(pool.data(), c->d_pool, (size_t)c->poolUsed, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> fromTier((size_t)n_reads, 0);
+    if (c->tier && c->tierReads > 0 && c->tier->ran) {
+        bbmap_ctx *t = c->tier;
+        std::vector<int32_t> ids((size_t)c->tierReads);
+        std::vector<bbmap_final> tf((size_t)c->tierReads);
+        MHIP(hipMemcpy(ids.data(), c->d_tierReadIds, (size_t)c->tierReads * 4, hipMemcpyDeviceToHost));
+        MHIP(hipMemcpy(tf.data(), t->d_final, (size_t)c->tierReads * sizeof(bbmap_final), hipMemcpyDeviceToHost));
+        tpool.resize((size_t)t->poolUsed + 4);
+        if (t->poolUsed > 0) MHIP(hipMemcpy(tpool.data(), t->d_pool, (size_t)t->poolUsed, hipMemcpyDeviceToHost));
+        for (long long i = 0; i < c->tierReads; i++) {
+            const int32_t r = ids[(size_t)i];
+            if (r < 0 || r >= n_reads || out[r].nsites != BBMAP_NSITES_IN_TIER) continue;
+            out[r] = tf[(size_t)i]; fromTier[(size_t)r] = 1;
+        }
+    }
+    int64_t used = 0;
+    for (int64_t r = 0; r < n_reads; r++) {
+        bbmap_final &f = out[r];
+        if (f.match_len <= 0) { f.match_off = 0; continue; }
+        const std::vector<uint8_t> &src = fromTier[(size_t)r] ? tpool : pool;
+        if (f.match_off < 0 || f.match_off + f.match_len > (int64_t)src.size()) return mfail(BBMAP_E_HIP, "bbmap_get_final: a match string lies outside its pool (internal error)");
+        if (match_out && used + f.match_len <= match_cap) memcpy(match_out + used, src.data() + f.match_off, (size_t)f.match_len);
+        f.match_off = used; used += f.match_len;
+    }
+    if (match_bytes) *match_bytes = used;
     return BBMAP_OK;
 }
 

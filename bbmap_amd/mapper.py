@@ -14,7 +14,11 @@ MSITE_DTYPE = np.dtype([("chrom", "<i4"), ("strand", "<i4"), ("start", "<i4"), (
                         ("perfect", "<i4"), ("semiperfect", "<i4"), ("rescued", "<i4"), ("ngaps", "<i4"),
                         ("gaps", "<i4", (16,)), ("match_job", "<i4"), ("reserved", "<i4", (2,))])
 JOBINFO_DTYPE = np.dtype([("read", "<i4"), ("seq", "<i4"), ("kind", "<i4"), ("site", "<i4")])
-assert MSITE_DTYPE.itemsize == 128
+# bbmap_final: what BBMap prints for a read (the final alignment stage)
+FINAL_DTYPE = np.dtype([("mapped", "<i4"), ("chrom", "<i4"), ("strand", "<i4"), ("start", "<i4"), ("stop", "<i4"), ("mapScore", "<i4"),
+                        ("paired", "<i4"), ("ambiguous", "<i4"), ("perfect", "<i4"), ("rescued", "<i4"), ("match_len", "<i4"),
+                        ("nsites", "<i4"), ("match_off", "<i8"), ("reserved", "<i4", (2,))])
+assert MSITE_DTYPE.itemsize == 128 and FINAL_DTYPE.itemsize == 64
 GAPPED_BIT = 1 << 30
 
 
@@ -23,7 +27,7 @@ class bbmap_config(C.Structure):
                 ("max_sites", C.c_int32), ("minRatio", C.c_float)] + [(n, C.c_int32) for n in (
                     "slowAlignPadding", "slowRescuePadding", "extraPadding", "tipSearchDist", "maxPairDist", "averagePairDist",
                     "maxRescueDist", "maxRescueMismatches", "maxTrimSitesToRetain", "trimList", "doRescue", "alignColumns",
-                    "clearzone3", "msaMaxColumns", "fastCols", "jobsPerRead")] + [("reserved", C.c_int32 * 4)]
+                    "clearzone3", "msaMaxColumns", "fastCols", "jobsPerRead", "finalStage")] + [("reserved", C.c_int32 * 4)]
 
 
 class bbmap_output(C.Structure):
@@ -31,7 +35,8 @@ class bbmap_output(C.Structure):
                 ("gmatch_stride", C.c_int32), ("reserved", C.c_int32), ("n_jobs", C.c_int64), ("n_gapped_jobs", C.c_int64),
                 ("jobs", C.c_void_p), ("results", C.c_void_p), ("jobinfo", C.c_void_p), ("match", C.c_void_p),
                 ("gjobs", C.c_void_p), ("gresults", C.c_void_p), ("gjobinfo", C.c_void_p), ("gmatch", C.c_void_p),
-                ("ggaps", C.c_void_p)]
+                ("ggaps", C.c_void_p), ("final", C.c_void_p), ("final_match", C.c_void_p), ("final_match_bytes", C.c_int64),
+                ("n_final_fills", C.c_int64)]
 
 
 class bbmap_stats(C.Structure):
@@ -40,7 +45,8 @@ class bbmap_stats(C.Structure):
                [(n, C.c_float) for n in ("ms_probe", "ms_begin", "ms_score", "ms_slow", "ms_finish", "ms_rescue", "ms_total",
                                          "ms_dp_narrow", "ms_dp_wave", "ms_dp_generic", "ms_dp_gapped", "ms_quick_rescue")] + \
                [("probe_stats", C.c_int64 * 5), ("reads_reprobed", C.c_int64), ("ms_overflow", C.c_float), ("log_growths", C.c_float),
-                ("ms_dp_wave_max", C.c_float), ("reserved_f", C.c_float)]
+                ("ms_dp_wave_max", C.c_float), ("ms_final", C.c_float), ("final_fills", C.c_int64), ("final_rounds", C.c_int64),
+                ("final_local", C.c_int64)]
 
 
 class bbmap_overflow_output(C.Structure):
@@ -66,6 +72,10 @@ def _bind(L):
     L.bbmap_map_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.bbmap_map_batch.restype = C.c_int
+    L.bbmap_get_final.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.bbmap_get_final.restype = C.c_int
+    L.bbmap_set_average_pair_dist.argtypes = [C.c_void_p, C.c_int32]
+    L.bbmap_set_average_pair_dist.restype = C.c_int
     for f in ("bbmap_default_config", "bbmap_create", "bbmap_map_batch_device", "bbmap_get_output", "bbmap_last_stats",
               "bbmap_get_overflow_output"):
         getattr(L, f).restype = C.c_int
@@ -189,6 +199,20 @@ class Mapper:
                                           sites_cap, C.byref(total)), "bbmap_map_batch")
         return ns, offs, sites[:min(total.value, sites_cap)], total.value
 
+    def final(self, with_match=True):
+        """bbmap_get_final: (records FINAL_DTYPE[n], match blob uint8[]) of the last step, overflow tier included; read r's match
+        string is blob[match_off : match_off + match_len]."""
+        fin = np.zeros(self.n, FINAL_DTYPE)
+        nb = C.c_int64(0)
+        _lib.check(self.L.bbmap_get_final(self.h, self.n, fin.ctypes.data, None, 0, C.byref(nb)), "bbmap_get_final")
+        blob = np.zeros(max(1, nb.value), np.uint8)
+        if with_match and nb.value:
+            _lib.check(self.L.bbmap_get_final(self.h, self.n, fin.ctypes.data, blob.ctypes.data, blob.size, C.byref(nb)), "bbmap_get_final")
+        return fin, blob
+
+    def set_average_pair_dist(self, v):
+        _lib.check(self.L.bbmap_set_average_pair_dist(self.h, int(v)), "bbmap_set_average_pair_dist")
+
     def pack_sites(self, counts, offsets, packed):
         """The last step's site lists without their empty slots (bbmap_pack_sites_device), enqueued on the current stream:
         counts int32[n+1], offsets int64[n+1], packed uint8[cap_records * 128] -- device tensors of the caller's."""
@@ -243,4 +267,6 @@ class Mapper:
             t = self._fetch_output(ov.out, int(ov.n_reads), with_match)
             t["read_ids"] = _copy(ov.read_ids, int(ov.n_reads) * 4, self.dev).view(np.int32)
             out["overflow"] = t
+        if self.cfg.finalStage and rows is None:
+            out["final"], out["final_match"] = self.final(with_match)
         return out

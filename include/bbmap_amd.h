@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define BBMAP_AMD_ABI_VERSION 5
+#define BBMAP_AMD_ABI_VERSION 6
 
 enum {
     BBMAP_OK = 0,
@@ -174,8 +174,9 @@ int bbmsa_legacy_stats(bbmsa_ctx *ctx, int64_t *stats6);
  * 668-757: long gaps shrink to 64+rem bases, GAPC symbols, 64 bases), fills it as fillLimited(..., gaps) does
  * (:116-128), runs score(..., gapped=true) / traceback(..., gapped=true) (:362-372, :499-531) and translates
  * score[1], score[2] back to reference coordinates (:759-779).  Jobs with ngaps == 0 behave exactly as in
- * bbmsa_align_batch_device.  For gapped jobs the mode bits of job.flags are ignored (always the Java fillLimited
- * + window clamp + score); BBMSA_DO_TRACEBACK is honoured.  The reference asserts gstart == 0 (:514); a job that
+ * bbmsa_align_batch_device.  For gapped jobs the mode bits of job.flags select the Java fillLimited (any mode but
+ * BBMSA_FILL_UNLIMITED_RAW) or fillUnlimited(read, ref, a, b, gaps) (:166-176; BBMSA_FILL_UNLIMITED_RAW), always with the
+ * window clamp and score; BBMSA_DO_TRACEBACK is honoured.  The reference asserts gstart == 0 (:514); a job that
  * would break that, or whose gapped reference exceeds maxColumns + 2 bytes, gets BBMSA_ST_BAD_SHAPE. */
 #define BBMSA_MAX_GAPS 16
 typedef struct bbmsa_gaps { int32_t ngaps; int32_t gaps[BBMSA_MAX_GAPS]; } bbmsa_gaps;   /* 68 bytes */
@@ -451,9 +452,13 @@ int bbpipe_quick_rescue_device(void *stream, int64_t n_jobs, const bbresc_job *j
  *     mergeDuplicateSites Tools.java:697-759
  *     rescue / slowRescue AbstractMapThread.java:1144-1306 (quickRescue :2303-2404), mate 1 as anchor, then mate 2
  *   Configuration: bbmap.sh defaults (BBMap.setDefaults, BBMap.java:45-65), reads without qualities.
- *   Not carried over: per-thread adaptive state of the Java mapper (DYNAMIC_INSERT_LENGTH, the "mating is not working" skip
- *   of rescue()), scaffold boundaries inside a chromosome, and everything after the rescue stage (final pairing, ambiguity /
- *   clearzone policy, genMatchString -> realign_new): those stay on the host side of the boundary.
+ *     the final stage    BBMapThread.java:492-732 / :1116-1356 (cfg.finalStage): final pairing (pairSiteScoresFinal), the ambiguity
+ *                        policy, genMatchString -> genMatchStringForSite -> realign_new (AbstractMapThread.java:860-1068,
+ *                        TranslateColorspaceRead.java:229-653: up to three fillLimited and one fillUnlimited per call, again in rounds),
+ *                        fixXY / clipTipIndels / toLocalAlignment, applyClearzone3 and the tip penalty -> bbmap_final per read
+ *   Not carried over: per-thread adaptive state of the Java mapper (DYNAMIC_INSERT_LENGTH: the caller feeds averagePairDist, see
+ *   bbmap_set_average_pair_dist; the "mating is not working" skip of rescue()), scaffold boundaries inside a chromosome, the
+ *   non-default output policies (ambiguous=toss/random/all, secondary alignments, identity / edit filters, local alignment).
  *   Added product: every successful fill also returns its traceback string (as the quickmatch=t branch obtains it,
  *   BBMapThread.java:345, without fixXY / clipTipIndels); site state follows the default (quickmatch=f) flow.
  * ===================================================================================== */
@@ -477,7 +482,9 @@ typedef struct bbmap_jobinfo {     /* one entry per fill, parallel to the job / 
     int32_t read;                  /* read the fill belongs to */
     int32_t seq;                   /* its position in that read's sequence of fillAndScoreLimited calls; -1 = a fill issued ahead
                                     * of time that the sequence turned out not to contain (ignore it) */
-    int32_t kind;                  /* 0 scoreSlow fill, 1 scoreSlow wider refill, 2 slowRescue */
+    int32_t kind;                  /* 0 scoreSlow fill, 1 scoreSlow wider refill, 2 slowRescue; final stage (realign_new,
+                                    * current/align2/TranslateColorspaceRead.java:370, :413, :450, :457): 3 first fill, 4 padded refill,
+                                    * 5 third fill, 6 fillUnlimited */
     int32_t site;                  /* list position of the site when the fill was issued */
 } bbmap_jobinfo;                   /* 16 bytes */
 
@@ -508,11 +515,28 @@ typedef struct bbmap_config {
                                     * windows and gapped references go to the second context (the "gapped" log) */
     int32_t jobsPerRead;           /* STARTING capacity of the job log = jobsPerRead * max_reads (0 = 3); the logs grow on demand.
                                     * < 0: exactly -jobsPerRead entries in each log to start with (tests of the growth path) */
+    int32_t finalStage;            /* 1 (default, BBIDX_PROFILE_BBMAP): the whole of processRead / processReadPair -- after rescue the final
+                                    * pairing, the ambiguity policy, genMatchString -> genMatchStringForSite -> realign_new (the fills that
+                                    * produce the printed start / stop / score and the match string), clipping and the score penalties;
+                                    * 0: stop after the rescue stage (the site lists as scoreSlow and rescue leave them) */
     int32_t reserved[4];           /* [0] != 0: strictly one fill per read and round (no fills ahead of time; for tests)
                                     * [1] overflow tier: reads it can hold per batch (0 = 4096, < 0 = no tier)
                                     * [2] overflow tier: its max_sites (0 = 1024)
                                     * [3] BBIDX_PROFILE_*: which mapper / aligner classes are followed (must equal the index's) */
 } bbmap_config;
+
+/* What BBMap prints for a read: stream.Read's mapping fields when processRead / processReadPair return (current/stream/Read.java;
+ * set by genMatchString, current/align2/AbstractMapThread.java:946-959, and the policy behind it).  Filled when cfg.finalStage. */
+typedef struct bbmap_final {
+    int32_t mapped;                /* Read.mapped() */
+    int32_t chrom, strand, start, stop;   /* -1, 0, -1, -1 when not mapped */
+    int32_t mapScore;
+    int32_t paired, ambiguous, perfect, rescued;
+    int32_t match_len;             /* length of Read.match (long format: m S N D I X Y C), 0 = null */
+    int32_t nsites;                /* sites left in the read's list (the list itself: bbmap_output.sites), or the overflow flags */
+    int64_t match_off;             /* byte offset of the string in bbmap_output.final_match (valid when match_len > 0) */
+    int32_t reserved[2];
+} bbmap_final;                     /* 64 bytes */
 
 typedef struct bbmap_output {      /* device pointers, valid until the next bbmap_map_batch_device / bbmap_destroy */
     const bbmap_msite *sites;      /* n_reads x cap */
@@ -527,6 +551,13 @@ typedef struct bbmap_output {      /* device pointers, valid until the next bbma
     const bbmsa_job *jobs;   const bbmsa_result *results;  const bbmap_jobinfo *jobinfo;  const uint8_t *match;
     const bbmsa_job *gjobs;  const bbmsa_result *gresults; const bbmap_jobinfo *gjobinfo; const uint8_t *gmatch;
     const bbmsa_gaps *ggaps;
+    /* the final alignment stage (cfg.finalStage): one record per read and the pool its match strings live in.  A site that was given a
+     * match string of its own refers to it in the same pool: sites[].reserved[0] = byte offset / 4 + 1 (0 = none),
+     * reserved[1] & 0xffff = its length.  NULL / 0 when the stage is off. */
+    const bbmap_final *final;
+    const uint8_t *final_match;
+    int64_t final_match_bytes;     /* bytes of the pool in use */
+    int64_t n_final_fills;         /* fills the stage issued (they are in the two logs, kinds 3..6) */
 } bbmap_output;
 
 typedef struct bbmap_stats {
@@ -542,7 +573,8 @@ typedef struct bbmap_stats {
     float log_growths;             /* times a fill log had to grow during the batch (the logs start at jobsPerRead entries per read) */
     float ms_dp_wave_max;          /* the longest single wavefront-kernel pass of the plain DP context in the batch (round 1's, as a rule);
                                     * ms_dp_wave is the sum over all rounds and rescue passes */
-    float reserved_f;
+    float ms_final;                /* the final alignment stage (included in ms_total) */
+    int64_t final_fills, final_rounds, final_local;   /* its fills, rounds, reads that went through toLocalAlignment */
 } bbmap_stats;
 
 typedef struct bbmap_ctx bbmap_ctx;
@@ -559,6 +591,11 @@ int bbmap_default_config_profile(int32_t profile, bbmap_config *cfg);
  * class's static (`if(paired){BBIndex.QUIT_AFTER_TWO_PERFECTS=false;}`, current/align2/BBMap.java:434). */
 int bbmap_create(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx **out);
 void bbmap_destroy(bbmap_ctx *ctx);
+/* AVERAGE_PAIR_DIST for the batches to come.  The reference's mapping threads move it as they see pairs (DYNAMIC_INSERT_LENGTH:
+ * `if(numMated>1000 && r.paired()){AVERAGE_PAIR_DIST=(int)(innerLengthSum*1f/numMated);}`, current/align2/BBMapThread.java:1307-1309,
+ * per thread); a host that carries that running value sets it here between batches (cfg.averagePairDist is only the initial value,
+ * INITIAL_AVERAGE_PAIR_DIST).  It enters pairSiteScoresInitial / Final and the rescue search (:1086, :1093). */
+int bbmap_set_average_pair_dist(bbmap_ctx *ctx, int32_t average_pair_dist);
 /* Maps a batch that is resident on the device.  reads[i].bases_off addresses the plus strand inside `bases`; the call writes
  * every read's reverse complement at bases_off + minus_delta.  Enqueues on `stream` and waits for it: the call returns when the
  * batch is done (the rounds of scoreSlow need the job counts on the host). */
@@ -584,6 +621,11 @@ typedef struct bbmap_overflow_output {
     bbmap_output out;
 } bbmap_overflow_output;
 int bbmap_get_overflow_output(bbmap_ctx *ctx, bbmap_overflow_output *out);
+/* The last batch's final records on the host, overflow tier included (a read the tier mapped gets the tier's record): out[n_reads];
+ * the match strings are packed into match_out in read order and out[r].match_off is rewritten to the string's offset THERE.
+ * *match_bytes = bytes the strings take; strings that do not fit match_cap are not written (call again with a larger buffer).
+ * match_out may be NULL (records only).  BBMAP_E_ARG when the context runs without the final stage. */
+int bbmap_get_final(bbmap_ctx *ctx, int64_t n_reads, bbmap_final *out, uint8_t *match_out, int64_t match_cap, int64_t *match_bytes);
 int bbmap_last_stats(bbmap_ctx *ctx, bbmap_stats *out);
 /* The last batch's site lists without their empty slots, for a host that copies them back: counts (n_reads + 1 ints), offsets
  * (n_reads + 1 int64: exclusive prefix sums, offsets[n_reads] = total) and packed (packed_cap records) are device buffers of the

@@ -63,6 +63,7 @@ enum { CLEARZONE1E = 2 * 100 - 70 + 127 + 1, QR_MATCH = 70, QR_MATCH2 = 100 };  
 #endif
 
 typedef struct { orc_msite s[LISTCAP]; int n; } slist;
+typedef struct { uint8_t *p; int len; } mstr;       /* a match string of the final stage (final_stage.inc) */
 
 typedef struct {
     const orc_index *ix;
@@ -76,6 +77,8 @@ typedef struct {
     int64_t dpJobs, cells, rescueScans;
     int seq[2];                    /* per-read fill sequence numbers of the pair being processed */
     int64_t readIdx[2];
+    mstr *ms; int nms, mscap;      /* match strings of the pair being processed (final stage) */
+    int64_t finalFills;
 } mapper;
 
 /* ------------------------------------------------------------------ SiteScore setters (SiteScore.java:905-998) */
@@ -653,8 +656,10 @@ static void rescue(mapper *M, int whichLoose, slist *anchor, slist *loose, int a
     }
 }
 
-/* ------------------------------------------------------------------ processRead (BBMapThread.java:389-490) */
-static void process_read(mapper *M, const readin *in, slist *l) {
+#include "final_stage.inc"
+
+/* ------------------------------------------------------------------ processRead (BBMapThread.java:389-490; with finalStage to :732) */
+static void process_read(mapper *M, const readin *in, slist *l, orc_final *fin, uint8_t *fmatch, int fstride) {
     const uint8_t *bp = in->bp; const int L = in->L;
     uint8_t *bm = (uint8_t *)malloc((size_t)L + 1);
     complement_into(bm, bp, L);
@@ -668,12 +673,19 @@ static void process_read(mapper *M, const readin *in, slist *l) {
         if (near < 1) score_slow(M, 0, l, bp, bm, L, maxSw, maxImp, 0);
     }
     if (l->n > 0) { merge_duplicate_sites(l); sort_list(l, cmp_score); }
+    if (M->P->finalStage) {
+        rstate r; r_init(&r, bp, bm, L, M->readIdx[0]);
+        final_single(M, &r, l);
+        store_final(M, &r, l, fin, fmatch, fstride);
+        m_reset(M);
+    }
     free(bm);
 }
 
 /* ------------------------------------------------------------------ processReadPair (BBMapThread.java:943-1098) */
 static void process_pair_tail(mapper *M, const uint8_t *bp1, const uint8_t *bm1, const uint8_t *bp2, const uint8_t *bm2, int L, slist *l1, slist *l2);
-static void process_pair(mapper *M, const readin *in1, const readin *in2, slist *l1, slist *l2) {
+static void process_pair(mapper *M, const readin *in1, const readin *in2, slist *l1, slist *l2, orc_final *fin1, orc_final *fin2,
+                         uint8_t *fmatch1, uint8_t *fmatch2, int fstride) {
     const orc_map_params *P = M->P;
     const uint8_t *bp1 = in1->bp, *bp2 = in2->bp;
     const int L = in1->L;                                   /* both mates have one length in every caller of this restatement */
@@ -703,6 +715,12 @@ static void process_pair(mapper *M, const readin *in1, const readin *in2, slist 
         }
     }
     process_pair_tail(M, bp1, bm1, bp2, bm2, L, l1, l2);
+    if (P->finalStage) {
+        rstate r1, r2; r_init(&r1, bp1, bm1, L, M->readIdx[0]); r_init(&r2, bp2, bm2, L, M->readIdx[1]);
+        final_pair(M, &r1, &r2, l1, l2);
+        store_final(M, &r1, l1, fin1, fmatch1, fstride); store_final(M, &r2, l2, fin2, fmatch2, fstride);
+        m_reset(M);
+    }
     free(bm1); free(bm2);
 }
 static void process_pair_tail(mapper *M, const uint8_t *bp1, const uint8_t *bm1, const uint8_t *bp2, const uint8_t *bm2, int L, slist *l1, slist *l2) {
@@ -737,6 +755,7 @@ void orc_map_default_params(orc_map_params *P) {
     memset(P, 0, sizeof *P);
     P->maxPairDist = 32000; P->averagePairDist = 100; P->maxRescueDist = 1200; P->maxRescueMismatches = 32;
     P->maxTrimSitesToRetain = 800; P->trimList = 1; P->doRescue = 1; P->clearzone3 = 800; P->extraPadding = 10;
+    P->finalStage = 1;
 #ifdef ORC_PACBIO   /* BBMapPacBio.setDefaults (BBMapPacBio.java:47-69), BBMapThreadPacBio.java:27-28, BBIndexPacBio.java:2462 */
     P->minRatio = 0.46f; P->slowAlignPadding = 8; P->slowRescuePadding = 16; P->tipSearchDist = 15;
     P->alignColumns = 7600; P->msaMaxRows = 6020; P->msaMaxColumns = 7600;
@@ -753,7 +772,8 @@ typedef struct {
     int cap; orc_msite *sites; int32_t *nsites;
     orc_mjob *log; int64_t logcap; volatile int64_t *nlog; uint8_t *match; int matchStride;
     volatile int64_t *next;
-    int64_t dpJobs, cells, rescueScans, mapped;
+    int64_t dpJobs, cells, rescueScans, mapped, finalFills;
+    orc_final *fin; uint8_t *fmatch; int fstride;
 } drv_arg;
 
 static void store_list(const slist *l, orc_msite *out, int32_t *nout, int cap) {
@@ -761,6 +781,7 @@ static void store_list(const slist *l, orc_msite *out, int32_t *nout, int cap) {
     if (l->n > cap) { *nout = -1; return; }
     *nout = l->n;
     memcpy(out, l->s, sizeof(orc_msite) * (size_t)l->n);
+    for (int i = 0; i < l->n; i++) out[i].reserved[0] = out[i].reserved[1] = 0;     /* the final stage's arena ids mean nothing outside */
 }
 
 static readin read_in(const drv_arg *w, int64_t r) {
@@ -788,21 +809,22 @@ static void *drv_worker(void *p) {
             if (w->paired) {
                 M.readIdx[0] = 2 * r; M.readIdx[1] = 2 * r + 1;
                 const readin a = read_in(w, 2 * r), b = read_in(w, 2 * r + 1);
-                process_pair(&M, &a, &b, l1, l2);
+                process_pair(&M, &a, &b, l1, l2, w->fin ? &w->fin[2 * r] : NULL, w->fin ? &w->fin[2 * r + 1] : NULL,
+                             w->fmatch ? w->fmatch + 2 * r * (int64_t)w->fstride : NULL, w->fmatch ? w->fmatch + (2 * r + 1) * (int64_t)w->fstride : NULL, w->fstride);
                 store_list(l1, w->sites ? w->sites + 2 * r * w->cap : NULL, w->nsites ? &w->nsites[2 * r] : NULL, w->cap);
                 store_list(l2, w->sites ? w->sites + (2 * r + 1) * w->cap : NULL, w->nsites ? &w->nsites[2 * r + 1] : NULL, w->cap);
                 w->mapped += (l1->n > 0) + (l2->n > 0);
             } else {
                 M.readIdx[0] = r;
                 const readin a = read_in(w, r);
-                process_read(&M, &a, l1);
+                process_read(&M, &a, l1, w->fin ? &w->fin[r] : NULL, w->fmatch ? w->fmatch + r * (int64_t)w->fstride : NULL, w->fstride);
                 store_list(l1, w->sites ? w->sites + r * w->cap : NULL, w->nsites ? &w->nsites[r] : NULL, w->cap);
                 w->mapped += (l1->n > 0);
             }
         }
     }
-    w->dpJobs = M.dpJobs; w->cells = M.cells; w->rescueScans = M.rescueScans;
-    free(l1); free(l2); free(M.tb); orc_msa_free(M.msa);
+    w->dpJobs = M.dpJobs; w->cells = M.cells; w->rescueScans = M.rescueScans; w->finalFills = M.finalFills;
+    free(l1); free(l2); free(M.tb); free(M.ms); orc_msa_free(M.msa);
     return NULL;
 }
 
@@ -815,6 +837,16 @@ double orc_map_reads(const orc_index *ix, const orc_map_params *P, const orc_rea
                      const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo, int cap,
                      orc_msite *sites, int32_t *nsites,
                      orc_mjob *log, int64_t logcap, int64_t *nlog, uint8_t *match, int matchStride, int threads, int64_t *stats4) {
+    return orc_map_reads_final(ix, P, recs, n_reads, paired, bases, baseScores, keyinfo, cap, sites, nsites, log, logcap, nlog, match, matchStride,
+                               threads, stats4, NULL, NULL, 0);
+}
+/* The same with the final stage's per-read records (P->finalStage): fin[n_reads], fmatch = n_reads x fstride bytes (the read's match string,
+ * when it fits; fin[r].match_len is its length either way).  stats4[0] counts the final stage's fills too. */
+double orc_map_reads_final(const orc_index *ix, const orc_map_params *P, const orc_read *recs, int64_t n_reads, int paired,
+                           const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo, int cap,
+                           orc_msite *sites, int32_t *nsites,
+                           orc_mjob *log, int64_t logcap, int64_t *nlog, uint8_t *match, int matchStride, int threads, int64_t *stats4,
+                           orc_final *fin, uint8_t *fmatch, int fstride) {
     if (threads < 1) threads = 1;
     if (n_reads < 1 || (paired && (n_reads & 1))) return -1.0;
     for (int64_t r = 0; r < n_reads; r++) if (recs[r].len > P->msaMaxRows - 1) return -1.0;      /* maxReadLength() = ALIGN_ROWS - 1 */
@@ -830,6 +862,7 @@ double orc_map_reads(const orc_index *ix, const orc_map_params *P, const orc_rea
         a->n = paired ? n_reads / 2 : n_reads; a->paired = paired;
         a->cap = cap; a->sites = sites; a->nsites = nsites;
         a->log = log; a->logcap = logcap; a->nlog = &nl; a->match = match; a->matchStride = matchStride; a->next = &next;
+        a->fin = fin; a->fmatch = fmatch; a->fstride = fstride;
         pthread_create(&th[t], NULL, drv_worker, a);
     }
     int64_t s[4] = {0, 0, 0, 0};

@@ -41,10 +41,21 @@ typedef struct orc_map_params {
     int32_t alignColumns;          /* BBIndex.ALIGN_COLUMNS 3000 */
     int32_t clearzone3;            /* PENALIZE_AMBIG ? 800 : 0 */
     int32_t msaMaxRows, msaMaxColumns;   /* the MSA instance: 601 x 3000 in the reference */
+    int32_t finalStage;            /* 1: the whole of processRead / processReadPair (final pairing, ambiguity, genMatchString -> realign_new,
+                                    * clipping, penalties: final_stage.inc); 0: stop after the rescue stage (rounds 1-3) */
 } orc_map_params;
 
+/* what BBMap prints for a read: stream.Read's mapping fields after processRead / processReadPair (current/stream/Read.java) */
+typedef struct orc_final {
+    int32_t mapped, chrom, strand, start, stop, mapScore;
+    int32_t paired, ambiguous, perfect, rescued;
+    int32_t match_len;             /* length of Read.match (long format), 0 = null */
+    int32_t nsites;                /* sites left in the read's list */
+} orc_final;                       /* 48 bytes */
+
 typedef struct orc_mjob {          /* one MSA.fillAndScoreLimited call */
-    int32_t read, seq, kind;       /* kind: 0 scoreSlow fill, 1 scoreSlow wider refill, 2 slowRescue */
+    int32_t read, seq, kind;       /* kind: 0 scoreSlow fill, 1 scoreSlow wider refill, 2 slowRescue; realign_new: 3 first fill, 4 padded
+                                    * refill, 5 third fill, 6 fillUnlimited */
     int32_t strand, chrom, refStartLoc, refEndLoc, minScore, ngaps;
     int32_t score_len; int32_t score[8];
     int32_t match_len, pad_;
@@ -62,6 +73,11 @@ double orc_map_reads(const orc_index *ix, const orc_map_params *P, const orc_rea
                      const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo, int cap,
                      orc_msite *sites, int32_t *nsites,
                      orc_mjob *log, int64_t logcap, int64_t *nlog, uint8_t *match, int matchStride, int threads, int64_t *stats4);
+double orc_map_reads_final(const orc_index *ix, const orc_map_params *P, const orc_read *recs, int64_t n_reads, int paired,
+                           const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo, int cap,
+                           orc_msite *sites, int32_t *nsites,
+                           orc_mjob *log, int64_t logcap, int64_t *nlog, uint8_t *match, int matchStride, int threads, int64_t *stats4,
+                           orc_final *fin, uint8_t *fmatch, int fstride);
 float orc_ratio_paired(float R);
 float orc_ratio_pre_rescue(float R);
 double orc_map_batch(const orc_index *ix, const orc_map_params *P, const uint8_t *reads1, const uint8_t *reads2, int64_t n, int L,

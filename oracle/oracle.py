@@ -425,7 +425,13 @@ class MapParams(C.Structure):
     _fields_ = [("minRatio", C.c_float)] + [(n, C.c_int32) for n in (
         "slowAlignPadding", "slowRescuePadding", "extraPadding", "tipSearchDist", "maxPairDist", "averagePairDist",
         "maxRescueDist", "maxRescueMismatches", "maxTrimSitesToRetain", "trimList", "doRescue", "alignColumns",
-        "clearzone3", "msaMaxRows", "msaMaxColumns")]
+        "clearzone3", "msaMaxRows", "msaMaxColumns", "finalStage")]
+
+
+# orc_final: stream.Read's mapping fields after processRead / processReadPair (the final alignment stage, final_stage.inc)
+FINAL_DTYPE = np.dtype([(n, "<i4") for n in ("mapped", "chrom", "strand", "start", "stop", "mapScore", "paired", "ambiguous",
+                                             "perfect", "rescued", "match_len", "nsites")])
+assert FINAL_DTYPE.itemsize == 48
 
 
 def map_default_params(profile="bbmap", **kw):
@@ -436,50 +442,46 @@ def map_default_params(profile="bbmap", **kw):
     return p
 
 
-def map_batch(oi, reads1, reads2, L, offsets, key_scores, params=None, cap=64, want_log=True, threads=1, match_stride=0):
-    """The mapper control flow (BBMapThread.processRead / processReadPair up to the end of rescue) on the CPU oracle.
-    reads1/reads2: uint8 arrays of n*L bases (reads2 None = single-ended).  Returns a dict: sites1/nsites1 (and 2), the job
-    log (one record per fillAndScoreLimited call, with its traceback string), stats, seconds."""
-    L_ = oi.L
-    p = params or map_default_params(getattr(oi, "profile", "bbmap"))
-    r1 = np.ascontiguousarray(reads1, np.uint8)
-    n = r1.size // L
-    r2 = None if reads2 is None else np.ascontiguousarray(reads2, np.uint8)
-    offs = np.asarray(offsets, np.int32).copy()
-    ks = np.asarray(key_scores, np.int32).copy()
-    s1 = np.zeros((n, cap), MSITE_DTYPE)
-    n1 = np.zeros(n, np.int32)
-    s2 = np.zeros((n, cap), MSITE_DTYPE) if r2 is not None else None
-    n2 = np.zeros(n, np.int32) if r2 is not None else None
-    logcap = (n * 8 * (2 if r2 is not None else 1) + 64) if want_log else 0
-    log = np.zeros(max(1, logcap), MJOB_DTYPE)
-    stride = match_stride or (p.msaMaxRows + 700)
-    match = np.zeros((max(1, logcap), stride), np.uint8) if want_log else None
-    nlog = C.c_int64(0)
-    stats = np.zeros(4, np.int64)
-    L_.orc_map_batch.restype = C.c_double
-    L_.orc_map_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
-                                 C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-    t = L_.orc_map_batch(C.c_void_p(oi.h), C.byref(p), r1.ctypes.data, None if r2 is None else r2.ctypes.data, n, L,
-                         offs.ctypes.data, ks.ctypes.data, len(offs), cap,
-                         s1.ctypes.data, n1.ctypes.data, None if s2 is None else s2.ctypes.data, None if n2 is None else n2.ctypes.data,
-                         log.ctypes.data if want_log else None, logcap, C.addressof(nlog),
-                         match.ctypes.data if want_log else None, stride, threads, stats.ctypes.data)
-    if want_log and nlog.value > logcap:
-        raise RuntimeError("job log overflow")
-    return dict(sites1=s1, nsites1=n1, sites2=s2, nsites2=n2, log=log[:nlog.value] if want_log else None,
-                match=match[:nlog.value] if want_log else None, stats=stats.tolist(), seconds=t)
-
-
 READ_DTYPE = np.dtype([("bases_off", "<i8"), ("keys_off", "<i8"), ("len", "<i4"), ("nkeys", "<i4")])     # orc_read = bbidx_read
+
+
+def map_batch(oi, reads1, reads2, L, offsets, key_scores, params=None, cap=64, want_log=True, threads=1, match_stride=0):
+    """The mapper control flow (BBMapThread.processRead / processReadPair; params.finalStage = 0 stops after the rescue stage) on
+    the CPU oracle, for the uniform case: every read L bases, one set of key offsets / scores.  reads1/reads2: uint8 arrays of
+    n*L bases (reads2 None = single-ended).  Returns a dict: sites1/nsites1 (and 2), final1 (and 2) + fmatch1 (and 2), the job
+    log (one record per fill, with its traceback string), stats, seconds."""
+    r1 = np.ascontiguousarray(reads1, np.uint8).reshape(-1, L)
+    n = r1.shape[0]
+    paired = reads2 is not None
+    if paired:
+        r2 = np.ascontiguousarray(reads2, np.uint8).reshape(-1, L)
+        bases = np.stack([r1, r2], axis=1).reshape(-1)
+    else:
+        bases = r1.reshape(-1)
+    nr = 2 * n if paired else n
+    recs = np.zeros(nr, READ_DTYPE)
+    recs["bases_off"] = np.arange(nr, dtype=np.int64) * L
+    recs["keys_off"] = 0
+    recs["len"] = L
+    recs["nkeys"] = len(offsets)
+    keyinfo = np.concatenate([np.asarray(offsets, np.int32), np.asarray(key_scores, np.int32)])
+    o = map_reads(oi, recs, bases, keyinfo, None, paired, params, cap, want_log, threads, match_stride, jobs_per_read=12)
+    out = dict(log=o["log"], match=o["match"], stats=o["stats"], seconds=o["seconds"])
+    if paired:
+        out.update(sites1=o["sites"][0::2], nsites1=o["nsites"][0::2], sites2=o["sites"][1::2], nsites2=o["nsites"][1::2],
+                   final1=o["final"][0::2], final2=o["final"][1::2], fmatch1=o["fmatch"][0::2], fmatch2=o["fmatch"][1::2])
+    else:
+        out.update(sites1=o["sites"], nsites1=o["nsites"], sites2=None, nsites2=None, final1=o["final"], final2=None,
+                   fmatch1=o["fmatch"], fmatch2=None)
+    return out
 
 
 def map_reads(oi, recs, bases, keyinfo, base_scores=None, paired=False, params=None, cap=64, want_log=True, threads=1,
               match_stride=0, jobs_per_read=8):
     """The general form of map_batch: per-read records (READ_DTYPE: where a read's bases / base scores and its keys are, its
     length and key count; keyinfo holds offsets[nkeys] then keyScores[nkeys] per read), as bbmap_map_batch_device takes them.
-    Returns a dict: sites (n x cap), nsites, log, match, stats, seconds."""
+    Returns a dict: sites (n x cap), nsites, final (FINAL_DTYPE per read: what BBMap prints; zeros when params.finalStage = 0),
+    fmatch (n x fstride: the reads' match strings), log, match, stats, seconds."""
     L_ = oi.L
     p = params or map_default_params(getattr(oi, "profile", "bbmap"))
     rc = np.ascontiguousarray(recs, READ_DTYPE)
@@ -495,16 +497,21 @@ def map_reads(oi, recs, bases, keyinfo, base_scores=None, paired=False, params=N
     match = np.zeros((max(1, logcap), stride), np.uint8) if want_log else None
     nlog = C.c_int64(0)
     stats = np.zeros(4, np.int64)
-    L_.orc_map_reads.restype = C.c_double
-    L_.orc_map_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-    t = L_.orc_map_reads(C.c_void_p(oi.h), C.byref(p), rc.ctypes.data, n, 1 if paired else 0, b.ctypes.data,
-                         None if bs is None else bs.ctypes.data, ki.ctypes.data, cap, sites.ctypes.data, ns.ctypes.data,
-                         log.ctypes.data if want_log else None, logcap, C.addressof(nlog),
-                         match.ctypes.data if want_log else None, stride, threads, stats.ctypes.data)
+    fin = np.zeros(n, FINAL_DTYPE)
+    fstride = int(stride)
+    fmatch = np.zeros((n, fstride), np.uint8)
+    L_.orc_map_reads_final.restype = C.c_double
+    L_.orc_map_reads_final.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int]
+    t = L_.orc_map_reads_final(C.c_void_p(oi.h), C.byref(p), rc.ctypes.data, n, 1 if paired else 0, b.ctypes.data,
+                               None if bs is None else bs.ctypes.data, ki.ctypes.data, cap, sites.ctypes.data, ns.ctypes.data,
+                               log.ctypes.data if want_log else None, logcap, C.addressof(nlog),
+                               match.ctypes.data if want_log else None, stride, threads, stats.ctypes.data,
+                               fin.ctypes.data, fmatch.ctypes.data, fstride)
     if t < 0:
         raise ValueError("orc_map_reads: bad argument (read longer than the MSA's rows, or mates of different length)")
     if want_log and nlog.value > logcap:
         raise RuntimeError("job log overflow")
-    return dict(sites=sites, nsites=ns, log=log[:nlog.value] if want_log else None,
+    return dict(sites=sites, nsites=ns, final=fin, fmatch=fmatch, log=log[:nlog.value] if want_log else None,
                 match=match[:nlog.value] if want_log else None, stats=stats.tolist(), seconds=t)

@@ -4,6 +4,7 @@ import numpy as np
 
 SITE_FIELDS = ("chrom", "strand", "start", "stop", "hits", "quickScore", "score", "slowScore", "pairedScore",
                "perfect", "semiperfect", "rescued", "ngaps")
+FINAL_FIELDS = ("mapped", "chrom", "strand", "start", "stop", "mapScore", "paired", "ambiguous", "perfect", "rescued", "match_len", "nsites")
 GAPPED_BIT = 1 << 30
 
 
@@ -114,4 +115,42 @@ def compare(out, orc, n_reads, paired, reads_range=None, check_match=True):
                 bad.append("read %d site %d differs in %s: device %s, oracle %s" % (
                     r, s, dif, {f: int(g[f]) for f in SITE_FIELDS}, {f: int(o[f]) for f in SITE_FIELDS}))
                 break
+    bad += compare_final(out, orc, rng, paired)
+    return bad
+
+
+def oracle_final(orc, r, paired):
+    """(record, match bytes) of read r in an oracle result (map_reads: interleaved; map_batch: per mate)"""
+    if "final" in orc:
+        f, fm = orc["final"][r], orc["fmatch"][r]
+    elif paired:
+        w = 1 + (r % 2)
+        f, fm = orc["final%d" % w][r // 2], orc["fmatch%d" % w][r // 2]
+    else:
+        f, fm = orc["final1"][r], orc["fmatch1"][r]
+    ml = int(f["match_len"])
+    return f, (fm[:ml].tobytes() if ml <= fm.shape[0] else None)
+
+
+def compare_final(out, orc, rng, paired):
+    """The final alignment stage: what BBMap prints per read (mapped / chrom / strand / start / stop / mapScore / flags) and the match
+    string, device (bbmap_get_final, tier included) against the oracle.  Skipped when either side ran without the stage."""
+    if "final" not in out or not ("final" in orc or "final1" in orc):
+        return []
+    bad = []
+    gfin, blob = out["final"], out["final_match"]
+    for r in rng:
+        o, om = oracle_final(orc, r, paired)
+        g = gfin[r]
+        if int(g["nsites"]) < 0 and int(g["nsites"]) != -3:
+            continue                                        # flagged (overflow): reported with the site lists
+        dif = [f for f in FINAL_FIELDS if int(g[f]) != int(o[f])]
+        if dif:
+            bad.append("read %d final record differs in %s: device %s, oracle %s" % (r, dif, {f: int(g[f]) for f in FINAL_FIELDS}, {f: int(o[f]) for f in FINAL_FIELDS}))
+            continue
+        ml = int(g["match_len"])
+        if ml and om is not None:
+            gm = blob[int(g["match_off"]): int(g["match_off"]) + ml].tobytes()
+            if gm != om:
+                bad.append("read %d match string: device %r, oracle %r" % (r, gm[:300], om[:300]))
     return bad
