@@ -22,7 +22,7 @@ EXPORTS = [
     "bbmap_copy_to_host", "bbidx_get_chrom_table",
     "bbpipe_revcomp_device", "bbpipe_quick_rescue_device",
     "bbidx_build_profile", "bbkeys_default_config", "bbkeys_make", "bbkeys_make_batch", "bbmap_default_config_profile",
-    "bbmap_get_final", "bbmap_set_average_pair_dist",
+    "bbmap_get_final", "bbmap_set_average_pair_dist", "bbmap_final_batch_device",
 ]
 
 

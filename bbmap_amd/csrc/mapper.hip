@@ -1244,6 +1244,7 @@ static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *par
     if (S.finalStage) {
         // match strings of the final stage: one of the read's length per perfect read, about two per imperfect one; grows on demand
         c->poolUnits = (n * (long long)(3 * (cfg->max_read_len + 16)) + 65536) / 4;
+        if (const char *e = getenv("BBMAP_FINAL_POOL_UNITS")) { if (*e && atoll(e) >= 64) c->poolUnits = atoll(e); }      // (tests of the growth path)
         DA(c->d_fin, n); DA(c->d_final, n); DA(c->d_pool, c->poolUnits * 4);
     }
     const int nch = index->dev.nchroms;
@@ -1380,6 +1381,86 @@ static void add_dp_ms(bbmap_ctx *c, bool plain, bool gapped) {
 
 static void tier_start_async(bbmap_ctx *c, long long found);
 
+// The final alignment stage (mapper_final.h) over the site lists in c->d_ms: policy, genMatchString in rounds, policy,
+// toLocalAlignment.  jobBase / gBase: entries of the two fill logs already used (and run).
+static int run_final_stage(bbmap_ctx *c, hipStream_t stream, bbmapper::Dev &D, int64_t n_reads, const uint8_t *bases, long long jobBase, long long gBase,
+                           long long &finalRounds, long long &finalLocal) {
+    const unsigned TB = 128;
+    const long long units = c->cfg.paired ? n_reads / 2 : n_reads;
+    {
+        D.fin = c->d_fin; D.finalOut = c->d_final; D.pool = c->d_pool; D.poolUnits = c->poolUnits;
+        D.match = c->d_match; D.gmatch = c->d_gmatch; D.matchStride = c->matchStride; D.gmatchStride = c->gmatchStride;
+        hipLaunchKernelGGL(bbmapper::final_begin_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, D);
+        MHIP(hipGetLastError());
+        long long nActive = n_reads; bool first = true; int cur = 0;
+        bool ranPlain = false, ranGapped = false;
+        for (int round = 0; nActive > 0; round++) {
+            if (round > 64 * c->cfg.max_sites + 64) return mfail(BBMAP_E_HIP, "bbmap_map_batch_device: the final stage does not come to an end (internal error)");
+            MHIP(hipMemsetAsync(c->d_counters + 2, 0, 4, stream));
+            MHIP(hipMemsetAsync(c->d_counters + 21, 0, 8, stream));
+            D.activeIn = first ? nullptr : c->d_active[cur]; D.nActiveIn = (int)nActive; D.activeOut = c->d_active[1 - cur];
+            hipLaunchKernelGGL(bbmapper::final_round_kernel, dim3((unsigned)((nActive + TB - 1) / TB)), dim3(TB), 0, stream, D);
+            MHIP(hipGetLastError());
+            MTRY(read_counters(c, stream));
+            add_dp_ms(c, ranPlain, ranGapped);
+            const long long asked = c->h_counters[0], gasked = c->h_counters[1];
+            const long long total = asked < c->jobCap ? asked : c->jobCap, gtotal = gasked < c->gjobCap ? gasked : c->gjobCap;
+            MTRY(run_fills(c, stream, bases, jobBase, total - jobBase, gBase, gtotal - gBase));
+            ranPlain = total > jobBase; ranGapped = gtotal > gBase;
+            jobBase = total; gBase = gtotal;
+            if (asked > c->jobCap || gasked > c->gjobCap) {
+                MTRY(grow_logs(c, stream, D, asked, gasked, total, gtotal));
+                D.match = c->d_match; D.gmatch = c->d_gmatch;
+            }
+            if (c->h_counters[22] > 0) {           // the match-string pool was full for some reads: they repeat their step next round
+                long long nu = c->poolUnits * 2, need = (long long)c->h_counters[20] + (long long)c->h_counters[22] * ((long long)c->h_counters[21] + 64);
+                if (nu < need) nu = need + need / 4;
+                if (nu > 0x7ffffff0LL) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: the final stage's match strings exceed 8 GB; map smaller batches");
+                std::vector<void *> dead;
+                MTRY(regrow(c, stream, &c->d_pool, (size_t)c->h_counters[20] * 4, (size_t)nu * 4, dead));
+                MHIP(hipStreamSynchronize(stream));
+                for (void *q : dead) (void)hipFree(q);
+                c->poolUnits = nu; D.pool = c->d_pool; D.poolUnits = nu;
+            }
+            nActive = c->h_counters[2];
+            cur = 1 - cur; first = false;
+            finalRounds++;
+        }
+        MHIP(hipStreamSynchronize(stream));
+        add_dp_ms(c, ranPlain, ranGapped);
+        MHIP(hipMemsetAsync(c->d_counters + 24, 0, 8, stream));
+        hipLaunchKernelGGL(bbmapper::final_end_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, D);
+        MHIP(hipGetLastError());
+        MTRY(read_counters(c, stream));
+        finalLocal = c->h_counters[24];
+        if ((long long)c->h_counters[20] + (long long)c->h_counters[25] + 64 > c->poolUnits) {      // room for toLocalAlignment's strings
+            const long long nu = (long long)c->h_counters[20] + (long long)c->h_counters[25] + 65536;
+            if (nu > 0x7ffffff0LL) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: the final stage's match strings exceed 8 GB; map smaller batches");
+            std::vector<void *> dead;
+            MTRY(regrow(c, stream, &c->d_pool, (size_t)c->h_counters[20] * 4, (size_t)nu * 4, dead));
+            MHIP(hipStreamSynchronize(stream));
+            for (void *q : dead) (void)hipFree(q);
+            c->poolUnits = nu; D.pool = c->d_pool; D.poolUnits = nu;
+        }
+        hipLaunchKernelGGL(bbmapper::final_local_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, D);
+        MHIP(hipGetLastError());
+    }
+    return BBMAP_OK;
+}
+
+
+static void fill_dev(bbmap_ctx *c, bbmapper::Dev &D, int64_t n_reads, const bbidx_read *reads, uint8_t *bases, int64_t minus_delta) {
+    memset(&D, 0, sizeof D);
+    D.S = c->S; D.reads = reads; D.bases = bases; D.minusDelta = minus_delta; D.nreads = n_reads;
+    D.chromArr = c->d_chromArr; D.chromArrLen = c->d_chromArrLen; D.refsBase = c->refsBase;
+    D.psites = c->d_psites; D.pnsites = c->d_pnsites; D.maxSites = c->cfg.max_sites;
+    D.ms = c->d_ms; D.mcount = c->d_mcount; D.cap = c->cfg.max_sites; D.nearArr = c->d_near; D.slow = c->d_slow;
+    D.counters = c->d_counters; D.plainColumns = c->plainColumns; D.fillAhead = c->cfg.reserved[0] ? 0 : 1;
+    D.jobs = c->d_jobs; D.jinfo = c->d_jinfo; D.results = c->d_results; D.jobCap = c->jobCap;
+    D.gjobs = c->d_gjobs; D.ggaps = c->d_ggaps; D.ginfo = c->d_ginfo; D.gresults = c->d_gresults; D.gjobCap = c->gjobCap;
+    D.rjobs = c->d_rjobs; D.rinfo = c->d_rinfo; D.rres = c->d_rres; D.pres = c->d_pres; D.rescCap = c->rescCap; D.rsite = c->d_rsite;
+}
+
 // one context's pass over `n_reads` read records
 static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const bbidx_read *reads, uint8_t *bases,
                        int64_t minus_delta, const int8_t *baseScores, const int32_t *keyinfo, bool writeRc) {
@@ -1391,15 +1472,8 @@ static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const 
     MTRY(bbidx_find_batch_device_rc(c->index, stream, n_reads, reads, bases, baseScores, keyinfo, c->d_psites, c->cfg.max_sites,
                                     c->d_pnsites, writeRc ? bases + minus_delta : nullptr));
     MHIP(hipEventRecord(c->ev[1], stream));
-    bbmapper::Dev D; memset(&D, 0, sizeof D);
-    D.S = c->S; D.reads = reads; D.bases = bases; D.minusDelta = minus_delta; D.nreads = n_reads;
-    D.chromArr = c->d_chromArr; D.chromArrLen = c->d_chromArrLen; D.refsBase = c->refsBase;
-    D.psites = c->d_psites; D.pnsites = c->d_pnsites; D.maxSites = c->cfg.max_sites;
-    D.ms = c->d_ms; D.mcount = c->d_mcount; D.cap = c->cfg.max_sites; D.nearArr = c->d_near; D.slow = c->d_slow;
-    D.counters = c->d_counters; D.plainColumns = c->plainColumns; D.fillAhead = c->cfg.reserved[0] ? 0 : 1;
-    D.jobs = c->d_jobs; D.jinfo = c->d_jinfo; D.results = c->d_results; D.jobCap = c->jobCap;
-    D.gjobs = c->d_gjobs; D.ggaps = c->d_ggaps; D.ginfo = c->d_ginfo; D.gresults = c->d_gresults; D.gjobCap = c->gjobCap;
-    D.rjobs = c->d_rjobs; D.rinfo = c->d_rinfo; D.rres = c->d_rres; D.pres = c->d_pres; D.rescCap = c->rescCap; D.rsite = c->d_rsite;
+    bbmapper::Dev D;
+    fill_dev(c, D, n_reads, reads, bases, minus_delta);
     const unsigned TB = 128;
     const long long units = c->cfg.paired ? n_reads / 2 : n_reads;
     hipLaunchKernelGGL(bbmapper::begin_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, D);
@@ -1487,67 +1561,10 @@ static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const 
         }
     }
     MHIP(hipEventRecord(c->ev[6], stream));
-    // ---- the final alignment stage (mapper_final.h): policy, genMatchString in rounds, policy, toLocalAlignment
+    // ---- the final alignment stage
     c->finalFills = 0; c->poolUsed = 0;
     long long finalRounds = 0, finalLocal = 0;
-    if (c->S.finalStage) {
-        D.fin = c->d_fin; D.finalOut = c->d_final; D.pool = c->d_pool; D.poolUnits = c->poolUnits;
-        D.match = c->d_match; D.gmatch = c->d_gmatch; D.matchStride = c->matchStride; D.gmatchStride = c->gmatchStride;
-        hipLaunchKernelGGL(bbmapper::final_begin_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, D);
-        MHIP(hipGetLastError());
-        nActive = n_reads; first = true; cur = 0;
-        bool ranPlain = false, ranGapped = false;
-        for (int round = 0; nActive > 0; round++) {
-            if (round > 64 * c->cfg.max_sites + 64) return mfail(BBMAP_E_HIP, "bbmap_map_batch_device: the final stage does not come to an end (internal error)");
-            MHIP(hipMemsetAsync(c->d_counters + 2, 0, 4, stream));
-            MHIP(hipMemsetAsync(c->d_counters + 21, 0, 8, stream));
-            D.activeIn = first ? nullptr : c->d_active[cur]; D.nActiveIn = (int)nActive; D.activeOut = c->d_active[1 - cur];
-            hipLaunchKernelGGL(bbmapper::final_round_kernel, dim3((unsigned)((nActive + TB - 1) / TB)), dim3(TB), 0, stream, D);
-            MHIP(hipGetLastError());
-            MTRY(read_counters(c, stream));
-            add_dp_ms(c, ranPlain, ranGapped);
-            const long long asked = c->h_counters[0], gasked = c->h_counters[1];
-            const long long total = asked < c->jobCap ? asked : c->jobCap, gtotal = gasked < c->gjobCap ? gasked : c->gjobCap;
-            MTRY(run_fills(c, stream, bases, jobBase, total - jobBase, gBase, gtotal - gBase));
-            ranPlain = total > jobBase; ranGapped = gtotal > gBase;
-            jobBase = total; gBase = gtotal;
-            if (asked > c->jobCap || gasked > c->gjobCap) {
-                MTRY(grow_logs(c, stream, D, asked, gasked, total, gtotal));
-                D.match = c->d_match; D.gmatch = c->d_gmatch;
-            }
-            if (c->h_counters[22] > 0) {           // the match-string pool was full for some reads: they repeat their step next round
-                long long nu = c->poolUnits * 2, need = (long long)c->h_counters[20] + (long long)c->h_counters[22] * ((long long)c->h_counters[21] + 64);
-                if (nu < need) nu = need + need / 4;
-                if (nu > 0x7ffffff0LL) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: the final stage's match strings exceed 8 GB; map smaller batches");
-                std::vector<void *> dead;
-                MTRY(regrow(c, stream, &c->d_pool, (size_t)c->h_counters[20] * 4, (size_t)nu * 4, dead));
-                MHIP(hipStreamSynchronize(stream));
-                for (void *q : dead) (void)hipFree(q);
-                c->poolUnits = nu; D.pool = c->d_pool; D.poolUnits = nu;
-            }
-            nActive = c->h_counters[2];
-            cur = 1 - cur; first = false;
-            finalRounds++;
-        }
-        MHIP(hipStreamSynchronize(stream));
-        add_dp_ms(c, ranPlain, ranGapped);
-        MHIP(hipMemsetAsync(c->d_counters + 24, 0, 8, stream));
-        hipLaunchKernelGGL(bbmapper::final_end_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, D);
-        MHIP(hipGetLastError());
-        MTRY(read_counters(c, stream));
-        finalLocal = c->h_counters[24];
-        if ((long long)c->h_counters[20] + (long long)c->h_counters[25] + 64 > c->poolUnits) {      // room for toLocalAlignment's strings
-            const long long nu = (long long)c->h_counters[20] + (long long)c->h_counters[25] + 65536;
-            if (nu > 0x7ffffff0LL) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: the final stage's match strings exceed 8 GB; map smaller batches");
-            std::vector<void *> dead;
-            MTRY(regrow(c, stream, &c->d_pool, (size_t)c->h_counters[20] * 4, (size_t)nu * 4, dead));
-            MHIP(hipStreamSynchronize(stream));
-            for (void *q : dead) (void)hipFree(q);
-            c->poolUnits = nu; D.pool = c->d_pool; D.poolUnits = nu;
-        }
-        hipLaunchKernelGGL(bbmapper::final_local_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, D);
-        MHIP(hipGetLastError());
-    }
+    if (c->S.finalStage) MTRY(run_final_stage(c, stream, D, n_reads, bases, jobBase, gBase, finalRounds, finalLocal));
     MHIP(hipEventRecord(c->ev[7], stream));
     MTRY(read_counters(c, stream));
     c->finalFills = c->h_counters[23]; c->poolUsed = 4ll * c->h_counters[20];
@@ -1670,6 +1687,41 @@ extern "C" int bbmap_map_batch_device(bbmap_ctx *c, void *stream_, int64_t n_rea
     MHIP(hipStreamSynchronize(stream));
     (void)hipEventElapsedTime(&c->stats.ms_overflow, e0, e1);      // what the tier added to the batch after the main pass
     c->stats.ms_total += c->stats.ms_overflow;
+    return BBMAP_OK;
+}
+
+// The final alignment stage alone, over site lists the caller provides (see include/bbmap_amd.h).
+extern "C" int bbmap_final_batch_device(bbmap_ctx *c, void *stream_, int64_t n_reads, const bbidx_read *reads, uint8_t *bases, int64_t minus_delta,
+                                        const bbmap_msite *sites, const int32_t *nsites) {
+    if (!c) return mfail(BBMAP_E_ARG, "bbmap_final_batch_device: null context");
+    if (!c->S.finalStage) return mfail(BBMAP_E_ARG, "bbmap_final_batch_device: the context was created without the final stage");
+    if (n_reads < 1 || n_reads > c->cfg.max_reads || (c->cfg.paired && (n_reads & 1))) return mfail(BBMAP_E_ARG, "bbmap_final_batch_device: bad read count");
+    if (!reads || !bases || !sites || !nsites) return mfail(BBMAP_E_ARG, "bbmap_final_batch_device: null buffer");
+    hipStream_t stream = (hipStream_t)stream_;
+    MHIP(hipSetDevice(c->cfg.device));
+    c->tierStarted = false; c->tierReads = 0;
+    if (c->tier) c->tier->ran = false;
+    memset(&c->stats, 0, sizeof c->stats);
+    c->stats.reads = n_reads;
+    MHIP(hipMemsetAsync(c->d_counters, 0, 64 * 4, stream));
+    MHIP(hipMemsetAsync(c->d_slow, 0, sizeof(bbmapper::SlowState) * (size_t)n_reads, stream));      // fills are numbered from 0
+    MHIP(hipMemcpyAsync(c->d_ms, sites, sizeof(bbmap_msite) * (size_t)n_reads * (size_t)c->cfg.max_sites, hipMemcpyDeviceToDevice, stream));
+    MHIP(hipMemcpyAsync(c->d_mcount, nsites, 4 * (size_t)n_reads, hipMemcpyDeviceToDevice, stream));
+    MHIP(hipEventRecord(c->ev[6], stream));
+    bbmapper::Dev D;
+    fill_dev(c, D, n_reads, reads, bases, minus_delta);
+    long long finalRounds = 0, finalLocal = 0;
+    MTRY(run_final_stage(c, stream, D, n_reads, bases, 0, 0, finalRounds, finalLocal));
+    MHIP(hipEventRecord(c->ev[7], stream));
+    MTRY(read_counters(c, stream));
+    c->finalFills = c->h_counters[23]; c->poolUsed = 4ll * c->h_counters[20];
+    c->nJobs = c->h_counters[0]; c->nGapped = c->h_counters[1];
+    bbmap_stats &st = c->stats;
+    st.fills = c->nJobs; st.gapped_fills = c->nGapped;
+    (void)hipEventElapsedTime(&st.ms_final, c->ev[6], c->ev[7]);
+    st.ms_total = st.ms_final;
+    st.final_fills = c->finalFills; st.final_rounds = finalRounds; st.final_local = finalLocal;
+    c->ran = true;
     return BBMAP_OK;
 }
 

@@ -35,7 +35,7 @@ struct FinalRead {
     // genMatchString's state
     int pc;                     // where to resume (PC_*), PC_DONE when the read has finished
     int i;                      // loop index over the sites
-    int best, scoreChanged, sorting, topObj, pairedLost;
+    int best, scoreChanged, sorting, topObj_, pairedLost;
     int oldSlow, oldScoreS;     // the site's scores before its match string was made
     // genMatchStringForSite
     int oldScoreG, gstep;
@@ -51,9 +51,11 @@ enum { PC_DONE = 0, PC_SITE_LOOP, PC_GEN_START, PC_REALIGN_START, PC_EMIT_FILL, 
        PC_GEN_CLIP, PC_SITE_DONE, PC_AFTER_LOOP, PC_SORT_LOOP, PC_FINISH };
 
 #define SITE_MATCH(ss) ((ss).reserved[0])                  // pool reference (offset / 4 + 1), 0 = match == null
-#define SITE_MLEN(ss) ((ss).reserved[1] & 0xffff)          // its length
-#define SITE_OBJ(ss) ((ss).reserved[1] >> 16)              // object identity (the reference compares SiteScore references, :939)
-__device__ inline void site_set_match(Site &ss, int ref, int len) { ss.reserved[0] = ref; ss.reserved[1] = (ss.reserved[1] & ~0xffff) | (len & 0xffff); }
+#define SITE_MLEN(ss) ((ss).reserved[1] & 0x7fffffff)      // its length
+// genMatchString compares SiteScore REFERENCES (`r.topSite()!=top`, :939): the top site is marked before the list is merged and sorted
+// (a merge keeps the first of two equal sites and drops the second, marks included), and looked for afterwards
+#define SITE_TOPMARK 0x80000000u
+__device__ inline void site_set_match(Site &ss, int ref, int len) { ss.reserved[0] = ref; ss.reserved[1] = (int)(((unsigned)ss.reserved[1] & SITE_TOPMARK) | ((unsigned)len & 0x7fffffffu)); }
 
 __device__ inline uint8_t *pool_ptr(const Dev &D, int ref) { return D.pool + 4ll * (ref - 1); }
 // bump allocation in 4-byte units; 0 = the pool is full (nothing changed; the host grows it before the round is repeated)
@@ -367,7 +369,8 @@ __device__ int emit_final_fill(const Dev &D, long long r, const bbidx_read &rr, 
     j.ref_off = (long long)(D.chromArr[ss.chrom] - D.refsBase);
     j.read_len = rr.len; j.ref_len = D.chromArrLen[ss.chrom];
     j.refStartLoc = minLoc; j.refEndLoc = maxLoc; j.minScore = minscore;
-    j.flags = (kind == 6 ? BBMSA_FILL_UNLIMITED_RAW : BBMSA_FILL_LIMITED) | BBMSA_DO_SCORE | BBMSA_DO_TRACEBACK;
+    // (gap symbols stay compact in the log's string: a long deletion's 'D's would not fit its slot; the pool copy expands them)
+    j.flags = (kind == 6 ? BBMSA_FILL_UNLIMITED_RAW : BBMSA_FILL_LIMITED) | BBMSA_DO_SCORE | BBMSA_DO_TRACEBACK | BBMSA_TRACE_KEEP_GAPS;
     if (ss.ngaps || (maxLoc - minLoc + 1) > D.plainColumns) {
         const unsigned k = atomicAdd(&D.counters[1], 1u);
         if ((long long)k >= D.gjobCap) return NO_ROOM;
@@ -517,12 +520,12 @@ __device__ bool can_pair(const Site &a, const Site &b, int len1, int len2, int M
 
 __device__ inline void fin_init(FinalRead &f, int seq) {
     f.mapped = 0; f.paired = 0; f.ambiguous = 0; f.perfect = 0; f.rescued = 0; f.chrom = -1; f.strand = 0; f.start = -1; f.stop = -1; f.mapScore = 0;
-    f.match = 0; f.matchLen = 0; f.pc = PC_DONE; f.i = 0; f.best = INT_MIN; f.scoreChanged = 0; f.sorting = 0; f.topObj = 0; f.pairedLost = 0;
+    f.match = 0; f.matchLen = 0; f.pc = PC_DONE; f.i = 0; f.best = INT_MIN; f.scoreChanged = 0; f.sorting = 0; f.topObj_ = 0; f.pairedLost = 0;
     f.oldSlow = 0; f.oldScoreS = 0; f.oldScoreG = 0; f.gstep = 0; f.recur = 0; f.padding = 0; f.forbidIndels = 0; f.fixXY = 0; f.minValid = 0;
     f.scoreNoIndel = 0; f.minLoc = 0; f.maxLoc = 0; f.old0 = 0; f.epl = 0; f.epr = 0; f.fillKind = 0; f.minscore = 0; f.pending = -1; f.haveMax = 0; f.cols3 = 0;
     f.seq = seq; f.needLocal = 0; f.reservedI = 0;
 }
-__device__ inline void tag_objects(Site *s, int n) { for (int i = 0; i < n; i++) { s[i].reserved[0] = 0; s[i].reserved[1] = (i + 1) << 16; } }
+__device__ inline void tag_objects(Site *s, int n) { for (int i = 0; i < n; i++) { s[i].reserved[0] = 0; s[i].reserved[1] = 0; } }
 __device__ inline void gen_begin(FinalRead &f, int n) {      // genMatchString's entry: `if(USE_SS_MATCH_FOR_PRIMARY && topSite().match!=null)` never holds here
     if (n > 0) { f.pc = PC_SITE_LOOP; f.i = 0; f.best = INT_MIN; f.scoreChanged = 0; f.sorting = 0; }
 }
@@ -690,19 +693,28 @@ __device__ bool final_advance(const Dev &D, long long r, FinalRead &f) {
             }
             if (again) { f.pc = PC_EMIT_FILL; break; }
             if (nsc > 0) {                                                      // max != null: traceback, limits, score (:469-476)
-                int mlen = res.match_len > 0 ? res.match_len : 0;
+                const int clen = res.match_len > 0 ? res.match_len : 0;          // the log's string, gap symbols compact
+                uint8_t *src = const_cast<uint8_t *>(fill_match(D, f.pending));
+                int gsyms = 0;
+                if (ss.ngaps) for (int q = 0; q < clen; q++) gsyms += src[q] == '-';
+                const int mlen = clen + gsyms * (GAPLEN - 1);                    // traceback2 :481-493: each '-' stands for 128 'D'
                 const int ref = pool_alloc(D, mlen);
                 if (!ref) { D.mcount[r] = n; return true; }
-                uint8_t *m = pool_ptr(D, ref);
-                const uint8_t *src = fill_match(D, f.pending);
-                for (int q = 0; q < mlen; q++) m[q] = src[q];
-                if (f.fillKind == 6) {                                           // the stale `columns` of the JNI class (see above)
+                if (f.fillKind == 6 && ss.ngaps == 0) {
+                    // the stale `columns` of the JNI class (see above): an insertion is 'Y' at or beyond the THIRD fill's column count.  Redone
+                    // on the log's string (idempotent); not emulated for gapped references, whose third fill counts gapped columns
                     int col = res.score[1] - f.minLoc;                          // column of the cell before the path's first symbol
-                    if (ss.ngaps == 0) for (int q = 0; q < mlen; q++) {
-                        const uint8_t c = m[q];
-                        if (c == 'I' || c == 'Y') m[q] = (col >= f.cols3) ? 'Y' : 'I';
-                        else if (c != 'X') col++;
+                    for (int q = 0; q < clen; q++) {
+                        const uint8_t c = src[q];
+                        if (c == 'I' || c == 'Y') src[q] = (col >= f.cols3) ? 'Y' : 'I';
+                        else col++;                                              // (leading 'X's: score[1] lies that many columns left of the window)
                     }
+                }
+                uint8_t *m = pool_ptr(D, ref);
+                if (gsyms == 0) for (int q = 0; q < clen; q++) m[q] = src[q];
+                else {
+                    int o = 0;
+                    for (int q = 0; q < clen; q++) { const uint8_t ch = src[q]; if (ch != '-') m[o++] = ch; else for (int g = 0; g < GAPLEN; g++) m[o++] = 'D'; }
                 }
                 site_set_match(ss, ref, mlen);
                 set_limits(ss, res.score[1], res.score[2]);
@@ -779,17 +791,18 @@ __device__ bool final_advance(const Dev &D, long long r, FinalRead &f) {
         case PC_SORT_LOOP: {                                                    // `while(needsSorting)` (:916-943); sorting: 1 = inside, 2 = (re-)enter
             if (f.sorting == 2) {
                 f.sorting = 1;
-                f.topObj = SITE_OBJ(s[0]);
+                s[0].reserved[1] = (int)((unsigned)s[0].reserved[1] | SITE_TOPMARK);             // `final SiteScore top=r.topSite();`
                 n = merge_duplicate_sites_exact(s, n);
                 sort_sites<false>(s, n);
-                if (n > 0 && SITE_MATCH(s[0]) == 0) { f.pc = PC_GEN_START; break; }            // comes back here with sorting = 2
-                if (f.paired && SITE_OBJ(s[0]) != f.topObj) { f.paired = 0; f.pairedLost = 1; }
-                f.sorting = 0; f.pc = PC_FINISH;
-                break;
+                if (n > 0 && SITE_MATCH(s[0]) == 0) { f.pc = PC_GEN_START; break; }            // comes back here with sorting = 1
+                f.sorting = 0;
             }
-            // back from the top site's genMatchStringForSite: needsSorting = true -> the loop body runs again
-            if (f.paired && SITE_OBJ(s[0]) != f.topObj) { f.paired = 0; f.pairedLost = 1; }
-            f.sorting = 2;
+            // `if(r.paired() && r.topSite()!=top)`, after the top site's genMatchStringForSite when it had none
+            const bool sameTop = ((unsigned)s[0].reserved[1] & SITE_TOPMARK) != 0;
+            for (int q = 0; q < n; q++) s[q].reserved[1] = (int)((unsigned)s[q].reserved[1] & ~SITE_TOPMARK);
+            if (f.paired && !sameTop) { f.paired = 0; f.pairedLost = 1; }
+            if (f.sorting == 1) f.sorting = 2;                                   // needsSorting = true: the loop body once more
+            else f.pc = PC_FINISH;
             break;
         }
         case PC_FINISH: {                                                       // :946-959

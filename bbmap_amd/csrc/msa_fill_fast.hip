@@ -629,9 +629,10 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     uint8_t *out = p.match + j * (long long)p.match_stride;
-                    const int total = n + gapSyms * (kGapLen - 1);
+                    const bool keepGaps = (jb.flags & BBMSA_TRACE_KEEP_GAPS) != 0;      // leave each '-' in the string (the caller expands)
+                    const int total = keepGaps ? n : n + gapSyms * (kGapLen - 1);
                     if (total > p.match_stride) matchLen = -1;
-                    else if (gapSyms == 0) {
+                    else if (gapSyms == 0 || keepGaps) {
                         for (int i = gl; i < n; i += G) out[i] = tmp[n - 1 - i];
                         matchLen = n;
                     } else {

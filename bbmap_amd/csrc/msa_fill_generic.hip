@@ -330,11 +330,12 @@ template <class S> __global__ __launch_bounds__(64) void msa_fill_generic_kernel
             }
             if (wantTrace) {
                 if (col != row) { while (row > 0) { if (n < p.match_stride) out[n] = 'X'; else overflow = true; n++; row--; col--; } }
-                const int totalLen = n + gaps * (kGapLen - 1);
+                const bool keepGaps = (jb.flags & BBMSA_TRACE_KEEP_GAPS) != 0;      // leave each '-' in the string (the caller expands)
+                    const int totalLen = keepGaps ? n : n + gaps * (kGapLen - 1);
                 if (overflow || totalLen > p.match_stride) r.match_len = -1;
                 else {
                     for (int i = 0, k = n - 1; i < k; i++, k--) { const uint8_t t0 = out[i]; out[i] = out[k]; out[k] = t0; }
-                    if (gaps > 0) {           // expand '-' to 128 'D' from the back so nothing is overwritten early
+                    if (gaps > 0 && !keepGaps) {           // expand '-' to 128 'D' from the back so nothing is overwritten early
                         int w = totalLen - 1;
                         for (int i = n - 1; i >= 0; i--) {
                             const uint8_t ch = out[i];

@@ -402,11 +402,12 @@ __global__ __launch_bounds__(64, BBMSA_NARROW_OCC) void msa_fill_narrow_kernel(c
                 }
                 if (wantTrace) {
                     if (col != row) { while (row > 0) { if (n < p.match_stride) out[n] = 'X'; else overflow = true; n++; row--; col--; } }
-                    const int totalLen = n + gaps * (kGapLen - 1);
+                    const bool keepGaps = (jb.flags & BBMSA_TRACE_KEEP_GAPS) != 0;      // leave each '-' in the string (the caller expands)
+                    const int totalLen = keepGaps ? n : n + gaps * (kGapLen - 1);
                     if (overflow || totalLen > p.match_stride) r.match_len = -1;
                     else {
                         for (int x = 0, y = n - 1; x < y; x++, y--) { const uint8_t t0 = out[x]; out[x] = out[y]; out[y] = t0; }
-                        if (gaps > 0) {
+                        if (gaps > 0 && !keepGaps) {
                             int w = totalLen - 1;
                             for (int x = n - 1; x >= 0; x--) {
                                 const uint8_t ch = out[x];

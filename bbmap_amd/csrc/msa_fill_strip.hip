@@ -634,9 +634,10 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
                 __builtin_amdgcn_wave_barrier();
                 uint8_t *out = p.match + j * (long long)p.match_stride;
-                const int totalLen = n + gapSyms * (kGapLen - 1);
+                const bool keepGaps = (jb.flags & BBMSA_TRACE_KEEP_GAPS) != 0;          // leave each '-' in the string (the caller expands)
+                const int totalLen = keepGaps ? n : n + gapSyms * (kGapLen - 1);
                 if (totalLen > p.match_stride) matchLen = -1;
-                else if (gapSyms == 0) {
+                else if (gapSyms == 0 || keepGaps) {
                     for (int i = lane; i < n; i += 64) out[i] = ld_agent_u8(tmp + n - 1 - i);
                     matchLen = n;
                 } else {

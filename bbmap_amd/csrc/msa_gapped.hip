@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void make_gref_kernel(const GappedParams P) {
         o.refStartLoc = 0; o.refEndLoc = greflimit;
         // fillLimited(read, ref, a, b, minScore, gaps) (:116-128), or fillUnlimited(read, ref, a, b, gaps) (:166-176: realign_new's last resort)
         o.flags = ((jb.flags & BBMSA_MODE_MASK) == BBMSA_FILL_UNLIMITED_RAW ? BBMSA_FILL_UNLIMITED_RAW : BBMSA_FILL_LIMITED) | BBMSA_DO_SCORE |
-                  (jb.flags & BBMSA_DO_TRACEBACK) | BBMSA_INTERNAL_GAPPED;
+                  (jb.flags & (BBMSA_DO_TRACEBACK | BBMSA_TRACE_KEEP_GAPS)) | BBMSA_INTERNAL_GAPPED;
     }
     if (lane == 0) { aux[0] = origin; aux[1] = greflimit2; aux[2] = bad ? 2 : 0; aux[3] = ngaps; P.out_jobs[j] = o; }
 }

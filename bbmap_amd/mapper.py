@@ -210,6 +210,19 @@ class Mapper:
             _lib.check(self.L.bbmap_get_final(self.h, self.n, fin.ctypes.data, blob.ctypes.data, blob.size, C.byref(nb)), "bbmap_get_final")
         return fin, blob
 
+    def final_only(self, sites, nsites):
+        """bbmap_final_batch_device: the final alignment stage alone over the given site lists (MSITE_DTYPE[n, cap], int32[n]); the
+        reverse complements must be in place (a step() wrote them)."""
+        st = np.ascontiguousarray(sites, MSITE_DTYPE)
+        assert st.shape == (self.n, self.cfg.max_sites)
+        d_sites = torch.from_numpy(st.view(np.uint8).reshape(-1).copy()).to(self.dev)
+        d_ns = torch.from_numpy(np.ascontiguousarray(nsites, np.int32)).to(self.dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.L.bbmap_final_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        self.L.bbmap_final_batch_device.restype = C.c_int
+        _lib.check(self.L.bbmap_final_batch_device(self.h, C.c_void_p(stream), self.n, self.reads.data_ptr(), self.bases.data_ptr(),
+                                                   self.total_bytes, d_sites.data_ptr(), d_ns.data_ptr()), "bbmap_final_batch_device")
+
     def set_average_pair_dist(self, v):
         _lib.check(self.L.bbmap_set_average_pair_dist(self.h, int(v)), "bbmap_set_average_pair_dist")
 

@@ -56,6 +56,9 @@ enum {
                                   /* iterationsLimited, used by the Java side for verbose statistics only): the library may  */
                                   /* then fill with a tighter minScore first and reports iterations = -1 when it did;        */
                                   /* result[], status, score[] and the match string are unchanged                            */
+    BBMSA_TRACE_KEEP_GAPS = 1 << 7, /* traceback: leave each gap symbol '-' of a gapped reference in the match string instead of expanding
+                                    * it to 128 'D' (MultiStateAligner11tsJNI.java:481-493): the string then always fits rows + columns
+                                    * bytes, and the caller expands it (a 16 kb deletion is 125 symbols, 16,000 'D') */
     BBMSA_INTERNAL_GAPPED = 1 << 8 /* set by the library on the jobs it derives for gapped references; never by callers */
 };
 /* the composite the mapper calls most: MSA.fillAndScoreLimited(read, ref, start, stop, minScore, null) */
@@ -602,6 +605,14 @@ int bbmap_set_average_pair_dist(bbmap_ctx *ctx, int32_t average_pair_dist);
 int bbmap_map_batch_device(bbmap_ctx *ctx, void *stream, int64_t n_reads, const bbidx_read *reads, uint8_t *bases,
                            int64_t minus_delta, const int8_t *baseScores, const int32_t *keyinfo);
 int bbmap_get_output(bbmap_ctx *ctx, bbmap_output *out);
+/* The final alignment stage ALONE over site lists the caller provides (a host that runs its own pairing / rescue policy, or a test
+ * that wants lists the mapper would rarely produce): sites = n_reads x cfg.max_sites records, nsites[r] = sites of read r, as
+ * bbmap_map_batch_device leaves them after rescue with finalStage = 0 (sorted as processRead / processReadPair leave them; scores
+ * set).  `bases` holds the plus strands and, at + minus_delta, the reverse complements (the caller's: bbpipe_revcomp_device writes
+ * them).  Results as after bbmap_map_batch_device: bbmap_get_output (the two fill logs hold this call's fills only, numbered from
+ * 0 per read; sites / nsites are the lists after the stage), bbmap_get_final.  No overflow tier is involved. */
+int bbmap_final_batch_device(bbmap_ctx *ctx, void *stream, int64_t n_reads, const bbidx_read *reads, uint8_t *bases, int64_t minus_delta,
+                             const bbmap_msite *sites, const int32_t *nsites);
 /* Host-buffer form, for a host that owns no device memory (the JNI glue, jni/hip_glue.c: Java cannot allocate HBM).  bases holds the
  * plus strands only (bases_bytes bytes, baseScores the same length; both required).  The call uploads the batch into device
  * buffers the context keeps, maps it as bbmap_map_batch_device does and returns the site lists without their empty slots:

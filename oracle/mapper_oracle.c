@@ -905,3 +905,43 @@ double orc_map_batch(const orc_index *ix, const orc_map_params *P, const uint8_t
     free(sites); free(nsites); free(recs); free(bases); free(keyinfo);
     return t;
 }
+
+/* The final alignment stage ALONE over given site lists (the counterpart of bbmap_final_batch_device): sites = n_reads x cap records with
+ * nsites[r] in use, replaced by the lists after the stage; fills are numbered from 0 per read.  Single-threaded. */
+int orc_final_reads(const orc_index *ix, const orc_map_params *P, const orc_read *recs, int64_t n_reads, int paired, const uint8_t *bases,
+                    int cap, orc_msite *sites, int32_t *nsites, orc_mjob *log, int64_t logcap, int64_t *nlog, uint8_t *match, int matchStride,
+                    orc_final *fin, uint8_t *fmatch, int fstride) {
+    if (n_reads < 1 || (paired && (n_reads & 1)) || !sites || !nsites || !fin) return -1;
+    mapper M; memset(&M, 0, sizeof M);
+    volatile int64_t nl = 0;
+    M.ix = ix; M.P = P; M.msa = orc_msa_new(P->msaMaxRows, P->msaMaxColumns);
+    M.tbcap = P->msaMaxRows + P->msaMaxColumns + 64 + 128 * 64; M.tb = (uint8_t *)malloc((size_t)M.tbcap);
+    M.log = log; M.logcap = logcap; M.nlog = &nl; M.match = match; M.matchStride = matchStride;
+    slist *ls[2] = {(slist *)malloc(sizeof(slist)), (slist *)malloc(sizeof(slist))};
+    const int per = paired ? 2 : 1;
+    for (int64_t u = 0; u < n_reads / per; u++) {
+        rstate rs[2]; uint8_t *bm[2] = {NULL, NULL};
+        M.seq[0] = M.seq[1] = 0;
+        for (int w = 0; w < per; w++) {
+            const int64_t r = per * u + w;
+            const int L = recs[r].len;
+            M.readIdx[w] = r;
+            bm[w] = (uint8_t *)malloc((size_t)L + 1);
+            complement_into(bm[w], bases + recs[r].bases_off, L);
+            r_init(&rs[w], bases + recs[r].bases_off, bm[w], L, r);
+            ls[w]->n = nsites[r] > 0 ? nsites[r] : 0;
+            memcpy(ls[w]->s, sites + r * cap, sizeof(orc_msite) * (size_t)ls[w]->n);
+        }
+        if (paired) final_pair(&M, &rs[0], &rs[1], ls[0], ls[1]); else final_single(&M, &rs[0], ls[0]);
+        for (int w = 0; w < per; w++) {
+            const int64_t r = per * u + w;
+            store_final(&M, &rs[w], ls[w], &fin[r], fmatch ? fmatch + r * (int64_t)fstride : NULL, fstride);
+            store_list(ls[w], sites + r * cap, &nsites[r], cap);
+            free(bm[w]);
+        }
+        m_reset(&M);
+    }
+    if (nlog) *nlog = nl;
+    free(ls[0]); free(ls[1]); free(M.tb); free(M.ms); orc_msa_free(M.msa);
+    return 0;
+}

@@ -78,6 +78,9 @@ double orc_map_reads_final(const orc_index *ix, const orc_map_params *P, const o
                            orc_msite *sites, int32_t *nsites,
                            orc_mjob *log, int64_t logcap, int64_t *nlog, uint8_t *match, int matchStride, int threads, int64_t *stats4,
                            orc_final *fin, uint8_t *fmatch, int fstride);
+int orc_final_reads(const orc_index *ix, const orc_map_params *P, const orc_read *recs, int64_t n_reads, int paired, const uint8_t *bases,
+                    int cap, orc_msite *sites, int32_t *nsites, orc_mjob *log, int64_t logcap, int64_t *nlog, uint8_t *match, int matchStride,
+                    orc_final *fin, uint8_t *fmatch, int fstride);
 float orc_ratio_paired(float R);
 float orc_ratio_pre_rescue(float R);
 double orc_map_batch(const orc_index *ix, const orc_map_params *P, const uint8_t *reads1, const uint8_t *reads2, int64_t n, int L,

@@ -515,3 +515,44 @@ def map_reads(oi, recs, bases, keyinfo, base_scores=None, paired=False, params=N
         raise RuntimeError("job log overflow")
     return dict(sites=sites, nsites=ns, final=fin, fmatch=fmatch, log=log[:nlog.value] if want_log else None,
                 match=match[:nlog.value] if want_log else None, stats=stats.tolist(), seconds=t)
+
+
+def final_reads(oi, recs, bases, sites, nsites, paired=False, params=None, match_stride=4200, jobs_per_read=16):
+    """The final alignment stage alone over given site lists (orc_final_reads): sites MSITE_DTYPE[n, cap], nsites int32[n].
+    Returns a dict like map_reads': sites / nsites after the stage, final, fmatch, log, match."""
+    L_ = oi.L
+    p = params or map_default_params(getattr(oi, "profile", "bbmap"))
+    rc = np.ascontiguousarray(recs, READ_DTYPE)
+    n = rc.size
+    b = np.ascontiguousarray(bases, np.uint8)
+    st = np.ascontiguousarray(sites, MSITE_DTYPE).copy()
+    ns = np.ascontiguousarray(nsites, np.int32).copy()
+    cap = st.shape[1]
+    logcap = n * jobs_per_read + 64
+    log = np.zeros(logcap, MJOB_DTYPE)
+    match = np.zeros((logcap, match_stride), np.uint8)
+    nlog = C.c_int64(0)
+    fin = np.zeros(n, FINAL_DTYPE)
+    fmatch = np.zeros((n, match_stride), np.uint8)
+    L_.orc_final_reads.restype = C.c_int
+    L_.orc_final_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    rcode = L_.orc_final_reads(C.c_void_p(oi.h), C.byref(p), rc.ctypes.data, n, 1 if paired else 0, b.ctypes.data, cap, st.ctypes.data,
+                               ns.ctypes.data, log.ctypes.data, logcap, C.addressof(nlog), match.ctypes.data, match_stride,
+                               fin.ctypes.data, fmatch.ctypes.data, match_stride)
+    if rcode != 0:
+        raise ValueError("orc_final_reads: bad argument")
+    if nlog.value > logcap:
+        raise RuntimeError("job log overflow")
+    return dict(sites=st, nsites=ns, final=fin, fmatch=fmatch, log=log[:nlog.value], match=match[:nlog.value])
+
+
+def final_branch_counts(oi, reset=True):
+    """Which of the final stage's rare paths ran since the last reset (see final_stage.inc: g_branch); single-threaded runs only."""
+    out = np.zeros(16, np.int64)
+    oi.L.orc_final_branch_counts.argtypes = [C.c_void_p, C.c_int]
+    oi.L.orc_final_branch_counts.restype = None
+    oi.L.orc_final_branch_counts(out.ctypes.data, 1 if reset else 0)
+    names = ("clip_tip_indels", "fix_xy", "to_local", "to_local_clipped", "realign_recursion", "second_realign", "resort_loop", "do_while_repeat",
+             "later_site_matched", "duplicate_best_removed")
+    return {n: int(out[i]) for i, n in enumerate(names)}

@@ -6,6 +6,7 @@ SITE_FIELDS = ("chrom", "strand", "start", "stop", "hits", "quickScore", "score"
                "perfect", "semiperfect", "rescued", "ngaps")
 FINAL_FIELDS = ("mapped", "chrom", "strand", "start", "stop", "mapScore", "paired", "ambiguous", "perfect", "rescued", "match_len", "nsites")
 GAPPED_BIT = 1 << 30
+TRACE_KEEP_GAPS = 1 << 7
 
 
 def gpu_fills(out):
@@ -20,10 +21,13 @@ def gpu_fills(out):
             assert key not in fills, "two fills with the same (read, seq) %r" % (key,)
             n = int(res["score_len"][i])
             ml = int(res["match_len"][i])
+            mstr = match[i, :ml].tobytes() if (match is not None and n > 0 and ml > 0) else b""
+            if int(jobs["flags"][i]) & TRACE_KEEP_GAPS and ml > 0:      # the final stage's fills keep gap symbols compact in the log
+                mstr = mstr.replace(b"-", b"D" * 128)
+                ml = len(mstr) if match is not None else ml
             fills[key] = dict(kind=int(info["kind"][i]), refStartLoc=int(jobs["refStartLoc"][i]), refEndLoc=int(jobs["refEndLoc"][i]),
                               minScore=int(jobs["minScore"][i]), score=res["score"][i][:n].tolist(), iterations=int(res["iterations"][i]),
-                              match=(match[i, :ml].tobytes() if (match is not None and n > 0 and ml > 0) else b""), index=i | bit,
-                              match_len=ml if n > 0 else 0, stride=int(stride))
+                              match=mstr, index=i | bit, match_len=ml if n > 0 else 0, stride=max(int(stride), ml))
     return fills
 
 
