@@ -1862,8 +1862,11 @@ extern "C" int bbmap_get_final(bbmap_ctx *c, int64_t n_reads, bbmap_final *out, 
     if (match_cap < 0 || (match_cap > 0 && !match_out)) return mfail(BBMAP_E_ARG, "bbmap_get_final: bad match buffer");
     MHIP(hipSetDevice(c->cfg.device));
     MHIP(hipMemcpy(out, c->d_final, (size_t)n_reads * sizeof(bbmap_final), hipMemcpyDeviceToHost));
-    std::vector<uint8_t> pool((size_t)c->poolUsed + 4), tpool;
-    if (c->poolUsed > 0) MHIP(hipMemcpy(pool.data(), c->d_pool, (size_t)c->poolUsed, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> pool, tpool;
+    if (match_out) {
+        pool.resize((size_t)c->poolUsed + 4);
+        if (c->poolUsed > 0) MHIP(hipMemcpy(pool.data(), c->d_pool, (size_t)c->poolUsed, hipMemcpyDeviceToHost));
+    }
     std::vector<uint8_t> fromTier((size_t)n_reads, 0);
     if (c->tier && c->tierReads > 0 && c->tier->ran) {
         bbmap_ctx *t = c->tier;
@@ -1871,8 +1874,10 @@ extern "C" int bbmap_get_final(bbmap_ctx *c, int64_t n_reads, bbmap_final *out, 
         std::vector<bbmap_final> tf((size_t)c->tierReads);
         MHIP(hipMemcpy(ids.data(), c->d_tierReadIds, (size_t)c->tierReads * 4, hipMemcpyDeviceToHost));
         MHIP(hipMemcpy(tf.data(), t->d_final, (size_t)c->tierReads * sizeof(bbmap_final), hipMemcpyDeviceToHost));
-        tpool.resize((size_t)t->poolUsed + 4);
-        if (t->poolUsed > 0) MHIP(hipMemcpy(tpool.data(), t->d_pool, (size_t)t->poolUsed, hipMemcpyDeviceToHost));
+        if (match_out) {
+            tpool.resize((size_t)t->poolUsed + 4);
+            if (t->poolUsed > 0) MHIP(hipMemcpy(tpool.data(), t->d_pool, (size_t)t->poolUsed, hipMemcpyDeviceToHost));
+        }
         for (long long i = 0; i < c->tierReads; i++) {
             const int32_t r = ids[(size_t)i];
             if (r < 0 || r >= n_reads || out[r].nsites != BBMAP_NSITES_IN_TIER) continue;
@@ -1883,9 +1888,11 @@ extern "C" int bbmap_get_final(bbmap_ctx *c, int64_t n_reads, bbmap_final *out, 
     for (int64_t r = 0; r < n_reads; r++) {
         bbmap_final &f = out[r];
         if (f.match_len <= 0) { f.match_off = 0; continue; }
-        const std::vector<uint8_t> &src = fromTier[(size_t)r] ? tpool : pool;
-        if (f.match_off < 0 || f.match_off + f.match_len > (int64_t)src.size()) return mfail(BBMAP_E_HIP, "bbmap_get_final: a match string lies outside its pool (internal error)");
-        if (match_out && used + f.match_len <= match_cap) memcpy(match_out + used, src.data() + f.match_off, (size_t)f.match_len);
+        if (match_out) {
+            const std::vector<uint8_t> &src = fromTier[(size_t)r] ? tpool : pool;
+            if (f.match_off < 0 || f.match_off + f.match_len > (int64_t)src.size()) return mfail(BBMAP_E_HIP, "bbmap_get_final: a match string lies outside its pool (internal error)");
+            if (used + f.match_len <= match_cap) memcpy(match_out + used, src.data() + f.match_off, (size_t)f.match_len);
+        }
         f.match_off = used; used += f.match_len;
     }
     if (match_bytes) *match_bytes = used;

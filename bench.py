@@ -154,8 +154,8 @@ def oracle_index(di, chroms, k):
 
 def cpu_baseline(oi, reads, L, paired, offsets, key_scores, target_seconds=20.0):
     """The same per-read flow on the host cores, from the CPU oracle (oracle/mapper_oracle.c: a port of the reference's
-    logic): probe + pairing + ungapped scores + scoreSlow DP + rescue, one worker thread per usable core sharing one
-    read-only index, on a bounded sample of the same batch."""
+    logic): probe + pairing + ungapped scores + scoreSlow DP + rescue + the final alignment stage (genMatchString -> realign_new,
+    match strings), one worker thread per usable core sharing one read-only index, on a bounded sample of the same batch."""
     from oracle.oracle import map_batch
     cores = usable_cores()
     r = reads.reshape(-1, L)
@@ -171,7 +171,7 @@ def cpu_baseline(oi, reads, L, paired, offsets, key_scores, target_seconds=20.0)
     out = run(count)
     nreads = count * (2 if paired else 1)
     return {"value": nreads / out["seconds"], "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d %s of the same batch through probe + %sungapped scores + scoreSlow DP%s on the CPU oracle "
+            "sample": "first %d %s of the same batch through probe + %sungapped scores + scoreSlow DP%s + final alignment stage (realign_new fills, match strings) on the CPU oracle "
                       "(index arrays shared with the device build), %d threads, %.1f s; %d fills, %d visited cells, %d rescue scans, "
                       "%d reads with a site" % (count, "pairs" if paired else "reads", "pairing + " if paired else "",
                                                 " + rescue" if paired else "", cores, out["seconds"], out["stats"][0], out["stats"][1],
@@ -214,8 +214,8 @@ def _hip_copy(dst, src, nbytes, kind, stream):
 def streaming_region(mp, batches, steps, warmup):
     """The same step with a DIFFERENT batch every time and the PCIe traffic a host would have inside the timed region: batch
     i + 1 is uploaded (pinned host memory, second stream) while batch i is mapped, and batch i's results -- the site lists without
-    their empty slots (bbmap_pack_sites_device), the per-read counts and both fill logs with their traceback strings -- are copied
-    to pinned host memory while batch i + 1 is mapped.  Returns (seconds for `steps` steps, bytes up per step, bytes down per step)."""
+    their empty slots (bbmap_pack_sites_device), the per-read counts, both fill logs with their traceback strings, the final records
+    and their match strings -- are copied to pinned host memory while batch i + 1 is mapped.  Returns (seconds for `steps` steps, bytes up per step, bytes down per step)."""
     import torch
     dev, n, total = mp.dev, mp.n, mp.total_bytes
     pin_in = [torch.from_numpy(np.ascontiguousarray(b).reshape(-1)).pin_memory() for b in batches]
@@ -229,7 +229,8 @@ def streaming_region(mp, batches, steps, warmup):
     o = mp.output_pointers()
     job_cap, gjob_cap = int(o.n_jobs * 1.3) + 4096, int(o.n_gapped_jobs * 1.5) + 4096
     per_job, per_gjob = 40 + 80 + 16 + o.match_stride, 40 + 80 + 16 + 68 + o.gmatch_stride
-    stage = [torch.zeros(job_cap * per_job + gjob_cap * per_gjob, dtype=torch.uint8, device=dev) for _ in range(2)]
+    final_cap = (n * 64 + int(o.final_match_bytes * 1.3) + 65536) if o.final else 0
+    stage = [torch.zeros(job_cap * per_job + gjob_cap * per_gjob + final_cap, dtype=torch.uint8, device=dev) for _ in range(2)]
     host_out = [torch.zeros(4 * (n + 1) + cap_rec * 128 + stage[0].numel(), dtype=torch.uint8).pin_memory() for _ in range(2)]
     main = torch.cuda.current_stream()
     copy = torch.cuda.Stream(device=dev)
@@ -260,6 +261,10 @@ def streaming_region(mp, batches, steps, warmup):
         # the logs live in the mapper's buffers, which the next step overwrites: staged device to device, then sent from the stage
         pieces = [(o.jobs, nj * 40), (o.results, nj * 80), (o.jobinfo, nj * 16), (o.match, nj * o.match_stride),
                   (o.gjobs, ng * 40), (o.gresults, ng * 80), (o.gjobinfo, ng * 16), (o.ggaps, ng * 68), (o.gmatch, ng * o.gmatch_stride)]
+        if o.final:                                                # the final records (what BBMap prints) and their match strings
+            if n * 64 + int(o.final_match_bytes) > final_cap:
+                raise RuntimeError("streaming_region: final staging buffer too small")
+            pieces += [(o.final, n * 64), (o.final_match, int(o.final_match_bytes))]
         off = 0
         for ptr, nb in pieces:
             _hip_copy(stage[s].data_ptr() + off, ptr, nb, 3, main.cuda_stream)
@@ -686,6 +691,13 @@ def main():
     if tier is not None:                                    # reads the overflow tier mapped (nsites == -3 in the main list)
         mapped += int(((tier["nsites"] > 0) & (tier["sites"][:, 0]["slowScore"] >= minScore)).sum())
         cells += int(tier["results"]["iterations"].sum() + tier["gresults"]["iterations"].sum())
+    fin = out.get("final")
+    final_info = None
+    if fin is not None:                                     # the final records: what BBMap would print
+        mapped = int((fin["mapped"] > 0).sum())
+        final_info = {"mapped": mapped, "paired": int((fin["paired"] > 0).sum()), "ambiguous": int((fin["ambiguous"] > 0).sum()),
+                      "perfect": int((fin["perfect"] > 0).sum()), "rescued": int(((fin["mapped"] > 0) & (fin["rescued"] > 0)).sum()),
+                      "match_string_bytes": int(fin["match_len"].sum())}
     parity = None
     if rank == 0 and args.parity_sample > 0:
         parity = parity_sample(mp, out, oi, reads, L, paired, offsets, key_scores, min(n, args.parity_sample))
@@ -714,9 +726,9 @@ def main():
         topd = od["sites"][:, 0]
         default_res = {"value": n * world * args.default_set_steps / d_el, "unit": "reads/s", "steps": args.default_set_steps,
                        "ms_per_step": 1e3 * d_el / args.default_set_steps,
-                       "mapped_fraction": float(((od["nsites"] > 0) & (topd["slowScore"] >= minScore)).mean()),
+                       "mapped_fraction": float((od["final"]["mapped"] > 0).mean()) if "final" in od else float(((od["nsites"] > 0) & (topd["slowScore"] >= minScore)).mean()),
                        "perfect_fraction": float(((od["nsites"] > 0) & (topd["perfect"] != 0)).mean()),
-                       "fills_per_step": int(std["fills"] + std["gapped_fills"]), "rescue_scans_per_step": int(std["rescue_scans"]),
+                       "fills_per_step": int(std["fills"] + std["gapped_fills"]), "final_fills_per_step": int(std["final_fills"]), "rescue_scans_per_step": int(std["rescue_scans"]),
                        "stage_ms": {key[3:]: round(float(v), 3) for key, v in std.items() if key.startswith("ms_")},
                        "what": "same reference and batch size, reads as sh/randomreads.sh makes them by default (every mutation rate 0; "
                                "seed 6); stage_ms of the last step"}
@@ -762,7 +774,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "%s; k=%d index built on the device, resident in HBM; %d x %d-bp %s per GPU and step (seed 4, "
                                    "mutated mix with deletions of 1..400 bases, 3 %% hard mates); per step: index probe (BBIndex.findAdvanced) -> %sungapped scores -> "
-                                   "scoreSlow DP + traceback in rounds%s" % (
+                                   "scoreSlow DP + traceback in rounds%s -> final alignment stage (final pairing, ambiguity policy, genMatchString -> realign_new DP in rounds, "
+                                   "clipping, penalties: the printed start / stop / score and match string of every read)" % (
                                        desc, k, n // 2 if paired else n, L, "read pairs (2 x 150, opposite strands, insert 200-400)" if paired
                                        else "single-ended reads", "mate pairing + list trimming -> " if paired else "list trimming -> ",
                                        (" -> rescue (quickRescue scan + slowRescue DP) for unpaired mates" if paired else "") +
@@ -771,12 +784,14 @@ def main():
                                        "100) and the 'mating is not working' switch that turns pairing off after many unpaired reads"),
                        "reads_per_gpu_per_step": n, "read_len": L, "paired": paired, "keys_per_read": nkeys, "max_sites": args.max_sites,
                        "fills_per_step": st["fills"] + st["gapped_fills"], "fills_second_context": st["gapped_fills"],
+                       "final_fills_per_step": st["final_fills"], "final_rounds": st["final_rounds"], "final_reads_through_local_alignment": st["final_local"],
+                       "final_records": final_info,
                        "refills_per_step": st["refills"], "scoreslow_rounds": st["rounds"], "fills_ahead_dropped_per_step": st["fills_dropped"],
                        "rescue_scans_per_step": st["rescue_scans"], "rescue_fills_per_step": st["rescue_fills"],
                        "reads_remapped_by_overflow_tier": st["reads_reprobed"], "reads_left_unmapped_by_overflow": st["reads_overflowed"], "reads_without_site": st["reads_without_site"],
                        "mapped_fraction": mapped / n, "dp_cells_per_step": cells,
                        # (the two DP contexts run side by side, so their kernel times overlap: the rate is over the two stages' wall time)
-                       "dp_gcups_over_scoreslow_and_rescue_stages": (cells / ((ms["ms_slow"] + ms["ms_rescue"]) * 1e-3) / 1e9) if cells else 0.0,
+                       "dp_gcups_over_scoreslow_rescue_and_final_stages": (cells / ((ms["ms_slow"] + ms["ms_rescue"] + ms.get("ms_final", 0.0)) * 1e-3) / 1e9) if cells else 0.0,
                        "probe_list_entries_per_step": int(ps[0] + ps[1]), "probe_extend_calls_per_step": int(ps[2]),
                        "stage_ms": {key[3:]: round(v, 3) for key, v in ms.items()},
                        "index_build_s_gpu": t_ix, "parity": parity},

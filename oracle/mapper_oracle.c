@@ -755,7 +755,11 @@ void orc_map_default_params(orc_map_params *P) {
     memset(P, 0, sizeof *P);
     P->maxPairDist = 32000; P->averagePairDist = 100; P->maxRescueDist = 1200; P->maxRescueMismatches = 32;
     P->maxTrimSitesToRetain = 800; P->trimList = 1; P->doRescue = 1; P->clearzone3 = 800; P->extraPadding = 10;
+#ifdef ORC_PACBIO   /* the final stage is restated for BBMapThread only (BBMapThreadPacBio's tail differs: clearzone rule, applyClearzone3 call) */
+    P->finalStage = 0;
+#else
     P->finalStage = 1;
+#endif
 #ifdef ORC_PACBIO   /* BBMapPacBio.setDefaults (BBMapPacBio.java:47-69), BBMapThreadPacBio.java:27-28, BBIndexPacBio.java:2462 */
     P->minRatio = 0.46f; P->slowAlignPadding = 8; P->slowRescuePadding = 16; P->tipSearchDist = 15;
     P->alignColumns = 7600; P->msaMaxRows = 6020; P->msaMaxColumns = 7600;

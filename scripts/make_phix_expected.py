@@ -1,7 +1,8 @@
 """Writes tests/golden/phix_expected.json: what the CPU oracle returns for the reference's PhiX fixture (tests/golden/*.gz, copied
-from the reference's resources/), read by read -- the top site of every read in six runs (sample1 / sample2 single-ended and the
-pairs, each with keys placed from the qualities and as for quality-less input) and the score of the fill against each read's
-TRUTH window (the coordinates in its name +- SLOW_ALIGN_PADDING).  tests/test_golden_phix.py asserts the oracle (and, on the GPU,
+from the reference's resources/), read by read -- in six runs (sample1 / sample2 single-ended and the pairs, each with keys placed
+from the qualities and as for quality-less input): "runs" = the top site of every read when the flow stops after the rescue stage
+(finalStage = 0), "final" = the record BBMap prints after the final alignment stage (mapped, strand, start, stop, mapScore, paired,
+ambiguous, match string), and the score of the fill against each read's TRUTH window (the coordinates in its name +- SLOW_ALIGN_PADDING).  tests/test_golden_phix.py asserts the oracle (and, on the GPU,
 the device mapper) against this table field by field, so that a change that moves a single read shows.  The table is the
 restatement's output pinned at the commit that wrote it -- not output of the reference (no JVM in this image).
 Run from the repository root: python scripts/make_phix_expected.py"""
@@ -13,9 +14,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.golden_phix import fixture_runs, truth_window_scores      # noqa: E402
 
 if __name__ == "__main__":
-    table = {"runs": {}, "truth_window": {}}
+    table = {"runs": {}, "final": {}, "truth_window": {}}
     for name, run in fixture_runs().items():
-        out = run["oracle"]()
+        fin = run["oracle"]()
+        f = fin["final"]
+        table["final"][name] = [[int(f["mapped"][i]), int(f["strand"][i]), int(f["start"][i]), int(f["stop"][i]), int(f["mapScore"][i]),
+                                 int(f["paired"][i]), int(f["ambiguous"][i]), fin["fmatch"][i][:f["match_len"][i]].tobytes().decode()]
+                                for i in range(len(f))]
+        out = run["oracle"](final_stage=0)
         top = out["sites"][:, 0]
         table["runs"][name] = [[int(out["nsites"][i]), int(top["strand"][i]), int(top["start"][i]), int(top["stop"][i]), int(top["slowScore"][i])]
                                if out["nsites"][i] > 0 else [int(out["nsites"][i]), 0, 0, 0, 0] for i in range(len(top))]

@@ -97,10 +97,10 @@ def fixture_runs():
             reads, quals, paired = fixture_inputs(mode, use_q)
             recs, blob, bs, ki = K.make_batch(reads, quals)
 
-            def oracle(recs=recs, blob=blob, bs=bs, ki=ki, paired=paired):
+            def oracle(recs=recs, blob=blob, bs=bs, ki=ki, paired=paired, final_stage=1):
                 oi = O.OracleIndex([ref], k=13)
                 oi.s.p.quitAfterTwoPerfects = 0 if paired else 1            # BBMap.java:434
-                return O.map_reads(oi, recs, blob, ki, base_scores=bs, paired=paired, cap=64)
+                return O.map_reads(oi, recs, blob, ki, base_scores=bs, paired=paired, cap=64, params=O.map_default_params(finalStage=final_stage))
             runs["%s_%s" % (mode, "qual" if use_q else "noqual")] = {"inputs": (recs, blob, bs, ki, paired), "oracle": oracle}
     return runs
 

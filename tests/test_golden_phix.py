@@ -6,7 +6,10 @@ for quality-less input.
 
 What is pinned, and by what:
  * END RESULT vs the fixture's truth (reference-held): the reference's own two correctness rules (AbstractMapThread.isCorrectHit /
-   isCorrectHitLoose, current/align2/AbstractMapThread.java:2692-2717, thresh 0) as floors;
+   isCorrectHitLoose, current/align2/AbstractMapThread.java:2692-2717, thresh 0) as floors -- applied, as the reference applies them
+   (calcStatistics1 at the end of processRead), to the FINAL records: the coordinates after genMatchString -> realign_new,
+   clipTipIndels, the ambiguity policy and the minimum-score cut (FLOORS_FINAL); and, for the stage-by-stage view, to the site lists
+   as scoreSlow and rescue leave them (finalStage = 0; FLOORS);
  * the TRUTH-WINDOW property (reference-held truth + the DP): the fill scoreSlow would issue for a site at exactly the coordinates
    in a read's name never scores above what the mapper found for that read -- a mapper may beat the generator's placement, never
    lose to it (a wrong tie-break or window in the flow would show here);
@@ -28,6 +31,19 @@ FLOORS = {      # (mapped, strict, loose) of a sample's 100 reads, as the restat
     ("se", 1): (99, 86, 98), ("se", 2): (98, 79, 95),       # mapped on their own (sample2 with quality-placed keys: 95 loose, 96 without)
     ("pe", 1): (99, 86, 98), ("pe", 2): (98, 82, 98),       # as pairs (rescue brings three of sample2's reads home)
 }
+FLOORS_FINAL = {  # the same on the records BBMap prints.  Lower than FLOORS where a read's best site ends below MINIMUM_ALIGNMENT_SCORE_RATIO
+                  # (`r.mapScore<maxSwScore*MINIMUM_ALIGNMENT_SCORE_RATIO -> clearMapping`, BBMapThread.java:697-699) and is reported unmapped
+    ("se", 1): (94, 83, 93), ("se", 2): (91, 78, 91),
+    ("pe", 1): (98, 85, 97), ("pe", 2): (94, 78, 94),
+}
+
+
+def _final_against_truth(fin, truth):
+    mapped = fin["mapped"] > 0
+    same = mapped & (fin["chrom"] == 1) & (fin["strand"] == truth["strand"])
+    strict = same & (fin["start"] == truth["start"]) & (fin["stop"] == truth["stop"])
+    loose = same & ((fin["start"] == truth["start"]) | (fin["stop"] == truth["stop"]))
+    return int(mapped.sum()), int(strict.sum()), int(loose.sum())
 
 
 def _score_against_truth(sites, nsites, truth):
@@ -50,7 +66,8 @@ def _split(name, out):
 def runs():
     r = fixture_runs()
     for v in r.values():
-        v["out"] = v["oracle"]()
+        v["out"] = v["oracle"](final_stage=0)          # the lists as scoreSlow and rescue leave them
+        v["final"] = v["oracle"]()                     # the whole of processRead / processReadPair
     return r
 
 
@@ -65,6 +82,27 @@ def _check_truth(name, out):
         got = _score_against_truth(sites, nsites, truth)
         floor = FLOORS[(name[:2], which)]
         assert all(g >= f for g, f in zip(got, floor)), (name, which, got, floor)
+
+
+def _check_final(name, out, expected, check_truth=True):
+    """the final records: floors against the truth (isCorrectHit on what BBMap prints) and the per-read table, match strings included"""
+    fin, blob = out["final"], out.get("final_match")
+    if check_truth:
+        for which in ((1, 2) if name.startswith("pe") else (int(name[2]),)):
+            f = fin[which - 1::2] if name.startswith("pe") else fin
+            _, truth = sample_reads(which)
+            got = _final_against_truth(f, truth)
+            floor = FLOORS_FINAL[(name[:2], which)]
+            assert all(g >= fl for g, fl in zip(got, floor)), (name, which, got, floor)
+    for i, exp in enumerate(expected["final"][name]):
+        f = fin[i]
+        ml = int(f["match_len"])
+        if blob is not None:                           # device: (records, packed strings)
+            m = blob[int(f["match_off"]): int(f["match_off"]) + ml].tobytes().decode()
+        else:
+            m = out["fmatch"][i][:ml].tobytes().decode()
+        got = [int(f["mapped"]), int(f["strand"]), int(f["start"]), int(f["stop"]), int(f["mapScore"]), int(f["paired"]), int(f["ambiguous"]), m]
+        assert got == exp, "%s read %d final record: %s, table %s" % (name, i, got, exp)
 
 
 def _check_table(name, out, expected):
@@ -116,6 +154,31 @@ def test_oracle_meets_the_fixture_truth_in_all_six_runs(runs):
 def test_oracle_equals_the_per_read_table(runs, expected):
     for name, r in runs.items():
         _check_table(name, r["out"], expected)
+        _check_final(name, r["final"], expected)
+
+
+def test_final_records_on_the_fixture(runs):
+    """What the final alignment stage does to the fixture's reads, stated as numbers: it never moves a strict hit away from the truth,
+    every mapped read's match string spans exactly [start, stop] and consumes exactly the read, and the reads it reports unmapped are
+    those whose best alignment stays below MINIMUM_ALIGNMENT_SCORE_RATIO."""
+    min_score = int(np.float32(0.56) * np.float32(70 + 99 * 100))
+    for name, r in runs.items():
+        pre, fin = r["out"], r["final"]["final"]
+        for which, (sites, nsites) in _split(name, pre).items():
+            f = fin[which - 1::2] if name.startswith("pe") else fin
+            fm = r["final"]["fmatch"][which - 1::2] if name.startswith("pe") else r["final"]["fmatch"]
+            _, truth = sample_reads(which)
+            top = sites[:, 0]
+            for i in range(100):
+                was_strict = nsites[i] > 0 and top["strand"][i] == truth["strand"][i] and top["start"][i] == truth["start"][i] and top["stop"][i] == truth["stop"][i]
+                if f["mapped"][i]:
+                    m = fm[i][:f["match_len"][i]].tobytes()
+                    assert sum(m.count(c) for c in b"mSNIXYC") == 100
+                    assert sum(m.count(c) for c in b"mSNDXYC") == f["stop"][i] - f["start"][i] + 1
+                    if was_strict and not name.startswith("pe"):
+                        assert (f["start"][i], f["stop"][i]) == (truth["start"][i], truth["stop"][i]), (name, which, i)
+                elif nsites[i] > 0 and not name.startswith("pe"):
+                    assert top["slowScore"][i] < min_score + 300, (name, which, i, int(top["slowScore"][i]))
 
 
 def test_mapper_never_loses_to_the_truth_window(runs, expected):
@@ -145,7 +208,7 @@ def test_device_mapper_equals_oracle_on_the_fixture(runs, expected):
     tw = expected["truth_window"]
     for name, r in runs.items():
         recs, blob, bs, ki, paired = r["inputs"]
-        mp = Mapper.from_records(di, recs, blob, bs, ki, paired=paired, max_sites=32)
+        mp = Mapper.from_records(di, recs, blob, bs, ki, paired=paired, max_sites=32, finalStage=0)
         mp.step()
         out, st = mp.fetch(), mp.stats()
         mp.close()
@@ -155,6 +218,15 @@ def test_device_mapper_equals_oracle_on_the_fixture(runs, expected):
         _check_truth(name, out)
         _check_table(name, out, expected)
         _check_truth_window(name, out, tw)
+        # the whole flow: final records and match strings equal the oracle's, hence the table's and the floors on what BBMap prints
+        mp = Mapper.from_records(di, recs, blob, bs, ki, paired=paired, max_sites=32)
+        mp.step()
+        out, st = mp.fetch(), mp.stats()
+        mp.close()
+        assert st["final_fills"] > 50
+        bad = compare(out, r["final"], len(recs), paired)
+        assert not bad, name + " (final stage)\n" + "\n".join(bad[:20])
+        _check_final(name, out, expected)
     di.close()
     msa = M.MultiStateAligner11ts(maxRows=601, maxColumns=3000)
     for which in (1, 2):
