@@ -102,8 +102,8 @@ struct Dev {
     struct FinalRead *fin; bbmap_final *finalOut;
     uint8_t *pool; long long poolUnits;         // match strings: bump-allocated in 4-byte units, counters[20] = units in use
     const uint8_t *match, *gmatch; int matchStride, gmatchStride;
-                                // counters: [20] pool units in use, [21] largest allocation that failed, [22] allocations that failed, [23] final-stage
-                                // fills, [24] reads that need toLocalAlignment, [25] pool units those may take
+                                // counters: [20] pool units handed out (beyond the capacity once a request failed), [21] units in use when the first
+                                // request failed, [22] requests that failed, [24] reads that need toLocalAlignment, [25] pool units those may take
 };
 
 __device__ inline int imin(int a, int b) { return a < b ? a : b; }
@@ -1397,7 +1397,8 @@ static int run_final_stage(bbmap_ctx *c, hipStream_t stream, bbmapper::Dev &D, i
         for (int round = 0; nActive > 0; round++) {
             if (round > 64 * c->cfg.max_sites + 64) return mfail(BBMAP_E_HIP, "bbmap_map_batch_device: the final stage does not come to an end (internal error)");
             MHIP(hipMemsetAsync(c->d_counters + 2, 0, 4, stream));
-            MHIP(hipMemsetAsync(c->d_counters + 21, 0, 8, stream));
+            MHIP(hipMemsetAsync(c->d_counters + 21, 0xff, 4, stream));
+            MHIP(hipMemsetAsync(c->d_counters + 22, 0, 4, stream));
             D.activeIn = first ? nullptr : c->d_active[cur]; D.nActiveIn = (int)nActive; D.activeOut = c->d_active[1 - cur];
             hipLaunchKernelGGL(bbmapper::final_round_kernel, dim3((unsigned)((nActive + TB - 1) / TB)), dim3(TB), 0, stream, D);
             MHIP(hipGetLastError());
@@ -1413,11 +1414,14 @@ static int run_final_stage(bbmap_ctx *c, hipStream_t stream, bbmapper::Dev &D, i
                 D.match = c->d_match; D.gmatch = c->d_gmatch;
             }
             if (c->h_counters[22] > 0) {           // the match-string pool was full for some reads: they repeat their step next round
-                long long nu = c->poolUnits * 2, need = (long long)c->h_counters[20] + (long long)c->h_counters[22] * ((long long)c->h_counters[21] + 64);
-                if (nu < need) nu = need + need / 4;
+                const long long used = c->h_counters[21];                      // units handed out before the first request that failed
+                long long nu = c->poolUnits * 2, need = used + ((long long)c->h_counters[20] - used) * 2 + 65536;
+                if (nu < need) nu = need;
                 if (nu > 0x7ffffff0LL) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: the final stage's match strings exceed 8 GB; map smaller batches");
                 std::vector<void *> dead;
-                MTRY(regrow(c, stream, &c->d_pool, (size_t)c->h_counters[20] * 4, (size_t)nu * 4, dead));
+                MTRY(regrow(c, stream, &c->d_pool, (size_t)used * 4, (size_t)nu * 4, dead));
+                c->h_counters[34] = (unsigned)used;
+                MHIP(hipMemcpyAsync(c->d_counters + 20, c->h_counters + 34, 4, hipMemcpyHostToDevice, stream));
                 MHIP(hipStreamSynchronize(stream));
                 for (void *q : dead) (void)hipFree(q);
                 c->poolUnits = nu; D.pool = c->d_pool; D.poolUnits = nu;
@@ -1567,8 +1571,9 @@ static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const 
     if (c->S.finalStage) MTRY(run_final_stage(c, stream, D, n_reads, bases, jobBase, gBase, finalRounds, finalLocal));
     MHIP(hipEventRecord(c->ev[7], stream));
     MTRY(read_counters(c, stream));
-    c->finalFills = c->h_counters[23]; c->poolUsed = 4ll * c->h_counters[20];
+    c->poolUsed = 4ll * c->h_counters[20];
     c->nJobs = c->h_counters[0]; c->nGapped = c->h_counters[1];
+    c->finalFills = c->S.finalStage ? (c->nJobs + c->nGapped) - (jobBase + gBase) : 0;       // (jobBase / gBase: the logs before the final stage)
     bbmap_stats &st = c->stats;
     st.reads_overflowed = c->h_counters[3]; st.reads_without_site = c->h_counters[5];
     st.fills = c->nJobs; st.gapped_fills = c->nGapped; st.refills = c->h_counters[6]; st.rescue_fills = c->h_counters[7]; st.fills_dropped = c->h_counters[8];
@@ -1714,8 +1719,9 @@ extern "C" int bbmap_final_batch_device(bbmap_ctx *c, void *stream_, int64_t n_r
     MTRY(run_final_stage(c, stream, D, n_reads, bases, 0, 0, finalRounds, finalLocal));
     MHIP(hipEventRecord(c->ev[7], stream));
     MTRY(read_counters(c, stream));
-    c->finalFills = c->h_counters[23]; c->poolUsed = 4ll * c->h_counters[20];
+    c->poolUsed = 4ll * c->h_counters[20];
     c->nJobs = c->h_counters[0]; c->nGapped = c->h_counters[1];
+    c->finalFills = c->nJobs + c->nGapped;
     bbmap_stats &st = c->stats;
     st.fills = c->nJobs; st.gapped_fills = c->nGapped;
     (void)hipEventElapsedTime(&st.ms_final, c->ev[6], c->ev[7]);

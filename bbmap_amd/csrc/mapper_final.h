@@ -58,16 +58,22 @@ enum { PC_DONE = 0, PC_SITE_LOOP, PC_GEN_START, PC_REALIGN_START, PC_EMIT_FILL, 
 __device__ inline void site_set_match(Site &ss, int ref, int len) { ss.reserved[0] = ref; ss.reserved[1] = (int)(((unsigned)ss.reserved[1] & SITE_TOPMARK) | ((unsigned)len & 0x7fffffffu)); }
 
 __device__ inline uint8_t *pool_ptr(const Dev &D, int ref) { return D.pool + 4ll * (ref - 1); }
-// bump allocation in 4-byte units; 0 = the pool is full (nothing changed; the host grows it before the round is repeated)
-__device__ int pool_alloc(const Dev &D, int bytes) {
-    const unsigned units = (unsigned)((bytes + 3) >> 2) + 1u;
-    unsigned old = *(volatile unsigned *)&D.counters[20];
-    for (;;) {
-        if ((long long)old + units > D.poolUnits) { atomicMax(&D.counters[21], units); atomicAdd(&D.counters[22], 1u); return 0; }
-        const unsigned seen = atomicCAS(&D.counters[20], old, old + units);
-        if (seen == old) return (int)old + 1;
-        old = seen;
-    }
+// Bump allocation in 4-byte units; 0 = the pool is full (nothing changed; the host grows it before the round is repeated).  One
+// atomicAdd, no compare-and-swap loop (a million threads retrying on one word took seconds): a request that does not fit leaves the
+// counter beyond the capacity, so every later request of the round fails too, the strings handed out so far are exactly
+// [0, smallest `old` of a failed request), and the host sets the counter back to that before the next round (counters[21]).
+__device__ int pool_alloc_units(const Dev &D, unsigned units) {
+    const unsigned old = atomicAdd(&D.counters[20], units);
+    if ((long long)old + units > D.poolUnits) { atomicMin(&D.counters[21], old); atomicAdd(&D.counters[22], 1u); return 0; }
+    return (int)old + 1;
+}
+__device__ inline unsigned pool_units(int bytes) { return (unsigned)((bytes + 3) >> 2) + 1u; }
+__device__ inline int pool_alloc(const Dev &D, int bytes) { return pool_alloc_units(D, pool_units(bytes)); }
+// a round's first request of every read is made for the whole wavefront at once (final_round_kernel); the read takes it here
+struct PreAlloc { int ref; unsigned units; };
+__device__ inline int pool_take(const Dev &D, PreAlloc &pre, int bytes) {
+    if (pre.ref && pre.units >= pool_units(bytes)) { const int ref = pre.ref; pre.ref = 0; return ref; }
+    return pool_alloc(D, bytes);
 }
 
 __device__ inline uint8_t ca_get(const Dev &D, int chrom, int loc) {           // ChromosomeArray.get (current/dna/ChromosomeArray.java:232-234)
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(128) void final_begin_kernel(const Dev D) {
 
 // ---------------------------------------------------------------------------------------------- kernel 2: one round of genMatchString
 // Advances a read until it needs a fill (returns true: still active) or has finished genMatchString (PC_DONE).
-__device__ bool final_advance(const Dev &D, long long r, FinalRead &f) {
+__device__ bool final_advance(const Dev &D, long long r, FinalRead &f, PreAlloc &pre) {
     const Settings &S = D.S;
     const bbidx_read rr = D.reads[r];
     const int L = rr.len, maxSw = max_quality(S, L), maxI = max_imperfect(S, L);
@@ -618,7 +624,7 @@ __device__ bool final_advance(const Dev &D, long long r, FinalRead &f) {
         case PC_GEN_START: {                                                    // genMatchStringForSite (:968-1001)
             Site ss = s[cur];
             if (ss.perfect) {
-                const int ref = pool_alloc(D, L);
+                const int ref = pool_take(D, pre, L);
                 if (!ref) { D.mcount[r] = n; return true; }
                 uint8_t *m = pool_ptr(D, ref);
                 for (int q = 0; q < L; q++) m[q] = 'm';
@@ -634,7 +640,7 @@ __device__ bool final_advance(const Dev &D, long long r, FinalRead &f) {
             break;
         }
         case PC_REALIGN_START: {                                                // realign_new up to its first fill (:229-370, :487-522)
-            const int ref = pool_alloc(D, L);                                   // the string scoreNoIndelsAndMakeMatchString writes
+            const int ref = pool_take(D, pre, L);                               // the string scoreNoIndelsAndMakeMatchString writes
             if (!ref) { D.mcount[r] = n; return true; }
             Site ss = s[cur];
             const uint8_t *bases = D.bases + rr.bases_off + (ss.strand ? D.minusDelta : 0);
@@ -666,7 +672,6 @@ __device__ bool final_advance(const Dev &D, long long r, FinalRead &f) {
             D.mcount[r] = n;
             if (job == NO_ROOM) return true;                                    // log full: the same step next round
             f.seq++; f.pending = job; f.pc = PC_FILL_BACK;
-            atomicAdd(&D.counters[23], 1u);
             return true;                                                        // wait for the DP
         }
         case PC_FILL_BACK: {                                                    // a fill came back (:371-483, :523-622)
@@ -698,7 +703,7 @@ __device__ bool final_advance(const Dev &D, long long r, FinalRead &f) {
                 int gsyms = 0;
                 if (ss.ngaps) for (int q = 0; q < clen; q++) gsyms += src[q] == '-';
                 const int mlen = clen + gsyms * (GAPLEN - 1);                    // traceback2 :481-493: each '-' stands for 128 'D'
-                const int ref = pool_alloc(D, mlen);
+                const int ref = pool_take(D, pre, mlen);
                 if (!ref) { D.mcount[r] = n; return true; }
                 if (f.fillKind == 6 && ss.ngaps == 0) {
                     // the stale `columns` of the JNI class (see above): an insertion is 'Y' at or beyond the THIRD fill's column count.  Redone
@@ -828,19 +833,45 @@ __device__ bool final_advance(const Dev &D, long long r, FinalRead &f) {
     }
 }
 
+// bytes of the first string a read will ask for in this round (0 = none that can be told in advance): a site's first string has the
+// read's length ('m's of a perfect site, or what scoreNoIndelsAndMakeMatchString writes); a fill that came back brings its traceback
+__device__ int first_request(const Dev &D, long long r, const FinalRead &f) {
+    if (f.pc == PC_SITE_LOOP || f.pc == PC_GEN_START || f.pc == PC_REALIGN_START) return D.reads[r].len;
+    if (f.pc == PC_FILL_BACK) {
+        const bbmsa_result &res = fill_result(D, f.pending);
+        if (res.status != BBMSA_ST_OK || res.score_len <= 0 || res.match_len <= 0) return D.reads[r].len;       // (the next realign_new's string)
+        const Site &ss = D.ms[r * D.cap + (f.sorting ? 0 : f.i)];
+        int len = res.match_len;
+        if (ss.ngaps) { const uint8_t *src = fill_match(D, f.pending); int g = 0; for (int q = 0; q < res.match_len; q++) g += src[q] == '-'; len += g * (GAPLEN - 1); }
+        return len;
+    }
+    return 0;
+}
+
 __global__ __launch_bounds__(128) void final_round_kernel(const Dev D) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long count = D.activeIn ? D.nActiveIn : D.nreads;
+    const int lane = threadIdx.x & 63;
     bool stillActive = false;
     long long r = -1;
-    if (t < count) {
-        r = D.activeIn ? D.activeIn[t] : t;
-        FinalRead f = D.fin[r];
-        if (f.pc != PC_DONE) { stillActive = final_advance(D, r, f); D.fin[r] = f; }
+    FinalRead f; f.pc = PC_DONE;
+    if (t < count) { r = D.activeIn ? D.activeIn[t] : t; f = D.fin[r]; }
+    // one pool request per wavefront for the reads' first strings: inclusive prefix sum of the lanes' units, one atomicAdd
+    PreAlloc pre; pre.ref = 0; pre.units = 0;
+    {
+        const int bytes = f.pc != PC_DONE ? first_request(D, r, f) : 0;
+        const unsigned units = bytes > 0 ? pool_units(bytes) : 0u;
+        unsigned incl = units;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        const unsigned total = __shfl(incl, 63, 64);
+        int base = 0;
+        if (total) { if (lane == 0) base = pool_alloc_units(D, total); base = __shfl(base, 0, 64); }
+        if (base && units) { pre.ref = base + (int)(incl - units); pre.units = units; }
     }
+    if (f.pc != PC_DONE) { stillActive = final_advance(D, r, f, pre); D.fin[r] = f; }
     const unsigned long long m = __ballot(stillActive);
     if (m) {
-        const int lane = threadIdx.x & 63;
         unsigned base = 0;
         if (lane == __builtin_ctzll(m)) base = atomicAdd(&D.counters[2], (unsigned)__builtin_popcountll(m));
         base = __shfl(base, __builtin_ctzll(m));
