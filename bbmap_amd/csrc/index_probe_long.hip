@@ -24,6 +24,8 @@
 // quickScore / scoreLeft / scoreRight / scoreZ2 / maxQuickScore, extendScore, makeGapArray, calcApproxHitsCutoff :2562-2585.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <climits>
 #include <cstdio>
 
@@ -1188,22 +1190,27 @@ int bbidx_long_lds_bytes() { return bbidxl::lds_bytes(bbidxl::KMAX - 1, bbidxl::
 static const void *long_kernel_fn(int profile) {
     return profile ? (const void *)bbidxl::probe_long_kernel<bbidxl::ProfPacBio> : (const void *)bbidxl::probe_long_kernel<bbidxl::ProfBBMap>;
 }
-static int g_longCUs = 0;
-constexpr int LONG_MAX_BLOCKS_PER_CU = 8;
+constexpr int LONG_MAX_BLOCKS_PER_CU = 8, LONG_MAX_DEVICES = 64;
+// per device (a process may hold index contexts on several GPUs, and the overflow tier's helper thread probes too): the CU count, and
+// whether the kernels' dynamic LDS limit has been raised there
+static std::mutex g_longMutex;
+static int g_longCUs[LONG_MAX_DEVICES];
+static bool g_longReady[LONG_MAX_DEVICES][2];
+static int long_cus(int profile) {                     // of the CURRENT device (the callers have set it to the context's)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LONG_MAX_DEVICES) return 0;
+    std::lock_guard<std::mutex> lock(g_longMutex);
+    if (!g_longReady[dev][profile ? 1 : 0]) {
+        if (hipFuncSetAttribute(long_kernel_fn(profile), hipFuncAttributeMaxDynamicSharedMemorySize, bbidx_long_lds_bytes()) != hipSuccess) return 0;
+        hipDeviceProp_t prop;
+        g_longCUs[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        g_longReady[dev][profile ? 1 : 0] = true;
+    }
+    return g_longCUs[dev];
+}
 
 // blocks the workspace has to be sized for: the most any launch uses
-int bbidx_long_blocks(int profile) {
-    static bool ready[2] = {false, false};
-    if (!ready[profile ? 1 : 0]) {
-        if (hipFuncSetAttribute(long_kernel_fn(profile), hipFuncAttributeMaxDynamicSharedMemorySize, bbidx_long_lds_bytes()) != hipSuccess) return 0;
-        int dev = 0;
-        hipDeviceProp_t prop;
-        g_longCUs = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_longCUs = prop.multiProcessorCount;
-        ready[profile ? 1 : 0] = true;
-    }
-    return g_longCUs * LONG_MAX_BLOCKS_PER_CU;
-}
+int bbidx_long_blocks(int profile) { return long_cus(profile) * LONG_MAX_BLOCKS_PER_CU; }
 
 int bbidx_launch_long(const bbidx::Params &P, hipStream_t stream, int profile, int *ws, int blocks) {
     static thread_local char msg[256];
@@ -1229,7 +1236,8 @@ int bbidx_launch_long(const bbidx::Params &P, hipStream_t stream, int profile, i
     int per = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, long_kernel_fn(profile), 64, (size_t)lds) != hipSuccess || per < 1) per = 1;
     if (per > LONG_MAX_BLOCKS_PER_CU) per = LONG_MAX_BLOCKS_PER_CU;
-    long long nb = (long long)(g_longCUs > 0 ? g_longCUs : 256) * per;
+    const int cus = long_cus(profile);
+    long long nb = (long long)(cus > 0 ? cus : 256) * per;
     if (nb > blocks) nb = blocks;
     if (nb > P.nreads) nb = P.nreads;
     if (nb < 1) nb = 1;

@@ -147,10 +147,10 @@ extern "C" int bbkeys_make(const bbkeys_config *cfg, const uint8_t *bases, const
         for (int i = 0; i < len; i++) baseScores[i] = quality ? (int8_t)(java_round(100 * T.probCorrect[quality[i] & 127]) - 100) : (int8_t)0;
     }
     if (len < K) return 0;                                                                  // :645
-    {   // DISCARD_MOSTLY_UNDEFINED_READS :651-654
+    {   // :650-654: `if(PERFECTMODE || SEMIPERFECTMODE){if(r.containsUndefined()){return -1;}}else if(DISCARD_MOSTLY_UNDEFINED_READS){...}`
         int n = 0;
         for (int i = 0; i < len; i++) if (!fully_defined(bases[i])) n++;
-        if (n > 25 && len - n < n) return 0;
+        if (cfg->semiperfectMode ? n > 0 : (n > 25 && len - n < n)) return 0;
     }
     const int keyProbLen = len - K + 1;
     std::vector<float> keyProbs((size_t)keyProbLen);

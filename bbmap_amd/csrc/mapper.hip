@@ -1315,8 +1315,15 @@ template <class T> static int regrow(bbmap_ctx *c, hipStream_t stream, T **p, si
 // The reference's per-read lists of fills have no capacity.  When a round asks for more log entries than there are (the kernels
 // then hold the affected reads back, emit_fill's NO_ROOM), the logs are grown here before the next round; `needJobs` / `needGapped`
 // = entries that must fit.  The device counters are set back to the number of entries that were really written.
+// arrays a regrow has replaced: freed when the guard goes out of scope, after the stream has passed the copies (error paths included)
+struct DeadArrays {
+    hipStream_t stream; std::vector<void *> v;
+    explicit DeadArrays(hipStream_t s) : stream(s) {}
+    ~DeadArrays() { if (!v.empty()) { (void)hipStreamSynchronize(stream); for (void *q : v) (void)hipFree(q); } }
+};
 static int grow_logs(bbmap_ctx *c, hipStream_t stream, bbmapper::Dev &D, long long needJobs, long long needGapped, long long usedJobs, long long usedGapped) {
-    std::vector<void *> dead;
+    DeadArrays guard(stream);
+    std::vector<void *> &dead = guard.v;
     if (needJobs > c->jobCap) {
         long long nc = c->jobCap * 2; if (nc < needJobs) nc = needJobs + needJobs / 4 + 1024;
         MTRY(regrow(c, stream, &c->d_jobs, (size_t)usedJobs, (size_t)nc, dead));
@@ -1337,7 +1344,6 @@ static int grow_logs(bbmap_ctx *c, hipStream_t stream, bbmapper::Dev &D, long lo
     c->h_counters[32] = (unsigned)usedJobs; c->h_counters[33] = (unsigned)usedGapped;
     MHIP(hipMemcpyAsync(c->d_counters, c->h_counters + 32, 8, hipMemcpyHostToDevice, stream));
     MHIP(hipStreamSynchronize(stream));
-    for (void *q : dead) (void)hipFree(q);
     D.jobs = c->d_jobs; D.jinfo = c->d_jinfo; D.results = c->d_results; D.jobCap = c->jobCap;
     D.gjobs = c->d_gjobs; D.ggaps = c->d_ggaps; D.ginfo = c->d_ginfo; D.gresults = c->d_gresults; D.gjobCap = c->gjobCap;
     c->stats.log_growths += 1.0f;              // (how often the logs grew in this batch)
@@ -1366,7 +1372,8 @@ static void add_dp_ms(bbmap_ctx *c, bool plain, bool gapped) {
     float k3[3];
     if (plain && bbmsa_last_kernel_ms3(c->msa, k3) == BBMAP_OK) { c->stats.ms_dp_narrow += k3[0]; c->stats.ms_dp_wave += k3[1]; c->stats.ms_dp_generic += k3[2];
                                                                  if (k3[1] > c->stats.ms_dp_wave_max) c->stats.ms_dp_wave_max = k3[1]; }
-    if (gapped && bbmsa_last_kernel_ms3(c->msaGapped, k3) == BBMAP_OK) c->stats.ms_dp_gapped += k3[0] + k3[1] + k3[2];
+    // (mapPacBio has ONE context for both logs: its kernel times are the plain launch's already, a second reading would count them twice)
+    if (gapped && c->msaGapped != c->msa && bbmsa_last_kernel_ms3(c->msaGapped, k3) == BBMAP_OK) c->stats.ms_dp_gapped += k3[0] + k3[1] + k3[2];
     static const bool show = getenv("BBMAP_DP_COUNTS") != nullptr;      // where the fills of a launch sequence ended up (experiments)
     if (show) {
         int64_t n4[4];
@@ -1787,6 +1794,16 @@ extern "C" int bbmap_map_batch(bbmap_ctx *c, int64_t n_reads, const bbidx_read *
             return mfail(BBMAP_E_ARG, "bbmap_map_batch: a read lies outside the bases buffer");
         if (rd.nkeys < 0 || rd.keys_off < 0 || rd.keys_off + 2LL * rd.nkeys > keyinfo_ints)
             return mfail(BBMAP_E_ARG, "bbmap_map_batch: a read's key offsets and scores lie outside keyinfo");
+        // the probe kernels index the read with these offsets (LDS and global memory): every key inside its read, offsets ascending
+        // (KeyRing.makeOffsets3 gives them so), no more keys than the profile's kernels take
+        if (rd.nkeys > (c->cfg.reserved[3] == BBIDX_PROFILE_PACBIO ? BBIDX_PACBIO_MAX_KEYS : BBIDX_MAX_KEYS))
+            return mfail(BBMAP_E_ARG, "bbmap_map_batch: a read has more keys than the index profile allows (BBIDX_MAX_KEYS / BBIDX_PACBIO_MAX_KEYS)");
+        const int kk = c->index->dev.p.k;
+        for (int q = 0; q < rd.nkeys; q++) {
+            const int o = keyinfo[rd.keys_off + q];
+            if (o < 0 || o + kk > rd.len || (q > 0 && o < keyinfo[rd.keys_off + q - 1]))
+                return mfail(BBMAP_E_ARG, "bbmap_map_batch: a key offset lies outside its read, or the offsets are not ascending");
+        }
     }
     MHIP(hipSetDevice(c->cfg.device));
     const size_t nb = (size_t)bases_bytes;

@@ -43,6 +43,7 @@ struct StripParams {
     int pipeK, pipeSlots;
     int *pipeBoundary;            // per slot: pipeK x 3 x (maxColumns + 2) ints
     int *pipeSync;                // per slot: PIPE_SYNC_INTS(pipeK) ints, zeroed before the launch
+    int pipeSpinLimit;            // polls of a hand-shake word before a wave gives up (BBMSA_PIPE_SPIN_LIMIT; ~3 s by default)
 };
 
 namespace {
@@ -73,11 +74,18 @@ __device__ __forceinline__ uint8_t ld_agent_u8(const uint8_t *p) { return __hip_
 
 }  // namespace
 
-// hand-shake words of a slot: [0] jobs finished; then per strip: columns of its last row published, first good column of that row so
-// far (-1: none), last good column (final), state (0 running, 1 done, 2 done and dead: the row has no good cell, 3 failed), first row
-// not entered, visited cells (2 ints)
+// hand-shake words of a slot: [0] "go": jobs ALL of whose pipeK waves are through with, [1] arrivals (every wave adds one per job when
+// it is through with it; the last one to arrive zeroes the per-strip words and raises [0]), [3] the slot is dead (a wave gave up waiting:
+// its jobs go to the one-thread kernel), [6] jobs claimed (a job's result is written, or the job handed on, by whoever raises this from
+// its index: exactly once); then per strip: columns of its last row published, first good column of that row so far (-1: none), last
+// good column (final), state (0 running, 1 done, 2 done and dead: the row has no good cell, 3 failed), first row not entered, visited
+// cells (2 ints).
+// Why so careful: the waves of a slot are only ASSUMED co-resident (the grid is sized from an occupancy query).  If one of them starts
+// late, its partners time out -- and must neither reuse the hand-shake words while the straggler may still write them (no job starts
+// before all pipeK waves have arrived from the one before) nor lose a job (a dead slot's remaining jobs are claimed one by one and
+// handed to the one-thread kernel by whichever wave gets there).
 __host__ __device__ constexpr int pipe_sync_ints(int K) { return 8 + 8 * K; }
-constexpr int PIPE_SPIN_LIMIT = 1 << 21;      // ~3 s of polling: a wave that waits longer gives the job to the one-thread kernel
+constexpr int PIPE_SPIN_LIMIT = 1 << 21;      // default of StripParams.pipeSpinLimit: ~3 s of polling
 
 template <class S, int R, bool PIPE>
 __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p) {
@@ -101,32 +109,65 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
         syProg = sync + 8; syFirst = sync + 8 + K; syLast = sync + 8 + 2 * K; syState = sync + 8 + 3 * K; syNoEnter = sync + 8 + 4 * K;
         syIters = sync + 8 + 5 * K;                                  // (two ints per strip)
     }
-    // polls a hand-shake word until pred(value); false after PIPE_SPIN_LIMIT polls
+    // polls a hand-shake word until it reaches `need`; false after pipeSpinLimit polls or as soon as the slot is dead
     auto wait_ge = [&](const int *word, int need) -> bool {
-        for (int spin = 0; spin < PIPE_SPIN_LIMIT; spin++) {
+        for (int spin = 0; spin < p.pipeSpinLimit; spin++) {
             if (ld_agent(word) >= need) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); return true; }
+            if (ld_agent(sync + 3)) return false;
             __builtin_amdgcn_s_sleep(8);
         }
         return false;
+    };
+    // raises the slot's claim word from q to q + 1: true for exactly one caller per job
+    auto claim = [&](long long q) -> bool {
+        int got = 0;
+        if (lane == 0) {
+            int expected = (int)q;
+            got = __hip_atomic_compare_exchange_strong(sync + 6, &expected, (int)q + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+        }
+        return __builtin_amdgcn_readfirstlane(got) != 0;
+    };
+    // a wave that gave up waiting: the slot is dead from here on; every job of it that nobody has claimed yet goes to the one-thread kernel
+    auto drain = [&]() {
+        if (lane == 0) __hip_atomic_store(sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            const long long q = (long long)__builtin_amdgcn_readfirstlane(ld_agent(sync + 6));
+            const long long jq = slot + q * p.pipeSlots;
+            if (jq >= total) break;
+            if (claim(q) && lane == 0) { const unsigned k = atomicAdd(p.slow_count, 1u); p.slow_list[k] = (int)jq; }
+        }
     };
 
     for (long long kjob = 0;; kjob++) {
         long long j;
         if (PIPE) {
+            // (a dead slot is drained before anything else: the job that failed may have been the slot's last)
+            if (__builtin_amdgcn_readfirstlane(ld_agent(sync + 3))) { drain(); break; }
             j = slot + kjob * p.pipeSlots;
             if (j >= total) break;
-            if (!wait_ge(sync, (int)kjob)) break;                    // the slot's previous job is finished by all its waves
+            // no wave starts a job before ALL the slot's waves are through with the one before (a straggler still writing the hand-shake
+            // words of job kjob - 1 would corrupt job kjob); a wave that waits in vain declares the slot dead and hands its jobs on
+            if (!wait_ge(sync, (int)kjob)) { drain(); break; }
         } else {
             unsigned base = 0;
             if (lane == 0) base = atomicAdd(p.queue, 1u);
             j = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)base);
             if (j >= total) break;
         }
-        auto job_finished = [&]() {                                   // PIPE: lets the slot's waves go on to its next job
+        // PIPE: this wave is through with job kjob (finished, declined or failed).  The last of the slot's K waves to arrive puts the
+        // per-strip words back to zero and lets everybody go on to the next job.
+        auto arrive = [&]() {
             if (PIPE) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                if (lane == 0) __hip_atomic_store(sync, (int)kjob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int last = 0;
+                if (lane == 0) last = (__hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1 == K * ((int)kjob + 1)) ? 1 : 0;
+                if (__builtin_amdgcn_readfirstlane(last)) {
+                    for (int i = lane; i < 8 * K; i += 64) __hip_atomic_store(sync + 8 + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0) __hip_atomic_store(sync, (int)kjob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         };
 
@@ -159,7 +200,7 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
         }
         const bool banded = limited && halfband > 0;
         if (!shapeOK) {
-            if (lane == 0 && w == 0) {
+            if (w == 0 && (!PIPE || claim(kjob)) && lane == 0) {
                 bbmsa_result r;
                 for (int i = 0; i < 5; i++) r.result[i] = 0;
                 r.status = BBMSA_ST_BAD_SHAPE; r.iterations = 0;
@@ -167,7 +208,7 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
                 r.score_len = 0; r.match_len = 0; r.fill_kind = 0; r.columns = columns;
                 p.results[j] = r;
             }
-            if (w == 0) job_finished();
+            arrive();
             continue;
         }
         // (Windows narrower than the read need no special case here: the per-plane priority of the "still needed" penalties --
@@ -175,8 +216,8 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
         // Round 2 handed them to the one-thread kernel as the 11ts wavefront kernel does, whose single penalty table cannot hold
         // both: a 6,000-base piece with a few more inserted than deleted bases then cost 12 s on one thread.)
         if (banded) {                                               // the generic kernel takes these
-            if (lane == 0 && w == 0) { const unsigned k = atomicAdd(p.slow_count, 1u); p.slow_list[k] = (int)j; }
-            if (w == 0) job_finished();
+            if (w == 0 && (!PIPE || claim(kjob)) && lane == 0) { const unsigned k = atomicAdd(p.slow_count, 1u); p.slow_list[k] = (int)j; }
+            arrive();
             continue;
         }
 
@@ -224,7 +265,7 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
 
         bool failed = false;                                          // PIPE: a hand-shake timed out
         bool deadAbove = false;                                       // PIPE: the strip above ended without a good cell in its last row
-        if (PIPE && w >= nstrips) continue;                           // fewer strips than waves: nothing to do for this job
+        if (PIPE && w >= nstrips) { arrive(); continue; }             // fewer strips than waves: nothing to do for this job
         for (int s = PIPE ? w : 0; s < (PIPE ? w + 1 : nstrips); s++) {
             const int rowBase = s * STRIP;                            // rows rowBase+1 .. rowBase+STRIP
             const int r0 = rowBase + lane * R + 1;
@@ -514,11 +555,18 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
             if (!PIPE && limited && noEnterRow <= rows) break;       // the fill died inside this strip: no row below is entered
         }
         if (PIPE) {
-            if (failed) {                                             // tell the waves below, and let the last one hand the job on
-                if (lane == 0) __hip_atomic_store(syState + w, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (failed) {
+                // a hand-shake timed out (or the slot died under us): tell the waves below, declare the slot dead -- its unclaimed jobs,
+                // this one included, go to the one-thread kernel (drain, at the top of the loop) -- and arrive
+                if (lane == 0) {
+                    __hip_atomic_store(syState + w, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                arrive();
+                continue;
             }
-            if (w != nstrips - 1) continue;                           // only the wave of the last strip goes on to the result
-            if (!failed) {
+            if (w != nstrips - 1) { arrive(); continue; }             // only the wave of the last strip goes on to the result
+            {
                 // every strip is done (a strip finishes only after the one above it): first row not entered, visited cells
                 int g = INT_MAX; long long its = 0;
                 if (lane < nstrips) {
@@ -531,13 +579,8 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
                 for (int d = 32; d >= 1; d >>= 1) { g = min(g, __shfl_xor(g, d, 64)); its += __shfl_xor(its, d, 64); }
                 noEnterRow = g; iters = its;
             }
-            // the hand-shake words go back to zero for the slot's next job (its other waves are waiting for job_finished)
-            for (int i = lane; i < 8 * K; i += 64) __hip_atomic_store(sync + 8 + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (failed) {
-                if (lane == 0) { const unsigned k = atomicAdd(p.slow_count, 1u); p.slow_list[k] = (int)j; }
-                job_finished();
-                continue;
-            }
+            // the job's result is this wave's to write -- unless the slot died meanwhile and a draining wave has claimed the job
+            if (!claim(kjob)) { arrive(); continue; }
         }
         if (!limited) iters = (long long)rows * columns;
 
@@ -664,7 +707,7 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
             p.results[j] = r;
         }
         __builtin_amdgcn_wave_barrier();
-        job_finished();
+        arrive();
     }
 }
 

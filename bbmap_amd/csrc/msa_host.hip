@@ -19,7 +19,7 @@ struct StripParams {            // msa_fill_strip.hip
     long long njobs; const unsigned int *njobs_dev; unsigned int *queue; unsigned int *dirbuf;
     long long dir_slot_dwords, dir_strip_dwords; int *boundary; uint8_t *tmpbuf; int *slow_list; unsigned int *slow_count;
     int match_stride; int maxRows, maxColumns; int bandwidth; float bandwidthRatio;
-    int pipeK, pipeSlots; int *pipeBoundary; int *pipeSync;
+    int pipeK, pipeSlots; int *pipeBoundary; int *pipeSync; int pipeSpinLimit;
 };
 int strip_rows_per_lane();
 const void *strip_kernel_pacbio();
@@ -324,6 +324,8 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
         sp.bandwidth = c->cfg.bandwidth; sp.bandwidthRatio = c->cfg.bandwidthRatio;
         long long sblocks = n_jobs < c->stripBlocks ? n_jobs : c->stripBlocks;
         sp.pipeK = 0; sp.pipeSlots = 0; sp.pipeBoundary = nullptr; sp.pipeSync = nullptr;
+        sp.pipeSpinLimit = env_int("BBMSA_PIPE_SPIN_LIMIT", 1 << 21);          // polls before a wave of the pipelined form gives up (~3 s; tests force timeouts)
+        if (sp.pipeSpinLimit < 1) sp.pipeSpinLimit = 1;
         void *sargs[] = {&sp};
         if (!n_jobs_dev && c->pipeJobsMax > 0 && n_jobs <= c->pipeJobsMax) {
             // few jobs (the late scoreSlow rounds of mapPacBio): a lone 6,000 x 6,100 fill is one wavefront's dependent chain, 370 ms;

@@ -502,7 +502,7 @@ def pacbio_main(args):
         probe_bytes = 2 * nkeys_total * 16 + 4 * (ps[0] + ps[1]) + ps[3] + 64 * ps[4]
         jobs_all = np.concatenate([out["jobs"], out["gjobs"]]) if len(out["gjobs"]) else out["jobs"]
         dp_bytes = int((2 * (jobs_all["read_len"].astype(np.int64) + (jobs_all["refEndLoc"] - jobs_all["refStartLoc"] + 1)) + 59).sum()) if len(jobs_all) else 0
-        dp_ms = ms["ms_dp_wave"] + ms["ms_dp_gapped"] * 0.0
+        dp_ms = ms["ms_dp_wave"] + ms["ms_dp_gapped"]
         kern = {"probe_long_kernel": {"ms": ms["ms_probe"], "algorithmic_bytes": int(probe_bytes)},
                 "msa_fill_strip_kernel": {"ms": dp_ms, "algorithmic_bytes": dp_bytes},
                 "msa_fill_generic_kernel(hand-overs)": {"ms": ms["ms_dp_generic"]},

@@ -234,6 +234,22 @@ JNIEXPORT jlong JNICALL Java_align2_BBMapHIP_mapBatch(JNIEnv *env, jclass cls, j
     return (jlong)total;
 }
 
+/* (JILjava/nio/ByteBuffer;Ljava/nio/ByteBuffer;I)J -- the last batch's final records (bbmap_final, 64 bytes each: what BBMap prints per read:
+ * mapped, chrom, strand, start, stop, mapScore, paired, ambiguous, perfect, rescued, match length / offset) and their match strings packed
+ * into `match`; returns the bytes the strings take (more than matchCap: call again with a larger buffer; `match` may be null: records only) */
+JNIEXPORT jlong JNICALL Java_align2_BBMapHIP_getFinal(JNIEnv *env, jclass cls, jlong ctx, jint nReads, jobject records, jobject match, jint matchCap) {
+    (void)cls;
+    if (nReads <= 0) return 0;
+    bbmap_final *pf = (bbmap_final *)direct(env, records, (long long)nReads * (long long)sizeof(bbmap_final), "records");
+    if (!pf) return 0;
+    uint8_t *pm = NULL;
+    if (match) { pm = (uint8_t *)direct(env, match, matchCap, "match"); if (!pm) return 0; }
+    int64_t bytes = 0;
+    const int rc = bbmap_get_final((bbmap_ctx *)(intptr_t)ctx, nReads, pf, pm, pm ? matchCap : 0, &bytes);
+    if (rc != BBMAP_OK) { throw_runtime(env, "bbmap_get_final", rc); return 0; }
+    return (jlong)bytes;
+}
+
 /* ([B)I -- copies the calling thread's last error text into buf (UTF-8, truncated), returns its length */
 JNIEXPORT jint JNICALL Java_align2_BBMapHIP_lastError(JNIEnv *env, jclass cls, jbyteArray buf) {
     (void)cls;

@@ -4,11 +4,13 @@ import java.nio.ByteBuffer;
 import java.nio.ByteOrder;
 
 /**
- * The whole per-batch flow on the device: everything between AbstractIndex.findAdvanced and the end of rescue in
- * BBMapThread.processRead / processReadPair (current/align2/BBMapThread.java:389-490, :943-1098) -- probe, pairing, trimList,
- * scoreNoIndels, tip deletions, the scoreSlow rounds, rescue -- for one read list per call.  What comes back per read is its
- * SiteScore list (start/stop, score/quickScore/slowScore/pairedScore, hits, perfect/semiperfect, rescued, gaps); the Java side
- * continues with the final pairing / ambiguity logic and output.
+ * The whole per-batch flow on the device: everything between AbstractIndex.findAdvanced and the end of
+ * BBMapThread.processRead / processReadPair (current/align2/BBMapThread.java:389-732, :943-1362) -- probe, pairing, trimList,
+ * scoreNoIndels, tip deletions, the scoreSlow rounds, rescue, and the final alignment stage (final pairing, ambiguity policy,
+ * genMatchString -> realign_new, clipping, penalties) -- for one read list per call.  What comes back per read is its final record
+ * ({@link #finalRecord}: mapped / chrom / strand / start / stop / mapScore / paired / ambiguous / perfect / rescued and the match
+ * string, i.e. what Read.setFromSite + genMatchString leave in the Read) and its SiteScore list (start/stop, score/quickScore/
+ * slowScore/pairedScore, hits, perfect/semiperfect, rescued, gaps); the Java side continues with statistics and output.
  *
  * paired: reads 2p and 2p+1 are mates.  Defaults are bbmap.sh's or mapPacBio.sh's (BBMap.setDefaults / BBMapPacBio.setDefaults).
  */
@@ -16,7 +18,7 @@ public final class BBMapHIP implements AutoCloseable {
 
 	static { System.loadLibrary("bbmap_amd_jni"); }
 
-	private static final int READ_BYTES = 24, MSITE_BYTES = 128, MAX_GAPS = 16;
+	private static final int READ_BYTES = 24, MSITE_BYTES = 128, MAX_GAPS = 16, FINAL_BYTES = 64;
 	/** nsites values below zero */
 	public static final int NSITES_OVERFLOW = -1, NSITES_MATE_OVERFLOW = -2;
 
@@ -24,6 +26,7 @@ public final class BBMapHIP implements AutoCloseable {
 	private static native void destroy(long ctx);
 	private static native long mapBatch(long ctx, int nReads, ByteBuffer reads, ByteBuffer bases, ByteBuffer baseScores, int basesBytes,
 			ByteBuffer keyinfo, int keyinfoInts, ByteBuffer nsites, ByteBuffer offsets, ByteBuffer sites, int sitesCap);
+	private static native long getFinal(long ctx, int nReads, ByteBuffer records, ByteBuffer match, int matchCap);
 	private static native int lastError(byte[] buf);
 
 	private long ctx;
@@ -38,6 +41,14 @@ public final class BBMapHIP implements AutoCloseable {
 		sitesCap = 8 * maxReads; sites = buf(sitesCap * MSITE_BYTES);
 	}
 
+	/** stream.Read's mapping fields after processRead / processReadPair (what the SAM writer prints) */
+	public static final class Final {
+		public boolean mapped, paired, ambiguous, perfect, rescued;
+		public int chrom, strand, start, stop, mapScore;
+		/** Read.match in long format (m S N D I X Y C), null when the read is not mapped */
+		public byte[] match;
+	}
+
 	/** stream.SiteScore, field for field */
 	public static final class Site {
 		public int chrom, strand, start, stop, hits, quickScore, score, slowScore, pairedScore;
@@ -48,6 +59,8 @@ public final class BBMapHIP implements AutoCloseable {
 	private int nReads, basesBytes, keyInts, sitesCap;
 	private ByteBuffer reads = buf(400 * READ_BYTES), bases = buf(400 * 160), baseScores = buf(400 * 160), keyinfo = buf(400 * 64 * 4);
 	private ByteBuffer nsites, offsets, sites;
+	private ByteBuffer finals = buf(400 * FINAL_BYTES), matches = buf(400 * 192);
+	private boolean haveFinals;
 	private long total;
 
 	private static ByteBuffer buf(int bytes) { return ByteBuffer.allocateDirect(bytes).order(ByteOrder.LITTLE_ENDIAN); }
@@ -58,7 +71,7 @@ public final class BBMapHIP implements AutoCloseable {
 		return n;
 	}
 
-	public void clear() { nReads = 0; basesBytes = 0; keyInts = 0; }
+	public void clear() { nReads = 0; basesBytes = 0; keyInts = 0; haveFinals = false; }
 
 	/** queue one read (a pair: r1 then r2); arguments as quickMap computes them (AbstractMapThread.java:659-728) */
 	public int add(byte[] basesP, byte[] baseScoresP, int[] offsets_, int[] keyScoresP) {
@@ -85,6 +98,32 @@ public final class BBMapHIP implements AutoCloseable {
 			sites = buf(sitesCap * MSITE_BYTES);
 			total = mapBatch(ctx, nReads, reads, bases, baseScores, basesBytes, keyinfo, keyInts, nsites, offsets, sites, sitesCap);
 		}
+	}
+
+	/** the final record of read r after map() (fetched from the device on first use) */
+	public Final finalRecord(int r) {
+		if (!haveFinals) {
+			finals = grown(finals, 0, nReads * FINAL_BYTES);
+			long need = getFinal(ctx, nReads, finals, matches, matches.capacity());
+			if (need > matches.capacity()) {
+				matches = buf((int)Math.min(Integer.MAX_VALUE - 64, need + need / 8));
+				getFinal(ctx, nReads, finals, matches, matches.capacity());
+			}
+			haveFinals = true;
+		}
+		final int o = r * FINAL_BYTES;
+		final Final f = new Final();
+		f.mapped = finals.getInt(o) != 0; f.chrom = finals.getInt(o + 4); f.strand = finals.getInt(o + 8); f.start = finals.getInt(o + 12);
+		f.stop = finals.getInt(o + 16); f.mapScore = finals.getInt(o + 20); f.paired = finals.getInt(o + 24) != 0;
+		f.ambiguous = finals.getInt(o + 28) != 0; f.perfect = finals.getInt(o + 32) != 0; f.rescued = finals.getInt(o + 36) != 0;
+		final int len = finals.getInt(o + 40);
+		if (len > 0) {
+			f.match = new byte[len];
+			final ByteBuffer m = matches.duplicate();
+			m.position((int)finals.getLong(o + 48));
+			m.get(f.match, 0, len);
+		}
+		return f;
 	}
 
 	/** sites of read r after map(): >= 0, or NSITES_OVERFLOW / NSITES_MATE_OVERFLOW (the list fitted no tier: the read is unmapped) */

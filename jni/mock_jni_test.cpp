@@ -63,6 +63,7 @@ void Java_align2_BBIndexHIP_findBatch(JNIEnv *, jclass, jlong, jint, jobject, jo
 jlong Java_align2_BBMapHIP_create(JNIEnv *, jclass, jlong, jint, jboolean, jint, jint, jint);
 void Java_align2_BBMapHIP_destroy(JNIEnv *, jclass, jlong);
 jlong Java_align2_BBMapHIP_mapBatch(JNIEnv *, jclass, jlong, jint, jobject, jobject, jobject, jint, jobject, jint, jobject, jobject, jobject, jint);
+jlong Java_align2_BBMapHIP_getFinal(JNIEnv *, jclass, jlong, jint, jobject, jobject, jint);
 jint Java_align2_BBMapHIP_lastError(JNIEnv *, jclass, jbyteArray);
 int bbjni_fill(int, const uint8_t *, int, const uint8_t *, int, int, int, int, int32_t *, int64_t *, int32_t *, int, int, int, float);
 void bbjni_release_thread(void);
@@ -376,6 +377,33 @@ static int test_glue(JNIEnv *env) {
             perfect += t.perfect != 0;
         }
         CHECK(home >= nreads * 97 / 100 && perfect > nreads / 20);
+        // BBMapHIP.getFinal: the final records (what BBMap prints) and their match strings; == bbmap_get_final, and consistent with the reads
+        {
+            std::vector<bbmap_final> fin((size_t)nreads), fin2((size_t)nreads);
+            std::vector<uint8_t> mstr((size_t)nreads * 256), mstr2((size_t)nreads * 256);
+            _jobject bF{fin.data(), (int)(fin.size() * sizeof(bbmap_final)), 1}, bM{mstr.data(), (int)mstr.size(), 1};
+            const jlong mbytes = Java_align2_BBMapHIP_getFinal(env, nullptr, mp, nreads, &bF, &bM, (jint)mstr.size());
+            CHECK(g_thrown == 0 && mbytes > 0 && mbytes <= (jlong)mstr.size());
+            int64_t mbytes2 = 0;
+            CHECK(bbmap_get_final((bbmap_ctx *)(intptr_t)mp, nreads, fin2.data(), mstr2.data(), (int64_t)mstr2.size(), &mbytes2) == BBMAP_OK);
+            CHECK(mbytes2 == mbytes && memcmp(fin.data(), fin2.data(), fin.size() * sizeof(bbmap_final)) == 0 && mstr == mstr2);
+            int fhome = 0;
+            for (int r = 0; r < nreads; r++) {
+                const bbmap_final &f = fin[(size_t)r];
+                if (!f.mapped) { CHECK(f.match_len == 0); continue; }
+                CHECK(f.match_len >= L && f.match_off >= 0 && f.match_off + f.match_len <= mbytes);
+                int rd = 0, rf = 0;
+                for (int q = 0; q < f.match_len; q++) { const uint8_t c = mstr[(size_t)(f.match_off + q)]; rd += c != 'D'; rf += c != 'I'; }
+                CHECK(rd == L && rf == f.stop - f.start + 1);                            // the string consumes the read and spans [start, stop]
+                fhome += f.chrom == 1 && f.strand == 0 && f.start == origin[(size_t)r] && f.stop == origin[(size_t)r] + L - 1;
+            }
+            CHECK(fhome >= nreads * 97 / 100);
+            // a records buffer that is too small is refused with an exception
+            _jobject tiny{fin.data(), 64, 1};
+            Java_align2_BBMapHIP_getFinal(env, nullptr, mp, nreads, &tiny, &bM, (jint)mstr.size());
+            CHECK(g_thrown == 1);
+            g_thrown = 0;
+        }
         // the same batch straight through the C ABI gives the same records
         std::vector<bbmap_msite> ms2((size_t)cap);
         std::vector<int32_t> mn2((size_t)nreads, -9);

@@ -158,7 +158,7 @@ GLUE_SYMBOLS = [            # natives of jni/java/align2/*.java, implemented in 
     "Java_align2_MultiStateAligner11tsHIP_create", "Java_align2_MultiStateAligner11tsHIP_destroy",
     "Java_align2_MultiStateAligner11tsHIP_alignBatch", "Java_align2_MultiStateAligner11tsHIP_alignGappedBatch",
     "Java_align2_BBIndexHIP_build", "Java_align2_BBIndexHIP_destroy", "Java_align2_BBIndexHIP_setMaxReadLen", "Java_align2_BBIndexHIP_findBatch",
-    "Java_align2_BBMapHIP_create", "Java_align2_BBMapHIP_destroy", "Java_align2_BBMapHIP_mapBatch", "Java_align2_BBMapHIP_lastError",
+    "Java_align2_BBMapHIP_create", "Java_align2_BBMapHIP_destroy", "Java_align2_BBMapHIP_mapBatch", "Java_align2_BBMapHIP_getFinal", "Java_align2_BBMapHIP_lastError",
 ]
 
 

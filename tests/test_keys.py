@@ -37,6 +37,16 @@ def test_quality_less_lengths():
     assert K.make_keys(rd)[0] == []
 
 
+def test_semiperfect_mode_refuses_reads_with_an_undefined_base():
+    # `if(PERFECTMODE || SEMIPERFECTMODE){if(r.containsUndefined()){return -1;}}` (AbstractMapThread.java:650-651): one N is enough there,
+    # while the default mode only discards MOSTLY undefined reads (:652-654)
+    rd = _read(150, 7).copy()
+    rd[40] = ord("N")
+    assert len(K.make_keys(rd)[0]) > 10
+    assert K.make_keys(rd, cfg=K.default_config(semiperfectMode=1))[0] == []
+    assert len(K.make_keys(_read(150, 7), cfg=K.default_config(semiperfectMode=1))[0]) > 10
+
+
 def test_qualities_move_keys_and_lower_scores():
     rd = _read(150, 2)
     q = np.full(150, 35, np.uint8)

@@ -214,3 +214,17 @@ def test_pacbio_fill_dies_inside_a_strip_and_a_narrow_window():
              (rd, genome, 890, 2200, int(maxq * 0.2)),          # window narrower than the read by more than two columns
              (rd[:700], genome, 890, 1630, int(0.99 * (90 + 100 * 699)))]
     check(probs, M.FILL_LIMITED_RAW | M.DO_SCORE | M.DO_TRACEBACK, maxRows=1600, maxColumns=2000)
+
+
+def test_pipelined_form_survives_hand_shake_timeouts(monkeypatch, strip_form):
+    """The pipelined form assumes the wavefronts of a slot are co-resident; when one is not, its partners time out.  With a spin limit of
+    a few polls nearly every hand-shake times out: slots die, their jobs are claimed one by one and handed to the one-thread kernel, no
+    job is lost or answered twice, and every result equals the sequential kernel's (= the oracle's)."""
+    if strip_form != "pipelined":
+        pytest.skip("the hand-shakes exist in the pipelined form only")
+    monkeypatch.setenv("BBMSA_PIPE_SPIN_LIMIT", "3")
+    probs = pacbio_problems(21, 40, lo=900, hi=1500)           # two or three strips per read
+    n_null = check(probs, M.FILL_AND_SCORE_LIMITED | M.DO_TRACEBACK, maxRows=1600, maxColumns=1800)
+    assert n_null < len(probs)
+    monkeypatch.setenv("BBMSA_PIPE_SPIN_LIMIT", "2000")        # some hand-shakes make it, some do not: slots die in the middle of a job
+    check(pacbio_problems(22, 40, lo=900, hi=1500), M.FILL_AND_SCORE_LIMITED | M.DO_TRACEBACK, maxRows=1600, maxColumns=1800)
