@@ -118,30 +118,43 @@ def shared_reference(name, lens, repeat_frac, local_rank, world_local):
 DEL_MODEL = "randomreads"      # deletions as sh/randomreads.sh draws them (1..400 bases); "short" = rounds 1-2's cap of 40
 
 
-def make_batch(chroms, n_reads, paired, seed, read_set="mutated", lead=None):
+def make_batch(chroms, n_reads, paired, seed, read_set="mutated", lead=None, with_truth=False):
     """n_reads reads (n_reads / 2 pairs) drawn from the chromosomes in proportion to their lengths.  read_set: "mutated" = the
     reference generator's commented-out stress mix (snp .4 / ins .2 / del .2 / n .2 of the imperfect half, perfect .5,
     current/align2/RandomReads3.java:74-79) plus 3 % hard mates; "default" = sh/randomreads.sh's defaults, every rate 0: reads are
-    exact copies of the reference (its quality-driven substitution errors are not modelled: the reads carry no qualities)."""
+    exact copies of the reference (its quality-driven substitution errors are not modelled: the reads carry no qualities).
+    with_truth: also the generator's coordinates per unit, in batch order -- {"chrom" (1-based), "start1", "strand1"[, "start2",
+    "strand2"]} (single-ended reads are drawn from the plus strand: strand1 = 0)."""
     from bbmap_amd import workload as W
     L = 150
     units = n_reads // 2 if paired else n_reads
     lens = np.array([len(c) for c in chroms], np.float64)
     share = np.floor(units * lens / lens.sum()).astype(np.int64)
     share[0] += units - share.sum()
-    parts = []
+    parts, tparts = [], []
     pf, hard = (0.5, 0.03) if read_set == "mutated" else (1.0, 0.0)
     for i, (c, m) in enumerate(zip(chroms, share)):
         if m <= 0:
             continue
         lo = lead[i] if lead else 0
         if paired:
-            parts.append(W.make_pairs(c, int(m), read_len=L, seed=seed + 7 * i, del_model=DEL_MODEL, perfect_frac=pf, hard_frac=hard, lo=lo)[0].reshape(-1, 2 * L))
+            rd, t = W.make_pairs(c, int(m), read_len=L, seed=seed + 7 * i, del_model=DEL_MODEL, perfect_frac=pf, hard_frac=hard, lo=lo)
+            parts.append(rd.reshape(-1, 2 * L))
+            tparts.append(np.stack([np.full(int(m), i + 1, np.int64), t["start1"], t["strand1"], t["start2"], t["strand2"]], axis=1))
         else:
-            parts.append(W.make_reads_and_jobs(c, int(m), read_len=L, seed=seed + 7 * i, del_model=DEL_MODEL, perfect_frac=pf, lo=lo)[0].reshape(-1, L))
+            rd, _, t = W.make_reads_and_jobs(c, int(m), read_len=L, seed=seed + 7 * i, del_model=DEL_MODEL, perfect_frac=pf, lo=lo)
+            parts.append(rd.reshape(-1, L))
+            tparts.append(np.stack([np.full(int(m), i + 1, np.int64), t["start"], np.zeros(int(m), np.int64)], axis=1))
     allp = np.concatenate(parts)
     perm = np.random.Generator(np.random.PCG64(seed)).permutation(len(allp))      # mix the chromosomes within the batch
-    return np.ascontiguousarray(allp[perm]).reshape(-1)
+    reads = np.ascontiguousarray(allp[perm]).reshape(-1)
+    if not with_truth:
+        return reads
+    tt = np.concatenate(tparts)[perm]
+    truth = {"chrom": tt[:, 0], "start1": tt[:, 1], "strand1": tt[:, 2]}
+    if paired:
+        truth.update(start2=tt[:, 3], strand2=tt[:, 4])
+    return reads, truth
 
 
 def oracle_index(di, chroms, k):

@@ -247,3 +247,33 @@ def test_host_buffer_entry_returns_packed_lists_with_the_overflow_tier():
     assert total2 == total and len(sites2) == 10 and (ns2 == ns).all()
     mp.close()
     di.close()
+
+
+def test_average_pair_dist_follows_the_host_between_batches():
+    """AVERAGE_PAIR_DIST moves while BBMap runs (DYNAMIC_INSERT_LENGTH, BBMapThread.java:1307-1309); the host carries the running value
+    and sets it between batches (bbmap_set_average_pair_dist).  Two batches on ONE context, the second with another value: each equals
+    the oracle run with that value, and the value matters (paired scores differ between the two)."""
+    L, k = 150, 12
+    ref = W.make_reference(300000, seed=6, pad=2000, repeat_frac=0.15)
+    reads, _ = W.make_pairs(ref, 1500, read_len=L, seed=4, pad=2000, hard_frac=0.08)
+    di = DeviceIndex.build([ref], k=k)
+    offs = O.make_offsets(L, k, 1.9)
+    ks = [100 * k] * len(offs)
+    n = reads.size // L
+    mp = Mapper(di, n, L, offs, ks, paired=True, max_sites=32)
+    mp.load_reads(reads)
+    oi = O.OracleIndex([ref], k=k)
+    oi.s.p.quitAfterTwoPerfects = 0
+    r = reads.reshape(-1, L)
+    outs = []
+    for apd in (100, 260):
+        mp.set_average_pair_dist(apd)
+        mp.step()
+        out = mp.fetch()
+        orc = O.map_batch(oi, r[0::2].copy(), r[1::2].copy(), L, offs, ks, params=O.map_default_params(averagePairDist=apd), cap=64, match_stride=4200)
+        bad = compare(out, orc, n, paired=True)
+        assert not bad, "averagePairDist %d\n" % apd + "\n".join(bad[:20])
+        outs.append(out)
+    assert (outs[0]["sites"]["pairedScore"] != outs[1]["sites"]["pairedScore"]).any()
+    mp.close()
+    di.close()

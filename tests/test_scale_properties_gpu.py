@@ -36,8 +36,9 @@ def test_full_size_reference_workload(name):
     chroms, _ = B.shared_reference(name, lens, 0.0 if name == "ecoli" else 0.1, 0, 1)
     if paired and len(chroms) == 1:
         pairs, truth = W.make_pairs(chroms[0], N // 2, read_len=L, seed=3, lo=B.LEAD_N.get(name, [0])[0])     # (chr21: not from its leading N-run)
+        truth["chrom"] = np.ones(N // 2, np.int64)
     else:
-        pairs, truth = B.make_batch(chroms, N, paired, 3), None        # single-ended reads / pairs from all 24 chromosomes, mixed
+        pairs, truth = B.make_batch(chroms, N, paired, 3, with_truth=True)      # single-ended reads / pairs from all 24 chromosomes, mixed
     di = DeviceIndex.build(chroms, k=K)
     offs = W.make_offsets(L, K, 1.9)
     out, st, again = _map(di, pairs, offs, paired)
@@ -77,13 +78,20 @@ def test_full_size_reference_workload(name):
     top = out["sites"][:, 0]
     minScore = int(np.float32(0.56) * np.float32(70 + (L - 1) * 100))
     assert ((ns > 0) & (top["slowScore"] >= minScore)).mean() > 0.99
-    if truth is None:
-        truth = {"start1": top["start"][0::2], "start2": top["start"][1::2], "strand1": top["strand"][0::2], "strand2": top["strand"][1::2]}
-    if not paired:
-        truth = {"start1": top["start"][0::2], "start2": top["start"][1::2], "strand1": top["strand"][0::2], "strand2": top["strand"][1::2]}
-    ok1 = (ns[0::2] > 0) & (np.abs(top["start"][0::2] - truth["start1"]) <= 40) & (top["strand"][0::2] == truth["strand1"])
-    ok2 = (ns[1::2] > 0) & (np.abs(top["start"][1::2] - truth["start2"]) <= 40) & (top["strand"][1::2] == truth["strand2"])
-    assert ok1.mean() > 0.97 and ok2.mean() > 0.97
+    if paired:
+        ok1 = (ns[0::2] > 0) & (top["chrom"][0::2] == truth["chrom"]) & (np.abs(top["start"][0::2] - truth["start1"]) <= 40) & (top["strand"][0::2] == truth["strand1"])
+        ok2 = (ns[1::2] > 0) & (top["chrom"][1::2] == truth["chrom"]) & (np.abs(top["start"][1::2] - truth["start2"]) <= 40) & (top["strand"][1::2] == truth["strand2"])
+        assert ok1.mean() > 0.97 and ok2.mean() > 0.97, (ok1.mean(), ok2.mean())
+    else:
+        ok = (ns > 0) & (top["chrom"] == truth["chrom"]) & (np.abs(top["start"] - truth["start1"]) <= 40) & (top["strand"] == truth["strand1"])
+        assert ok.mean() > 0.97, ok.mean()
+    # ... and in the records BBMap would print (the final alignment stage)
+    fin = out["final"]
+    if paired:
+        okf = (fin["mapped"][0::2] > 0) & (fin["chrom"][0::2] == truth["chrom"]) & (np.abs(fin["start"][0::2] - truth["start1"]) <= 40) & (fin["strand"][0::2] == truth["strand1"])
+    else:
+        okf = (fin["mapped"] > 0) & (fin["chrom"] == truth["chrom"]) & (np.abs(fin["start"] - truth["start1"]) <= 40) & (fin["strand"] == truth["strand1"])
+    assert okf.mean() > 0.97, okf.mean()
 
     # 4. a sample against the oracle
     oi = B.oracle_index(di, chroms, K)
