@@ -121,8 +121,11 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
             c->stripLds = (cfg->maxColumns + 2) * 4 + ((cfg->maxColumns + 2 + 7) & ~7);     // horizLimit ints + reference bytes
             const void *kfn = bbmsa::strip_kernel_pacbio();
             if (c->stripLds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, c->stripLds));
-            int per = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kfn, 64, c->stripLds));
+            // Resident wavefronts per CU, from the LDS a wavefront takes (160 KB per CU; the kernel holds ~128 VGPRs, up to 4 waves per
+            // SIMD, so LDS is what limits it).  Not asked of hipOccupancyMaxActiveBlocksPerMultiprocessor: that query was seen to fail with
+            // hipErrorUnknown depending on what the process had done before (after the CPU oracle had run in it), for reasons the
+            // runtime's log does not give; nothing here depends on the exact figure (the pipelined form no longer assumes co-residency).
+            int per = (160 * 1024) / (c->stripLds + 512);
             if (per < 1) per = 1;
             if (per > 8) per = 8;
             c->stripBlocks = c->numCUs * per;
@@ -136,8 +139,7 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
             {   // the pipelined form for launches with few jobs: the strips of one job in `strips` wavefronts
                 const void *kp = bbmsa::strip_kernel_pacbio_pipelined();
                 if (c->stripLds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, c->stripLds));
-                int perP = 0;
-                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perP, kp, 64, c->stripLds));
+                int perP = (160 * 1024) / (c->stripLds + 512);
                 if (perP < 1) perP = 1;
                 if (perP > 8) perP = 8;
                 c->pipeK = strips;
@@ -324,6 +326,8 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
         sp.bandwidth = c->cfg.bandwidth; sp.bandwidthRatio = c->cfg.bandwidthRatio;
         long long sblocks = n_jobs < c->stripBlocks ? n_jobs : c->stripBlocks;
         sp.pipeK = 0; sp.pipeSlots = 0; sp.pipeBoundary = nullptr; sp.pipeSync = nullptr;
+        sp.pipeSpinLimit = env_int("BBMSA_PIPE_SPIN_LIMIT", 1 << 21);          // polls before a wave of the pipelined form gives up (~3 s; tests force timeouts)
+        if (sp.pipeSpinLimit < 1) sp.pipeSpinLimit = 1;
         sp.pipeSpinLimit = env_int("BBMSA_PIPE_SPIN_LIMIT", 1 << 21);          // polls before a wave of the pipelined form gives up (~3 s; tests force timeouts)
         if (sp.pipeSpinLimit < 1) sp.pipeSpinLimit = 1;
         void *sargs[] = {&sp};

@@ -11,7 +11,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.golden_phix import fixture_runs, truth_window_scores      # noqa: E402
+from tests.golden_phix import fixture_runs, fixture_runs_pacbio, truth_window_scores, truth_window_scores_pacbio      # noqa: E402
 
 if __name__ == "__main__":
     table = {"runs": {}, "final": {}, "truth_window": {}}
@@ -27,6 +27,15 @@ if __name__ == "__main__":
                                if out["nsites"][i] > 0 else [int(out["nsites"][i]), 0, 0, 0, 0] for i in range(len(top))]
     for which in (1, 2):
         table["truth_window"]["sample%d" % which] = truth_window_scores(which)
+    # the same reads through mapPacBio's classes (BBIndexPacBio, BBMapThreadPacBio, MultiStateAligner9PacBio): top sites after scoreSlow
+    table["pacbio_runs"], table["pacbio_truth_window"] = {}, {}
+    for name, run in fixture_runs_pacbio().items():
+        out = run["oracle"]()
+        top = out["sites"][:, 0]
+        table["pacbio_runs"][name] = [[int(out["nsites"][i]), int(top["strand"][i]), int(top["start"][i]), int(top["stop"][i]), int(top["slowScore"][i])]
+                                      if out["nsites"][i] > 0 else [int(out["nsites"][i]), 0, 0, 0, 0] for i in range(len(top))]
+    for which in (1, 2):
+        table["pacbio_truth_window"]["sample%d" % which] = truth_window_scores_pacbio(which)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "phix_expected.json")
     with open(path, "w") as f:
         json.dump(table, f, separators=(",", ":"))

@@ -129,3 +129,52 @@ def truth_window_scores(which):
         sv, _ = msa.fillAndScoreLimited(rd, ref, a, b, floor)
         out.append(None if sv is None else [int(sv[0]), int(sv[1]), int(sv[2])])
     return out
+
+
+# ---------------------------------------------------------------------------------------------- the same fixture through mapPacBio's classes
+PACBIO_MSA = dict(msaMaxRows=160, msaMaxColumns=7600)         # BBMapThreadPacBio's 7600 columns; rows cut to the fixture's reads (memory)
+
+
+def fixture_runs_pacbio():
+    """The fixture's reads mapped as mapPacBio.sh would map them (100-base reads are legal input to BBMapPacBio): BBIndexPacBio's
+    constants (k 12, key density 3.5 / 2.8 / 4.5), BBMapThreadPacBio's single-ended flow, MultiStateAligner9PacBio.  Four runs:
+    sample1 / sample2, keys placed from the qualities or as for quality-less input.  name -> {"inputs", "oracle"}."""
+    from bbmap_amd import keys as K
+    from oracle import oracle as O
+    ref = phix_reference()
+    cfg = K.default_config(K.PROFILE_PACBIO)
+    runs = {}
+    for mode in ("se1", "se2"):
+        for use_q in (False, True):
+            reads, quals, _ = fixture_inputs(mode, use_q)
+            recs, blob, bs, ki = K.make_batch(reads, quals, cfg)
+
+            def oracle(recs=recs, blob=blob, bs=bs, ki=ki):
+                oi = O.OracleIndex([ref], profile="pacbio")
+                return O.map_reads(oi, recs, blob, ki, base_scores=bs, paired=False, cap=64, params=O.map_default_params("pacbio", **PACBIO_MSA))
+            runs["%s_%s" % (mode, "qual" if use_q else "noqual")] = {"inputs": (recs, blob, bs, ki, False), "oracle": oracle}
+    return runs
+
+
+def truth_window_jobs_pacbio(which):
+    """As truth_window_jobs with BBMapThreadPacBio's numbers: SLOW_ALIGN_PADDING 8, minMsaLimit = -CLEARZONE1e + (int)(0.46 * maxSwScore)
+    with CLEARZONE1e = 2 * 100 - 90 + 137 + 1 = 248 and maxSwScore = 90 + 99 * 100 (MultiStateAligner9PacBio.java:2377-2380)."""
+    reads, truth = sample_reads(which)
+    max_sw = 90 + 99 * 100
+    floor = -248 + int(np.float32(0.46) * np.float32(max_sw))
+    jobs = []
+    for i in range(len(reads)):
+        rd = _revcomp(reads[i]) if truth["strand"][i] else reads[i]
+        jobs.append((rd.tobytes(), int(truth["start"][i]) - 8, int(truth["stop"][i]) + 8, floor))
+    return jobs
+
+
+def truth_window_scores_pacbio(which):
+    from oracle import oracle as O
+    ref = phix_reference().tobytes()
+    msa = O.OracleMSA(160, 7600, scheme="9pacbio")
+    out = []
+    for rd, a, b, floor in truth_window_jobs_pacbio(which):
+        sv, _ = msa.fillAndScoreLimited(rd, ref, a, b, floor)
+        out.append(None if sv is None else [int(sv[0]), int(sv[1]), int(sv[2])])
+    return out

@@ -25,7 +25,8 @@ import os
 import numpy as np
 import pytest
 
-from tests.golden_phix import (HERE, fixture_runs, phix_reference, sample_reads, truth_window_jobs, truth_window_scores)
+from tests.golden_phix import (HERE, PACBIO_MSA, fixture_runs, fixture_runs_pacbio, phix_reference, sample_reads, truth_window_jobs,
+                               truth_window_jobs_pacbio, truth_window_scores, truth_window_scores_pacbio)
 
 FLOORS = {      # (mapped, strict, loose) of a sample's 100 reads, as the restatement gives them: asserted as floors against the truth
     ("se", 1): (99, 86, 98), ("se", 2): (98, 79, 95),       # mapped on their own (sample2 with quality-placed keys: 95 loose, 96 without)
@@ -193,6 +194,88 @@ def test_mapper_never_loses_to_the_truth_window(runs, expected):
     # minimum score; as a mate, rescue finds [11767, 11863] (5,135 points), again short of the deletion.  With the quality-less
     # key offsets the same read comes home at 6,993 points.  Every other read of every run holds the property.
     assert sorted((m[0], m[1], m[2]) for m in missed) == [("pe_qual", 2, 43), ("se2_qual", 2, 43)], missed
+
+
+# ---------------------------------------------------------------------------------------------- mapPacBio's classes on the same fixture
+# BBIndexPacBio / BBMapThreadPacBio / MultiStateAligner9PacBio have no reference-held vector of their own; the fixture's 100-base reads are
+# legal input to mapPacBio.sh, so its truth pins these classes' constants too: floors by the reference's correctness rules, the
+# truth-window property with the 9PacBio scores, a per-read table.
+FLOORS_PACBIO = {1: (100, 80, 99), 2: (98, 78, 97)}          # (mapped, strict, loose) per sample; keys from qualities or not: the same
+# reads whose list holds no site covering the truth (BBIndexPacBio's MAX_INDEL is 100: a 100-200-base deletion is not ONE site there,
+# the probe reports the longer half): the heuristic's misses, not the DP's -- listed so that a new one shows
+PACBIO_UNCOVERED = {1: [4, 9, 23, 24, 32, 48, 62, 77], 2: [44, 46, 47, 62, 63, 73, 79, 85]}
+
+
+@pytest.fixture(scope="module")
+def pacbio_runs():
+    r = fixture_runs_pacbio()
+    for v in r.values():
+        v["out"] = v["oracle"]()
+    return r
+
+
+def _check_pacbio(name, out, expected, tw):
+    which = int(name[2])
+    _, truth = sample_reads(which)
+    got = _score_against_truth(out["sites"], out["nsites"], truth)
+    assert all(g >= f for g, f in zip(got, FLOORS_PACBIO[which])), (name, got)
+    top = out["sites"][:, 0]
+    for i, exp in enumerate(expected["pacbio_runs"][name]):
+        ns = int(out["nsites"][i])
+        g = [ns, int(top["strand"][i]), int(top["start"][i]), int(top["stop"][i]), int(top["slowScore"][i])] if ns > 0 else [ns, 0, 0, 0, 0]
+        assert g == exp, "%s read %d: %s, table %s" % (name, i, g, exp)
+    worse, uncovered = [], []
+    for i, t in enumerate(tw["sample%d" % which]):
+        if t is None:
+            continue
+        n = max(int(out["nsites"][i]), 0)
+        best = int(out["sites"][i]["slowScore"][:n].max()) if n else -1
+        if best >= t[0]:
+            continue
+        s = out["sites"][i][:n]
+        covered = bool(((s["strand"] == truth["strand"][i]) & (s["start"] <= t[1]) & (s["stop"] >= t[2])).any()) if n else False
+        (worse if covered else uncovered).append(i)
+    assert not worse, (name, worse)
+    assert uncovered == PACBIO_UNCOVERED[which], (name, uncovered)
+
+
+def test_pacbio_classes_meet_the_fixture_truth(pacbio_runs, expected):
+    tw = {"sample1": truth_window_scores_pacbio(1), "sample2": truth_window_scores_pacbio(2)}
+    assert tw == expected["pacbio_truth_window"]
+    for name, r in pacbio_runs.items():
+        _check_pacbio(name, r["out"], expected, tw)
+        assert len(r["out"]["log"]) > 50                   # MultiStateAligner9PacBio fills ran
+
+
+@pytest.mark.gpu
+def test_device_pacbio_mapper_equals_oracle_on_the_fixture(pacbio_runs, expected):
+    """The four runs through the device's mapPacBio profile (long-read probe kernel, strip-tiled 9PacBio DP): equal to the oracle compiled
+    with -DORC_PACBIO fill by fill, hence to the floors, the table and the property; the truth-window fills on the device equal the oracle's."""
+    from bbmap_amd import msa as M
+    from bbmap_amd.index import DeviceIndex, PROFILE_PACBIO
+    from bbmap_amd.mapper import Mapper
+    from tests.mapper_check import compare
+    ref = phix_reference()
+    di = DeviceIndex.build([ref], profile=PROFILE_PACBIO)
+    tw = expected["pacbio_truth_window"]
+    for name, r in pacbio_runs.items():
+        recs, blob, bs, ki, _ = r["inputs"]
+        mp = Mapper.from_records(di, recs, blob, bs, ki, paired=False, max_sites=32, profile=PROFILE_PACBIO, msaMaxColumns=PACBIO_MSA["msaMaxColumns"])
+        mp.step()
+        out, st = mp.fetch(), mp.stats()
+        mp.close()
+        assert st["reads_overflowed"] == 0
+        bad = compare(out, r["out"], len(recs), False)
+        assert not bad, name + "\n" + "\n".join(bad[:20])
+        _check_pacbio(name, out, expected, tw)
+    di.close()
+    al = M.MultiStateAligner9PacBio(160, 7600)
+    for which in (1, 2):
+        probs = [(rd, ref.tobytes(), a, b, floor) for rd, a, b, floor in truth_window_jobs_pacbio(which)]
+        got = al.align(probs, M.FILL_AND_SCORE_LIMITED)
+        for g, t in zip(got, tw["sample%d" % which]):
+            assert (None if g["score"] is None else g["score"][:3]) == t
+    al.ctx.close()
 
 
 @pytest.mark.gpu
