@@ -168,7 +168,6 @@ struct NarrowParams {
     int bandwidth;
     float bandwidthRatio;
     int maxSlack;                 // candidate filter: maxQuality(rows) - minScore (points) at most this
-    int tightSlack;               // BBMSA_NO_ITERATIONS jobs beyond maxSlack are first tried with minScore = maxQuality - this
 };
 
 struct GenericParams {

@@ -27,7 +27,7 @@ struct bbmsa_ctx {
     unsigned int *d_wideDir;
     int *d_slowList2;
     // narrow-window kernel (msa_fill_narrow.hip): one job per lane
-    int narrowBlocks, narrowSlack, tightSlack;     // 0 blocks = disabled
+    int narrowBlocks, narrowSlack;     // 0 blocks = disabled
     unsigned long long *d_narrowDir;
     int *d_fastList;
     long long fastCap;

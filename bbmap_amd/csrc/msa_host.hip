@@ -244,7 +244,6 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     // narrow-window kernel: only without a band (a band changes the window rule); BBMSA_NARROW=0 disables it
     c->narrowBlocks = 0;
     c->narrowSlack = env_int("BBMSA_NARROW_SLACK", 2000);
-    c->tightSlack = env_int("BBMSA_TIGHT_SLACK", 900);     // a 16-diagonal band holds windows up to ~1000 points of slack
     if (!c->banded && env_int("BBMSA_NARROW", 1) != 0) {
         int perCU = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)bbmsa::msa_fill_narrow_kernel, 64, 0));
@@ -328,8 +327,6 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
         sp.pipeK = 0; sp.pipeSlots = 0; sp.pipeBoundary = nullptr; sp.pipeSync = nullptr;
         sp.pipeSpinLimit = env_int("BBMSA_PIPE_SPIN_LIMIT", 1 << 21);          // polls before a wave of the pipelined form gives up (~3 s; tests force timeouts)
         if (sp.pipeSpinLimit < 1) sp.pipeSpinLimit = 1;
-        sp.pipeSpinLimit = env_int("BBMSA_PIPE_SPIN_LIMIT", 1 << 21);          // polls before a wave of the pipelined form gives up (~3 s; tests force timeouts)
-        if (sp.pipeSpinLimit < 1) sp.pipeSpinLimit = 1;
         void *sargs[] = {&sp};
         if (!n_jobs_dev && c->pipeJobsMax > 0 && n_jobs <= c->pipeJobsMax) {
             // few jobs (the late scoreSlow rounds of mapPacBio): a lone 6,000 x 6,100 fill is one wavefront's dependent chain, 370 ms;
@@ -375,7 +372,7 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
         np.queue = c->d_counters + 3; np.fast_list = c->d_fastList; np.fast_count = c->d_counters + 4;
         np.dirbuf = c->d_narrowDir; np.stats = c->d_counters + 5;
         np.match_stride = match_stride; np.maxRows = c->cfg.maxRows; np.maxColumns = c->cfg.maxColumns;
-        np.bandwidth = c->cfg.bandwidth; np.bandwidthRatio = c->cfg.bandwidthRatio; np.maxSlack = c->narrowSlack; np.tightSlack = c->tightSlack;
+        np.bandwidth = c->cfg.bandwidth; np.bandwidthRatio = c->cfg.bandwidthRatio; np.maxSlack = c->narrowSlack;
         long long nb = (n_jobs + 63) / 64;
         if (nb > c->narrowBlocks) nb = c->narrowBlocks;
         hipLaunchKernelGGL(bbmsa::msa_fill_narrow_kernel, dim3((unsigned)nb), dim3(64), 0, stream, np);

@@ -52,10 +52,9 @@ enum {
     BBMSA_CLAMP_WINDOW = 1 << 3,  /* a=max(0,start), b=min(ref_len-1,end), MSA.java:104-105,118-121 */
     BBMSA_DO_SCORE     = 1 << 4,  /* run score2 on a non-null fill                                  */
     BBMSA_DO_TRACEBACK = 1 << 5,  /* run traceback2 on a non-null fill, write the match string      */
-    BBMSA_NO_ITERATIONS = 1 << 6, /* the caller does not need result.iterations (the counter the native code adds to       */
-                                  /* iterationsLimited, used by the Java side for verbose statistics only): the library may  */
-                                  /* then fill with a tighter minScore first and reports iterations = -1 when it did;        */
-                                  /* result[], status, score[] and the match string are unchanged                            */
+    BBMSA_NO_ITERATIONS = 1 << 6, /* the caller does not need result.iterations.  Accepted and without effect: until ABI 6 the     */
+                                  /* library first tried such a job with a tighter minScore; fillLimitedX's pruning turned out not */
+                                  /* to be admissible (a tighter bound can change a non-null result), so it never does now          */
     BBMSA_TRACE_KEEP_GAPS = 1 << 7, /* traceback: leave each gap symbol '-' of a gapped reference in the match string instead of expanding
                                     * it to 128 'D' (MultiStateAligner11tsJNI.java:481-493): the string then always fits rows + columns
                                     * bytes, and the caller expands it (a 16 kb deletion is 125 symbols, 16,000 'D') */

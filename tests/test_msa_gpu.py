@@ -367,10 +367,11 @@ def test_wide_pass_takes_windows_beyond_the_first_column_buffer():
     assert counts["generic"] == 0, counts
 
 
-def test_no_iterations_mode_keeps_scores_and_match_strings():
-    """BBMSA_NO_ITERATIONS lets the library try a tighter minScore first (narrow-window kernel).  Everything except the
-    visited-cell counter must stay bit-identical to the exact fill -- also where many alignments tie (low-complexity
-    sequence: indels inside homopolymers and dinucleotide repeats can be placed in several equally good ways)."""
+def test_no_iterations_flag_changes_nothing():
+    """BBMSA_NO_ITERATIONS is accepted and has no effect (the tighter-bound shortcut it used to allow was withdrawn: the
+    reference's pruning is not admissible, tests/test_oracle_final.py::test_a_tighter_min_score_can_change_a_fill).  Checked
+    where many alignments tie (low-complexity sequence: indels inside homopolymers and dinucleotide repeats can be placed in
+    several equally good ways): every field, the visited-cell counter included, and the split over the kernels stay the same."""
     import random
     from oracle.oracle import OracleMSA
     rng = random.Random(2024)
@@ -413,15 +414,9 @@ def test_no_iterations_mode_keeps_scores_and_match_strings():
     split_exact = al.ctx.last_counts()
     relaxed = al.align(probs, flags | M.NO_ITERATIONS)
     split_relaxed = al.ctx.last_counts()
-    assert split_relaxed["narrow"] > split_exact["narrow"] + 300, (split_exact, split_relaxed)     # the shortcut is really taken
-    shortcut = 0
+    assert split_relaxed == split_exact, (split_exact, split_relaxed)
     for e, r in zip(exact, relaxed):
-        assert (r["status"], r["result"], r["score"], r["match"]) == (e["status"], e["result"], e["score"], e["match"])
-        if r["iterations"] == -1:
-            shortcut += 1
-        else:
-            assert r["iterations"] == e["iterations"]
-    assert shortcut > 300
+        assert (r["status"], r["result"], r["score"], r["match"], r["iterations"]) == (e["status"], e["result"], e["score"], e["match"], e["iterations"])
     om = OracleMSA(160, 320)                                             # and the exact run is the oracle's, on a sample
     for p, e in list(zip(probs, exact))[:400]:
         sv, mx = om.fillAndScoreLimited(*p)

@@ -129,3 +129,41 @@ def test_rare_branches_are_reachable():
             if f["mapped"][i] and 0 < f["match_len"][i] <= fm.shape[1]:
                 rd, rf = _consumes(fm[i][:f["match_len"][i]].tobytes())
                 assert rd == L and rf == f["stop"][i] - f["start"][i] + 1, (cols, i, fm[i][:f["match_len"][i]].tobytes(), f[i])
+
+
+def test_a_tighter_min_score_can_change_a_fill():
+    """Why no kernel here ever substitutes a tighter minScore for the caller's: the pruning of fillLimitedX
+    (MultiStateAligner11tsJNI.c fillLimitedX, restated in oracle/msa11ts_oracle.c) is not admissible.  Re-running realign_new's own
+    fills on tip-damaged reads with minScore set 400 points BELOW the score the fill found returns null for some and, for a few, a
+    different non-null alignment with a lower score -- so a result obtained under a tighter bound proves nothing about the result under
+    the caller's bound (the narrow-window kernel's BBMSA_NO_ITERATIONS shortcut of rounds 2-3 and a 'known score' bound for the
+    final stage were both withdrawn over this)."""
+    from tests.test_final_gpu import _problem
+    ref, oi, reads, recs, offs, ks, s, ns = _problem(False, 1200, 40, 3)
+    orc = O.final_reads(oi, recs, reads.reshape(-1), s, ns, paired=False, params=O.map_default_params(msaMaxColumns=601, alignColumns=601))
+    msa = O.OracleMSA(601, 601)
+    refb = ref.tobytes()
+    comp = np.full(256, ord("N"), np.uint8)
+    for x, y in zip(b"ACGTN", b"TGCAN"):
+        comp[x] = y
+    tried = null = other = 0
+    for e in orc["log"]:
+        if e["kind"] not in (3, 4, 5) or e["ngaps"] or e["score_len"] <= 0:
+            continue
+        sc = int(e["score"][0])
+        if sc - 400 <= int(e["minScore"]):
+            continue
+        rd = reads[int(e["read"])]
+        if e["strand"]:
+            rd = comp[rd[::-1]]
+        a, b = int(e["refStartLoc"]), int(e["refEndLoc"])
+        loose, _ = msa.fillAndScoreLimited(rd.tobytes(), refb, a, b, int(e["minScore"]))
+        assert [int(x) for x in loose[:3]] == [int(x) for x in e["score"][:3]]              # (the log's result is reproducible)
+        tight, _ = msa.fillAndScoreLimited(rd.tobytes(), refb, a, b, sc - 400)
+        tried += 1
+        if tight is None:
+            null += 1
+        elif [int(x) for x in tight[:3]] != [int(x) for x in loose[:3]]:
+            other += 1
+            assert int(tight[0]) < int(loose[0])
+    assert tried > 500 and null > 20 and other > 5, (tried, null, other)
