@@ -32,6 +32,8 @@
 #include "index_ctx.h"
 
 void bbmap_set_error(const char *msg);
+void bbmsa_use_narrow(bbmsa_ctx *c, bool on);          // msa_host.hip (internal, see msa_ctx.h)
+int bbmsa_wait_first_pass(bbmsa_ctx *c, void *waiter);
 
 namespace bbmapper {
 
@@ -1351,7 +1353,14 @@ static int grow_logs(bbmap_ctx *c, hipStream_t stream, bbmapper::Dev &D, long lo
 }
 
 // launches the DP over the fills appended since (jobBase, gjobBase)
-static int run_fills(bbmap_ctx *c, hipStream_t stream, const uint8_t *bases, long long jobBase, long long nNew, long long gBase, long long gNew) {
+static int run_fills(bbmap_ctx *c, hipStream_t stream, const uint8_t *bases, long long jobBase, long long nNew, long long gBase, long long gNew,
+                     bool finalStage = false) {
+    // The one-job-per-lane narrow kernel runs in front of the wavefront kernel on the same stream and is a ~1.5 ms dependent chain
+    // however few jobs there are: worth it only for the big first rounds of scoreSlow (163 k of 459 k fills finish there in 4.8 ms
+    // on the bench workload).  The final stage's fills never fit its band (see msa_ctx.h), nor do the second context's wide windows.
+    static const long long narrowMin = getenv("BBMAP_NARROW_MIN_JOBS") ? atoll(getenv("BBMAP_NARROW_MIN_JOBS")) : 32768;
+    bbmsa_use_narrow(c->msa, !finalStage && nNew >= narrowMin);
+    if (c->msaGapped != c->msa) bbmsa_use_narrow(c->msaGapped, false);
     // the second context's launches first, on their own stream: its blocks take their share of the CUs and the plain context's
     // persistent blocks fill the rest (and the slots the others free)
     hipStream_t gs = (c->dpStream && nNew > 0) ? c->dpStream : stream;
@@ -1359,7 +1368,7 @@ static int run_fills(bbmap_ctx *c, hipStream_t stream, const uint8_t *bases, lon
         if (gs != stream) { MHIP(hipEventRecord(c->evFork, stream)); MHIP(hipStreamWaitEvent(gs, c->evFork, 0)); }
         MTRY(bbmsa_align_gapped_batch_device(c->msaGapped, gs, gNew, c->d_gjobs + gBase, c->d_ggaps + gBase, bases, c->refsBase,
                                              c->d_gresults + gBase, c->d_gmatch + gBase * c->gmatchStride, c->gmatchStride));
-        if (gs != stream) MHIP(hipEventRecord(c->evJoin, gs));
+        if (gs != stream) { MHIP(hipEventRecord(c->evJoin, gs)); if (nNew > 0) MTRY(bbmsa_wait_first_pass(c->msaGapped, stream)); }
     }
     if (nNew > 0)
         MTRY(bbmsa_align_batch_device(c->msa, stream, nNew, c->d_jobs + jobBase, bases, c->refsBase, c->d_results + jobBase,
@@ -1413,7 +1422,7 @@ static int run_final_stage(bbmap_ctx *c, hipStream_t stream, bbmapper::Dev &D, i
             add_dp_ms(c, ranPlain, ranGapped);
             const long long asked = c->h_counters[0], gasked = c->h_counters[1];
             const long long total = asked < c->jobCap ? asked : c->jobCap, gtotal = gasked < c->gjobCap ? gasked : c->gjobCap;
-            MTRY(run_fills(c, stream, bases, jobBase, total - jobBase, gBase, gtotal - gBase));
+            MTRY(run_fills(c, stream, bases, jobBase, total - jobBase, gBase, gtotal - gBase, true));
             ranPlain = total > jobBase; ranGapped = gtotal > gBase;
             jobBase = total; gBase = gtotal;
             if (asked > c->jobCap || gasked > c->gjobCap) {

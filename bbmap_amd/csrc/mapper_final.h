@@ -330,13 +330,19 @@ __device__ void fix_limits_xy(const Dev &D, Site &ss) {                         
 __device__ int score_no_indels_match(const Settings &S, const uint8_t *read, int len, const uint8_t *ref, int reflen, int refStart, uint8_t *match) {
     if (refStart < 0 || refStart + len > reflen) return -99999;
     int score = 0, mode = -1, t = 0;
+    unsigned *mw = reinterpret_cast<unsigned *>(match);              // (pool strings start on a 4-byte boundary: four symbols per store)
+    unsigned acc = 0;
     for (int i = 0; i < len; i++) {
         const int c = read[i], r = ref[refStart + i];
-        if (c == r && c != 'N') { if (mode == 0) { t++; score += S.ptsMatch2; } else { t = 0; score += S.ptsMatch; } match[i] = 'm'; mode = 0; }
-        else if (c >= 128 || c == 'N') match[i] = 'N';
-        else if (r >= 128 || r == 'N') match[i] = 'N';
-        else { match[i] = 'S'; if (mode == 1) t++; else t = 0; score += (t + 1 > 5 ? S.ptsSub3 : (t + 1 > 1 ? S.ptsSub2 : S.ptsSub)); mode = 1; }
+        unsigned sym;
+        if (c == r && c != 'N') { if (mode == 0) { t++; score += S.ptsMatch2; } else { t = 0; score += S.ptsMatch; } sym = 'm'; mode = 0; }
+        else if (c >= 128 || c == 'N') sym = 'N';
+        else if (r >= 128 || r == 'N') sym = 'N';
+        else { sym = 'S'; if (mode == 1) t++; else t = 0; score += (t + 1 > 5 ? S.ptsSub3 : (t + 1 > 1 ? S.ptsSub2 : S.ptsSub)); mode = 1; }
+        acc |= sym << (8 * (i & 3));
+        if ((i & 3) == 3) { mw[i >> 2] = acc; acc = 0; }
     }
+    for (int i = len & ~3; i < len; i++) match[i] = (uint8_t)(acc >> (8 * (i & 3)));
     return score;
 }
 
@@ -627,7 +633,9 @@ __device__ bool final_advance(const Dev &D, long long r, FinalRead &f, PreAlloc 
                 const int ref = pool_take(D, pre, L);
                 if (!ref) { D.mcount[r] = n; return true; }
                 uint8_t *m = pool_ptr(D, ref);
-                for (int q = 0; q < L; q++) m[q] = 'm';
+                unsigned *mw = reinterpret_cast<unsigned *>(m);                 // (4-byte aligned, see pool_units)
+                for (int q = 0; q < (L >> 2); q++) mw[q] = 0x6d6d6d6du;
+                for (int q = L & ~3; q < L; q++) m[q] = 'm';
                 site_set_match(ss, ref, L); s[cur] = ss;
                 f.pc = PC_GEN_CLIP;
             } else {

@@ -27,7 +27,7 @@ constexpr int kGapLen = 128;
 constexpr int kTableLen = 3072;       // upper bound of the delC / insC LDS tables: index time (<2048) + rows (<=640)
 // A context's tables only need min(longer side + 2, 2048) + maxRows + 8 entries: a streak (time) never exceeds the longer
 // matrix side + 1 (and is clamped below 2048), the "still needed" indel length never exceeds the rows.  Ints of LDS in front of the per-job areas:
-__host__ __device__ inline int lds_table_ints(int tableLen) { return 2 * tableLen + 256; }   // + delExt[128], insExt[32], subExt[8] (padded)
+__host__ __device__ inline int lds_table_ints(int tableLen) { return 2 * tableLen + 320; }   // + delExt[128], insExt[32], subExt[8] (padded to 192), mTab[32][4]
 
 // closed forms of calcDelScoreOffset (jni/...c:316-336) and of the cumulative
 // POINTSoff_INS_ARRAY_C table (MultiStateAligner11tsJNI.java:1582-1601)

@@ -28,6 +28,8 @@ struct bbmsa_ctx {
     int *d_slowList2;
     // narrow-window kernel (msa_fill_narrow.hip): one job per lane
     int narrowBlocks, narrowSlack;     // 0 blocks = disabled
+    bool narrowOff;                    // switched off by the caller for launches whose jobs it cannot take (bbmsa_use_narrow)
+    bool narrowUsed;                   // whether the last launch ran it
     unsigned long long *d_narrowDir;
     int *d_fastList;
     long long fastCap;
@@ -51,6 +53,16 @@ struct bbmsa_ctx {
     int *d_pipeBoundary, *d_pipeSync;
 };
 
+
+// Internal (mapper.hip).  The mapper switches the narrow kernel off for launches it cannot help: small ones (one job per lane is a
+// ~1.5 ms dependent chain however few jobs there are, in front of the wavefront kernel on the same stream) and the final alignment
+// stage's (realign_new pads its windows by >= 6 columns and passes minScore - 120: no such fill fits the 16-diagonal band).
+void bbmsa_use_narrow(bbmsa_ctx *c, bool on);
+// Makes `waiter` (a stream) wait until the context's last launch sequence has reached its first wavefront pass.  The mapper's two
+// contexts run side by side; the second one's sequence begins with make_gref_kernel, and if the first context's persistent blocks
+// are resident on every CU by then, the second context's passes (among them the latency-bound wide pass, which needs something
+// to overlap with) only start when those drain: measured, the final stage 86 -> 93 ms.
+int bbmsa_wait_first_pass(bbmsa_ctx *c, void *waiter);
 
 // msa_legacy.hip: persistent buffers, stream and the call combiner of a BBMSA_LEGACY_ONLY context (c->d_matrix / d_limits exist)
 int bbmsa_legacy_create(bbmsa_ctx *c);

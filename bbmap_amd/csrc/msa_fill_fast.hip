@@ -78,6 +78,10 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
     int *delExt = lds + 2 * TL;       // jni/...c:229-233 as a table of the streak (index <= 83)
     int *insExt = delExt + 128;               // POINTSoff_INS_ARRAY[streak+1], index min(streak,20)
     int *subExt = insExt + 32;                // POINTSoff_SUB_ARRAY[streak+1], index min(streak,5)
+    // The match/substitution plane's three case distinctions as ONE 16-byte lookup: index = min(streak, 5) | match << 3 | prevMatch << 4,
+    // entry = {points of staying in the plane (jni/...c:497-531), points of entering it from D / I (MATCH or SUB), what the prune
+    // test subtracts from the limit (MATCH2 or SUB3, :486), 0}.  Five selects and two compares per cell less than spelling it out.
+    int4 *mTab = reinterpret_cast<int4 *>(delExt + 192);
     for (int i = threadIdx.x; i < TL; i += blockDim.x) {
         delC[i] = calc_del_off(i);
         insC[i] = calc_ins_cum_off(i);
@@ -85,6 +89,14 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
     for (int i = threadIdx.x; i < 128; i += blockDim.x) delExt[i] = del_extend(i);
     if (threadIdx.x < 32) insExt[threadIdx.x] = ins_extend(threadIdx.x);
     if (threadIdx.x < 8) subExt[threadIdx.x] = sub_extend(threadIdx.x);
+    if (threadIdx.x < 32) {
+        const int st = threadIdx.x & 7, mt = (threadIdx.x >> 3) & 1, pv = threadIdx.x >> 4;
+        int4 e;
+        if (mt) { e.x = pv ? P_MATCH2 : P_MATCH; e.y = P_MATCH; e.z = P_MATCH2; }
+        else { e.x = pv ? (st <= 1 ? P_SUBR : P_SUB) : sub_extend(min(st, 5)); e.y = P_SUB; e.z = P_SUB3; }
+        e.w = 0;
+        mTab[threadIdx.x] = e;
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
         int delForce[R];                 // INT_MAX where the deletion barrier applies (row<3 || row>rows-3), else INT_MIN
         int insHiForce[R];               // INT_MAX where row > rows-2 (insertion barrier near the end), else INT_MIN
         unsigned dacc[R];
-        int mPrev[R];                    // match(row k, previous column) as 0/1 (kept in a VGPR: SGPR masks are scarce)
+        int mPrev[R];                    // match(row k, previous column) as 8/0: bit 3 of the mTab index (a VGPR: SGPR masks are scarce)
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const int row = r0 + k;
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
             pM[k] = c0v; pD[k] = c0v; pI[k] = c0v;
             minGood[k] = -1; maxGood[k] = -2; dacc[k] = 0;
             vlimP[k] = rowValid[k] ? vlim[k] + 2048 : (1 << 30);     // above every reachable packed value
-            mPrev[k] = (call1[k] == '!') ? 1 : 0;                        // ref0 of column 1 is '!' (jni/...c:463)
+            mPrev[k] = (call1[k] == '!') ? 8 : 0;                        // ref0 of column 1 is '!' (jni/...c:463)
             delForce[k] = (row < 3 || row > rows - 3) ? INT_MAX : INT_MIN;
             insHiForce[k] = (row > rows - 2) ? INT_MAX : INT_MIN;
         }
@@ -330,7 +342,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
             int dgM = svM, dgD = svD, dgI = svI;
             svM = upM; svD = upD; svI = upI;
             bool started = upMin >= 0;
-            bool prevMatch = (call0First == ref0) & (ref0 != 'N');
+            int pm8 = ((call0First == ref0) & (ref0 != 'N')) ? 8 : 0;      // prevMatch of my first row, as mPrev holds it
 
 #pragma unroll
             for (int k = 0; k < R; k++) {
@@ -357,15 +369,15 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const int streakM = dgM & kTimeMask;
                 const int sdm = dgM & kScoreMask;
                 const int mDI = max(dgD, dgI) & kScoreMask;
-                const int t3 = max(floorP, limitP - (match ? P_MATCH2 : P_SUB3));
+                const bool prevMatch = pm8 != 0;
+                const int mb8 = match ? 8 : 0;
+                int4 mt = mTab[min(streakM, 5) | mb8 | (pm8 << 1)];
+                asm volatile("" : "+v"(mt.x), "+v"(pen0));
+                const int t3 = max(floorP, limitP - mt.z);
                 const bool pruneM = !act | gap | (max(dgM, max(dgD, dgI)) < t3);      // (bitwise: no short-circuit branches)
-                int subx = subExt[min(streakM, 5)];
-                asm volatile("" : "+v"(subx), "+v"(pen0));
-                int addA = prevMatch ? (streakM <= 1 ? P_SUBR : P_SUB) : subx;
-                addA = (refN | (cl1 == 'N')) ? 0 : addA;
-                addA = match ? (prevMatch ? P_MATCH2 : P_MATCH) : addA;
+                const int addA = (refN | (cl1 == 'N')) ? 0 : mt.x;                    // (a match has neither base N)
                 const int sa = sdm + addA;
-                const int sbc = mDI + (match ? P_MATCH : P_SUB);
+                const int sbc = mDI + mt.y;
                 const bool aWinsM = sa >= sbc;
                 const int scoreM = max(sa, sbc);
                 const int timeM = (aWinsM & (match == prevMatch)) ? streakM + 1 : 1;
@@ -440,9 +452,8 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 upM = nM; upI = nI;
                 started = minGood[k] >= 0;
                 if (BANDED) upMaxG = maxGood[k];
-                const int mp = mPrev[k];
-                mPrev[k] = match ? 1 : 0;
-                prevMatch = mp != 0;
+                pm8 = mPrev[k];
+                mPrev[k] = mb8;
             }
             lastRef = ref1;
 

@@ -242,7 +242,7 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
         }
     }
     // narrow-window kernel: only without a band (a band changes the window rule); BBMSA_NARROW=0 disables it
-    c->narrowBlocks = 0;
+    c->narrowBlocks = 0; c->narrowOff = false; c->narrowUsed = false;
     c->narrowSlack = env_int("BBMSA_NARROW_SLACK", 2000);
     if (!c->banded && env_int("BBMSA_NARROW", 1) != 0) {
         int perCU = 0;
@@ -366,7 +366,9 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
     //           [5] jobs finished by the narrow kernel, [6] candidates it handed on
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 64, stream));
     HIP_TRY(hipEventRecord(c->ev[0], stream));
-    if (c->narrowBlocks > 0) {
+    const bool useNarrow = c->narrowBlocks > 0 && !c->narrowOff;
+    c->narrowUsed = useNarrow;
+    if (useNarrow) {
         bbmsa::NarrowParams np;
         np.jobs = jobs; np.reads = reads; np.refs = refs; np.results = results; np.match = match; np.njobs = n_jobs; np.njobs_dev = n_jobs_dev;
         np.queue = c->d_counters + 3; np.fast_list = c->d_fastList; np.fast_count = c->d_counters + 4;
@@ -384,7 +386,7 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
     fp.jobs = jobs; fp.reads = reads; fp.refs = refs; fp.results = results; fp.match = match;
     fp.njobs = n_jobs; fp.njobs_dev = n_jobs_dev;
     fp.queue = c->d_counters; fp.dirbuf = c->d_dir; fp.dir_slot_dwords = c->dirSlotDwords;
-    fp.list = c->narrowBlocks > 0 ? c->d_fastList : nullptr; fp.list_count = c->d_counters + 4;
+    fp.list = useNarrow ? c->d_fastList : nullptr; fp.list_count = c->d_counters + 4;
     fp.slow_list = c->d_slowList; fp.slow_count = c->d_counters + 1;
     fp.match_stride = match_stride; fp.lanesPerJob = c->G; fp.fastCols = c->fastCols; fp.tmpBytes = c->tmpBytes; fp.tableLen = c->tableLen;
     fp.maxRows = c->cfg.maxRows; fp.maxColumns = c->cfg.maxColumns;
@@ -424,6 +426,13 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
     return BBMAP_OK;
 }
 
+void bbmsa_use_narrow(bbmsa_ctx *c, bool on) { if (c) c->narrowOff = !on; }
+int bbmsa_wait_first_pass(bbmsa_ctx *c, void *waiter) {
+    if (!c || !c->timed) return BBMAP_OK;
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)waiter, c->ev[3], 0));       // recorded right in front of the last launch's first pass
+    return BBMAP_OK;
+}
+
 extern "C" int bbmsa_last_kernel_ms(bbmsa_ctx *c, float *ms_fast, float *ms_slow) {
     if (!c || !c->timed) return fail(BBMAP_E_ARG, "bbmsa_last_kernel_ms: nothing launched yet");
     HIP_TRY(hipSetDevice(c->device));
@@ -452,7 +461,7 @@ extern "C" int bbmsa_last_counts(bbmsa_ctx *c, int64_t *counts4) {
     HIP_TRY(hipEventSynchronize(c->ev[2]));
     unsigned h[16];
     HIP_TRY(hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
-    counts4[0] = h[5]; counts4[1] = h[6]; counts4[2] = c->narrowBlocks > 0 ? h[4] : 0; counts4[3] = c->wideBlocks > 0 ? h[7] : h[1];
+    counts4[0] = h[5]; counts4[1] = h[6]; counts4[2] = c->narrowUsed ? h[4] : 0; counts4[3] = c->wideBlocks > 0 ? h[7] : h[1];
     if (getenv("BBMAP_DP_COUNTS") && c->wideBlocks > 0) fprintf(stderr, "   (first pass handed %u jobs to the wide pass)\n", h[1]);
     return BBMAP_OK;
 }
