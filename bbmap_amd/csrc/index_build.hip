@@ -4,10 +4,10 @@
 // Every step is a bandwidth-bound pass over the genome or over the 4^k key space, so the whole build runs in HBM and
 // nothing but the length histogram (a few thousand counters) comes back to the host:
 //   1. emit: one thread per genome position packs its k bases into a key (invalid when a base is undefined or the
-//      k-mer is banned: period <= 2, IndexMaker4.java:327-339) and bumps the per-key counter of its block;
+//      k-mer is banned: period <= 2, IndexMaker4.java:327-339);
 //   2. a stable LSD radix sort (rocPRIM through hipCUB) of (key, site) pairs on the low 2k bits keeps genome order
 //      inside every list, which is the order IndexMaker4's one-thread-per-list fill produces;
-//   3. an exclusive prefix sum of the counters gives Block.starts;
+//   3. Block.starts are the run boundaries of the sorted keys (no counters, no prefix sum);
 //   4. COUNTS[key] = len(key) + len(rc(key)) over all blocks (palindromes once), "clumpy" keys zeroed
 //      (BBIndex.java:125-153);
 //   5. the site-weighted length histogram (Tools.makeLengthHistogram3, current/align2/Tools.java:1797-1850) is
@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -32,47 +33,63 @@ void bbmap_set_error(const char *msg);
 namespace bbidxb {
 using namespace bbidx;
 
-// one thread per position of one chromosome: key (or 0xFFFFFFFF) and encoded site
-__global__ void emit_kernel(const uint8_t *chrom, int len, int k, int chromNumber, int shift, int lowMask,
-                            unsigned *keys, int *sites, unsigned *counts32, unsigned long long *defined) {
-    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// one thread per position of one chromosome: key (or 0xFFFFFFFF) and encoded site.  The block's 256 + k - 1 bases are turned into
+// 2-bit codes once, in LDS (one coalesced load per base instead of k loads per position).  No per-key counter is bumped here: list
+// lengths come out of the sort (starts_from_sorted_kernel) -- 770 M atomics on a 268 MB table per block were a third of the build.
+__global__ __launch_bounds__(256) void emit_kernel(const uint8_t *chrom, int len, int k, int chromNumber, int shift, int lowMask,
+                                                   unsigned *keys, int *sites, unsigned long long *defined) {
+    __shared__ int8_t code[256 + 16];
     const int npos = len - k;
     unsigned long long def = 0;
-    if (a < len) def = base_num(chrom[a]) >= 0 ? 1ull : 0ull;
-    // block-level count of defined bases
+    // grid-stride over 256-position tiles: the count of defined bases stays in a register and costs one atomic per wave at the very
+    // end (one per wave and tile -- 12 M same-address atomics per block of the hg38 shape -- was 80 % of the whole build)
+    for (long long base = (long long)blockIdx.x * 256; base < len; base += (long long)gridDim.x * 256) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 256 + k - 1; i += 256) code[i] = base + i < len ? (int8_t)base_num(chrom[base + i]) : (int8_t)-1;
+        __syncthreads();
+        const long long a = base + threadIdx.x;
+        def += (a < len && code[threadIdx.x] >= 0) ? 1ull : 0ull;
+        if (a >= npos) continue;
+        unsigned key = 0;
+        bool valid = true;
+        for (int j = 0; j < k; j++) {
+            const int x = code[threadIdx.x + j];
+            valid = valid && x >= 0;
+            key = (key << 2) | (unsigned)(x & 3);
+        }
+        if (valid) {
+            const unsigned banmask = (1u << (2 * k - 4)) - 1u;
+            if ((key >> 4) == (key & banmask)) valid = false;              // homopolymers and dinucleotide repeats
+        }
+        keys[a] = valid ? key : 0xFFFFFFFFu;
+        sites[a] = ((chromNumber & lowMask) << shift) | (int)a;
+    }
     for (int d = 32; d >= 1; d >>= 1) def += __shfl_xor(def, d, 64);
     if ((threadIdx.x & 63) == 0 && def) atomicAdd(defined, def);
-    if (a >= npos) return;
-    unsigned key = 0;
-    bool valid = true;
-    for (int j = 0; j < k; j++) {
-        const int x = base_num(chrom[a + j]);
-        if (x < 0) { valid = false; break; }
-        key = (key << 2) | (unsigned)x;
-    }
-    if (valid) {
-        const unsigned banmask = (1u << (2 * k - 4)) - 1u;
-        if ((key >> 4) == (key & banmask)) valid = false;              // homopolymers and dinucleotide repeats
-    }
-    keys[a] = valid ? key : 0xFFFFFFFFu;
-    sites[a] = ((chromNumber & lowMask) << shift) | (int)a;
-    if (valid) atomicAdd(&counts32[key], 1u);
 }
 
-// moves the valid pairs to the front of the key order: an invalid pair sorts (on the low 2k bits) as the all-T k-mer,
-// which is banned and therefore owns no list, so everything after `nvalid` is padding
-__global__ void counts_to_starts_in(const unsigned *counts32, int *scanIn, long long nkeys) {
+// Block.starts from the sorted keys: starts[key] = index of the first pair whose key is >= key, starts[4^k] = number of valid pairs.
+// An invalid pair (0xFFFFFFFF) sorts, on the low 2k bits, as the all-T k-mer, which is banned and owns no list: everything from the
+// first invalid pair on is padding.  Thread i fills the keys in (key[i-1], key[i]]: an empty range inside a list, the keys without a
+// list in front of a list's first pair; thread npos closes the table.
+__global__ void starts_from_sorted_kernel(const unsigned *keysSorted, long long npos, int *starts, long long nkeys) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nkeys) scanIn[i] = (int)counts32[i];
+    if (i > npos) return;
+    long long cur = nkeys, prev = -1;
+    if (i < npos) { const unsigned v = keysSorted[i]; if (v != 0xFFFFFFFFu) cur = (long long)v; }
+    if (i > 0) { const unsigned v = keysSorted[i - 1]; prev = v != 0xFFFFFFFFu ? (long long)v : nkeys; }
+    for (long long kk = prev + 1; kk <= cur; kk++) starts[kk] = (int)i;
 }
-__global__ void accumulate_counts(const unsigned *counts32, unsigned long long *total, long long nkeys) {
+__global__ void accumulate_counts(const int *starts, unsigned long long *total, long long nkeys) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nkeys && counts32[i]) total[i] += counts32[i];
+    if (i >= nkeys) return;
+    const int n = starts[i + 1] - starts[i];
+    if (n) total[i] += (unsigned long long)n;
 }
 // BBIndex.java:125-143: adjacent entries of one list 1..5 bases apart
-__global__ void clump_kernel(const unsigned *keysSorted, const int *sitesSorted, long long nvalid, int k, unsigned *clump) {
+__global__ void clump_kernel(const unsigned *keysSorted, const int *sitesSorted, const int *nvalidDev, int k, unsigned *clump) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x + 1;
-    if (i >= nvalid) return;
+    if (i >= (long long)*nvalidDev) return;
     if (keysSorted[i] != keysSorted[i - 1]) return;
     const long long dif = (long long)sitesSorted[i] - (long long)sitesSorted[i - 1];
     if (dif > 0 && dif <= 5) {
@@ -191,11 +208,16 @@ extern "C" int bbidx_build_profile(int32_t device, int32_t profile, int32_t k, i
     if (device < 0 || device >= ndev) { bbmap_set_error("bbidx_build: bad device ordinal"); return BBMAP_E_ARG; }
     int rc = BBMAP_OK;
     bbidx_ctx *c = nullptr;
-    unsigned *d_keys = nullptr, *d_keys2 = nullptr, *d_cnt32 = nullptr, *d_clump = nullptr;
-    int *d_sites2 = nullptr, *d_scanIn = nullptr, *d_max = nullptr, *d_countsRaw = nullptr;
+    unsigned *d_keys = nullptr, *d_keys2 = nullptr, *d_clump = nullptr;
+    int *d_sites2 = nullptr, *d_max = nullptr, *d_countsRaw = nullptr;
     unsigned long long *d_total = nullptr, *d_defined = nullptr, *d_bins = nullptr;
     void *d_tmp = nullptr;
-    size_t tmpCap = 0;
+    hipStream_t cs = nullptr, us = nullptr;             // kernels / uploads
+    std::vector<hipEvent_t> evUp;
+    const bool timers = getenv("BBIDX_BUILD_TIMERS") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    double msUpload = 0;
     {
         if (hipSetDevice(device) != hipSuccess) { bbmap_set_error("bbidx_build: hipSetDevice failed"); return BBMAP_E_HIP; }
         hipDeviceProp_t prop;
@@ -220,95 +242,106 @@ extern "C" int bbidx_build_profile(int32_t device, int32_t profile, int32_t k, i
         c->dev.p.k = k; c->dev.p.chromBits = chromBits; c->dev.p.minChrom = 1; c->dev.p.maxChrom = nchroms; c->dev.p.profile = profile; c->dev.p.reserved = 0;
         c->dev.nblocks = nblocks; c->dev.nchroms = nchroms;
 
-        std::vector<const uint8_t *> hc((size_t)nchroms + 1, nullptr);
-        for (int ch = 1; ch <= nchroms; ch++) {
-            void *d = nullptr;
-            BHIP(hipMalloc(&d, (size_t)(chromArrLen[ch] > 0 ? chromArrLen[ch] : 1)));
-            c->allocs.push_back(d);
-            if (chromArrLen[ch] > 0) BHIP(hipMemcpy(d, chromArr[ch], (size_t)chromArrLen[ch], hipMemcpyHostToDevice));
-            hc[(size_t)ch] = (const uint8_t *)d;
-        }
-        BHIP(hipMalloc(&d_cnt32, (size_t)nkeys * 4));
-        BHIP(hipMalloc(&d_scanIn, (size_t)(nkeys + 1) * 4));
-        BHIP(hipMalloc(&d_total, (size_t)nkeys * 8));
-        BHIP(hipMalloc(&d_clump, (size_t)nkeys * 4));
-        BHIP(hipMalloc(&d_defined, 8));
-        BHIP(hipMalloc(&d_max, 4));
-        BHIP(hipMemset(d_total, 0, (size_t)nkeys * 8));
-        BHIP(hipMemset(d_clump, 0, (size_t)nkeys * 4));
-        BHIP(hipMemset(d_defined, 0, 8));
-        BHIP(hipMemset(d_max, 0, 4));
-
-        std::vector<const int *> hs((size_t)nblocks, nullptr), hsi((size_t)nblocks, nullptr);
+        // Per block: positions, and the largest block sizes the work buffers (allocated once: a hipFree per block is a device-wide
+        // synchronisation, and the next block's chromosomes are meant to upload while this block sorts)
+        std::vector<long long> blockPos((size_t)nblocks, 0);
+        long long maxPos = 0;
         for (int b = 0; b < nblocks; b++) {
             const int first = b * cpb > 1 ? b * cpb : 1, last = (b * cpb + cpb - 1) < nchroms ? (b * cpb + cpb - 1) : nchroms;
             long long npos = 0;
             for (int ch = first; ch <= last; ch++) npos += chromArrLen[ch] > k ? chromArrLen[ch] - k : 0;
             if (npos > 0x7fffffffLL - 64) { bbmap_set_error("bbidx_build: more than 2^31 - 64 positions in one block"); rc = BBMAP_E_ARG; goto fail; }   // (cursor look-ahead stays in int range)
-            c->totalSites += npos;
-            BHIP(hipMemset(d_cnt32, 0, (size_t)nkeys * 4));
+            blockPos[(size_t)b] = npos; c->totalSites += npos;
+            if (npos > maxPos) maxPos = npos;
+        }
+        BHIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        BHIP(hipStreamCreateWithFlags(&us, hipStreamNonBlocking));
+        std::vector<const uint8_t *> hc((size_t)nchroms + 1, nullptr);
+        for (int ch = 1; ch <= nchroms; ch++) {
+            void *d = nullptr;
+            BHIP(hipMalloc(&d, (size_t)(chromArrLen[ch] > 0 ? chromArrLen[ch] : 1)));
+            c->allocs.push_back(d);
+            hc[(size_t)ch] = (const uint8_t *)d;
+        }
+        BHIP(hipMalloc(&d_total, (size_t)nkeys * 8));
+        BHIP(hipMalloc(&d_clump, (size_t)nkeys * 4));
+        BHIP(hipMalloc(&d_defined, 8));
+        BHIP(hipMalloc(&d_max, 4));
+        BHIP(hipMemsetAsync(d_total, 0, (size_t)nkeys * 8, cs));
+        BHIP(hipMemsetAsync(d_clump, 0, (size_t)nkeys * 4, cs));
+        BHIP(hipMemsetAsync(d_defined, 0, 8, cs));
+        BHIP(hipMemsetAsync(d_max, 0, 4, cs));
+        BHIP(hipMalloc(&d_keys, (size_t)(maxPos > 0 ? maxPos : 1) * 4));
+        BHIP(hipMalloc(&d_keys2, (size_t)(maxPos > 0 ? maxPos : 1) * 4));
+        BHIP(hipMalloc(&d_sites2, (size_t)(maxPos > 0 ? maxPos : 1) * 4));
+        size_t tmpNeed = 0;
+        if (maxPos > 0) {
+            BHIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpNeed, d_keys, d_keys2, d_sites2, (int *)d_sites2, (int)maxPos, 0, 2 * k, cs));
+            BHIP(hipMalloc(&d_tmp, tmpNeed));
+        }
+
+        std::vector<const int *> hs((size_t)nblocks, nullptr), hsi((size_t)nblocks, nullptr);
+        evUp.resize((size_t)nblocks, nullptr);
+        for (int b = 0; b < nblocks; b++) {
+            const int first = b * cpb > 1 ? b * cpb : 1, last = (b * cpb + cpb - 1) < nchroms ? (b * cpb + cpb - 1) : nchroms;
+            const long long npos = blockPos[(size_t)b];
+            // this block's chromosomes go up on the upload stream while the previous block is still being sorted on the other
+            const double u0 = since();
+            for (int ch = first; ch <= last; ch++)
+                if (chromArrLen[ch] > 0) BHIP(hipMemcpyAsync((void *)hc[(size_t)ch], chromArr[ch], (size_t)chromArrLen[ch], hipMemcpyHostToDevice, us));
+            BHIP(hipEventCreateWithFlags(&evUp[(size_t)b], hipEventDisableTiming));
+            BHIP(hipEventRecord(evUp[(size_t)b], us));
+            msUpload += since() - u0;
+            BHIP(hipStreamWaitEvent(cs, evUp[(size_t)b], 0));
             int *d_sites = nullptr, *d_starts = nullptr;
             BHIP(hipMalloc(&d_starts, (size_t)(nkeys + 1) * 4)); c->allocs.push_back(d_starts);
             BHIP(hipMalloc(&d_sites, (size_t)(npos > 0 ? npos : 1) * 4)); c->allocs.push_back(d_sites);
-            BHIP(hipMalloc(&d_keys, (size_t)(npos > 0 ? npos : 1) * 4));
-            BHIP(hipMalloc(&d_keys2, (size_t)(npos > 0 ? npos : 1) * 4));
-            BHIP(hipMalloc(&d_sites2, (size_t)(npos > 0 ? npos : 1) * 4));
             long long off = 0;
             for (int ch = first; ch <= last; ch++) {
                 const int len = chromArrLen[ch];
                 if (len <= 0) continue;
-                const unsigned eb = (unsigned)((len + 255) / 256);
-                hipLaunchKernelGGL(bbidxb::emit_kernel, dim3(eb), dim3(256), 0, nullptr, hc[(size_t)ch], len, k, ch, shift, lowMask,
-                                   d_keys + off, d_sites2 + off, d_cnt32, d_defined);
+                unsigned eb = (unsigned)((len + 255) / 256);
+                if (eb > 8192u) eb = 8192u;
+                hipLaunchKernelGGL(bbidxb::emit_kernel, dim3(eb), dim3(256), 0, cs, hc[(size_t)ch], len, k, ch, shift, lowMask,
+                                   d_keys + off, d_sites2 + off, d_defined);
                 BHIP(hipGetLastError());
                 off += len > k ? len - k : 0;
             }
             if (npos > 0) {
-                size_t need = 0;
-                BHIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, d_keys, d_keys2, d_sites2, d_sites, (int)npos, 0, 2 * k, nullptr));
-                if (need > tmpCap) { if (d_tmp) (void)hipFree(d_tmp); d_tmp = nullptr; BHIP(hipMalloc(&d_tmp, need)); tmpCap = need; }
-                BHIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, need, d_keys, d_keys2, d_sites2, d_sites, (int)npos, 0, 2 * k, nullptr));
+                size_t need = tmpNeed;
+                BHIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, need, d_keys, d_keys2, d_sites2, d_sites, (int)npos, 0, 2 * k, cs));
             }
-            hipLaunchKernelGGL(bbidxb::counts_to_starts_in, dim3(kb), dim3(256), 0, nullptr, d_cnt32, d_scanIn, nkeys);
-            BHIP(hipMemset(d_scanIn + nkeys, 0, 4));
-            {
-                size_t need = 0;
-                BHIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_scanIn, d_starts, (int)(nkeys + 1), nullptr));
-                if (need > tmpCap) { if (d_tmp) (void)hipFree(d_tmp); d_tmp = nullptr; BHIP(hipMalloc(&d_tmp, need)); tmpCap = need; }
-                BHIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, need, d_scanIn, d_starts, (int)(nkeys + 1), nullptr));
-            }
-            hipLaunchKernelGGL(bbidxb::accumulate_counts, dim3(kb), dim3(256), 0, nullptr, d_cnt32, d_total, nkeys);
-            int nvalid = 0;
-            BHIP(hipMemcpy(&nvalid, d_starts + nkeys, 4, hipMemcpyDeviceToHost));
-            if (nvalid > 1) {
-                hipLaunchKernelGGL(bbidxb::clump_kernel, dim3((unsigned)((nvalid + 255) / 256)), dim3(256), 0, nullptr,
-                                   d_keys2, d_sites, (long long)nvalid, k, d_clump);
-            }
+            hipLaunchKernelGGL(bbidxb::starts_from_sorted_kernel, dim3((unsigned)((npos + 1 + 255) / 256)), dim3(256), 0, cs, d_keys2, npos, d_starts, nkeys);
+            hipLaunchKernelGGL(bbidxb::accumulate_counts, dim3(kb), dim3(256), 0, cs, d_starts, d_total, nkeys);
+            if (npos > 1)
+                hipLaunchKernelGGL(bbidxb::clump_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, cs,
+                                   d_keys2, d_sites, d_starts + nkeys, k, d_clump);
             BHIP(hipGetLastError());
-            BHIP(hipDeviceSynchronize());
-            (void)hipFree(d_keys); d_keys = nullptr; (void)hipFree(d_keys2); d_keys2 = nullptr; (void)hipFree(d_sites2); d_sites2 = nullptr;
             hs[(size_t)b] = d_starts; hsi[(size_t)b] = d_sites;
         }
         // COUNTS, clumpy keys, length histogram
         int *d_counts = nullptr;
         BHIP(hipMalloc(&d_counts, (size_t)nkeys * 4)); c->allocs.push_back(d_counts);
         BHIP(hipMalloc(&d_countsRaw, (size_t)nkeys * 4));
-        hipLaunchKernelGGL(bbidxb::combine_counts, dim3(kb), dim3(256), 0, nullptr, d_total, d_countsRaw, k, nkeys);
-        BHIP(hipMemcpy(d_counts, d_countsRaw, (size_t)nkeys * 4, hipMemcpyDeviceToDevice));
-        hipLaunchKernelGGL(bbidxb::zero_clumpy, dim3(kb), dim3(256), 0, nullptr, d_clump, d_countsRaw, d_counts, k, nkeys,
+        hipLaunchKernelGGL(bbidxb::combine_counts, dim3(kb), dim3(256), 0, cs, d_total, d_countsRaw, k, nkeys);
+        BHIP(hipMemcpyAsync(d_counts, d_countsRaw, (size_t)nkeys * 4, hipMemcpyDeviceToDevice, cs));
+        hipLaunchKernelGGL(bbidxb::zero_clumpy, dim3(kb), dim3(256), 0, cs, d_clump, d_countsRaw, d_counts, k, nkeys,
                            profile == BBIDX_PROFILE_PACBIO ? 2800 : 2000, profile == BBIDX_PROFILE_PACBIO ? 0.8f : 0.75f);   // CLUMPY_MIN_LENGTH_INDEX, CLUMPY_FRACTION
-        hipLaunchKernelGGL(bbidxb::max_kernel, dim3(2048), dim3(256), 0, nullptr, d_counts, nkeys, d_max);
+        hipLaunchKernelGGL(bbidxb::max_kernel, dim3(2048), dim3(256), 0, cs, d_counts, nkeys, d_max);
         BHIP(hipGetLastError());
         int mx = 0;
-        BHIP(hipMemcpy(&mx, d_max, 4, hipMemcpyDeviceToHost));
+        BHIP(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, cs));
+        BHIP(hipStreamSynchronize(cs));
+        const double msLists = since();
         BHIP(hipMalloc(&d_bins, (size_t)(mx + 1) * 8));
-        BHIP(hipMemset(d_bins, 0, (size_t)(mx + 1) * 8));
-        hipLaunchKernelGGL(bbidxb::bincount_kernel, dim3(2048), dim3(256), 0, nullptr, d_counts, nkeys, d_bins, mx + 1);
+        BHIP(hipMemsetAsync(d_bins, 0, (size_t)(mx + 1) * 8, cs));
+        hipLaunchKernelGGL(bbidxb::bincount_kernel, dim3(2048), dim3(256), 0, cs, d_counts, nkeys, d_bins, mx + 1);
         BHIP(hipGetLastError());
         std::vector<unsigned long long> bins((size_t)mx + 1);
-        BHIP(hipMemcpy(bins.data(), d_bins, (size_t)(mx + 1) * 8, hipMemcpyDeviceToHost));
+        BHIP(hipMemcpyAsync(bins.data(), d_bins, (size_t)(mx + 1) * 8, hipMemcpyDeviceToHost, cs));
         unsigned long long defined = 0;
-        BHIP(hipMemcpy(&defined, d_defined, 8, hipMemcpyDeviceToHost));
+        BHIP(hipMemcpyAsync(&defined, d_defined, 8, hipMemcpyDeviceToHost, cs));
+        BHIP(hipStreamSynchronize(cs));
         int hist[1001];
         length_histogram(bins, mx, hist);
         derive_params(c->dev.p, (long long)defined, hist);
@@ -332,21 +365,31 @@ extern "C" int bbidx_build_profile(int32_t device, int32_t profile, int32_t k, i
             up(clen.data(), clen.size() * 4, (const void **)&c->dev.chromLengths) != BBMAP_OK) {
             bbmap_set_error("bbidx_build: device allocation failed"); rc = BBMAP_E_HIP; goto fail;
         }
+        const double msStats = since();
         rc = bbidx_finish_create(c, hs, hsi);
         if (rc != BBMAP_OK) goto fail;
+        if (timers) fprintf(stderr, "bbidx_build: lists of %d block(s) %.1f ms (of which the host spent %.1f ms handing chromosomes to the upload stream), "
+                                    "COUNTS / histogram %.1f ms, fused key tables %.1f ms\n", nblocks, msLists, msUpload, msStats - msLists, since() - msStats);
     }
+    for (hipEvent_t e : evUp) if (e) (void)hipEventDestroy(e);
+    if (cs) (void)hipStreamDestroy(cs);
+    if (us) (void)hipStreamDestroy(us);
     if (d_tmp) (void)hipFree(d_tmp);
-    (void)hipFree(d_cnt32); (void)hipFree(d_scanIn); (void)hipFree(d_total); (void)hipFree(d_clump); (void)hipFree(d_defined);
+    (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_sites2);
+    (void)hipFree(d_total); (void)hipFree(d_clump); (void)hipFree(d_defined);
     (void)hipFree(d_max); (void)hipFree(d_countsRaw); if (d_bins) (void)hipFree(d_bins);
     *out = c;
     return BBMAP_OK;
 fail:
+    if (cs) (void)hipStreamSynchronize(cs);
+    if (us) (void)hipStreamSynchronize(us);
+    for (hipEvent_t e : evUp) if (e) (void)hipEventDestroy(e);
+    if (cs) (void)hipStreamDestroy(cs);
+    if (us) (void)hipStreamDestroy(us);
     if (d_tmp) (void)hipFree(d_tmp);
     if (d_keys) (void)hipFree(d_keys);
     if (d_keys2) (void)hipFree(d_keys2);
     if (d_sites2) (void)hipFree(d_sites2);
-    if (d_cnt32) (void)hipFree(d_cnt32);
-    if (d_scanIn) (void)hipFree(d_scanIn);
     if (d_total) (void)hipFree(d_total);
     if (d_clump) (void)hipFree(d_clump);
     if (d_defined) (void)hipFree(d_defined);
