@@ -373,8 +373,14 @@ __device__ int gref_limit(const Site &ss, int a, int b) {
     return gpos;
 }
 
-// one fill of realign_new appended to the plain or the wide log (kind 3 first fill, 4 padded refill, 5 third fill, 6 fillUnlimited)
-__device__ int emit_final_fill(const Dev &D, long long r, const bbidx_read &rr, const Site &ss, int site, int minLoc, int maxLoc, int minscore, int kind, int seq) {
+// one fill of realign_new for the plain or the wide log (kind 3 first fill, 4 padded refill, 5 third fill, 6 fillUnlimited).  The
+// slot comes from the caller: final_round_kernel takes a wavefront's slots with ONE atomicAdd per log (570 k same-address atomics,
+// one per fill, made the first round's kernel 8.5 ms).
+__device__ inline bool final_fill_is_wide(const Dev &D, const Site &ss, int minLoc, int maxLoc) {
+    return ss.ngaps || (maxLoc - minLoc + 1) > D.plainColumns;
+}
+__device__ void write_final_fill(const Dev &D, long long r, const bbidx_read &rr, const Site &ss, int site, int minLoc, int maxLoc, int minscore, int kind, int seq,
+                                 bool wide, unsigned k) {
     bbmap_jobinfo info; info.read = (int)r; info.seq = seq; info.kind = kind; info.site = site;
     bbmsa_job j;
     j.read_off = rr.bases_off + (ss.strand ? D.minusDelta : 0);
@@ -383,19 +389,12 @@ __device__ int emit_final_fill(const Dev &D, long long r, const bbidx_read &rr, 
     j.refStartLoc = minLoc; j.refEndLoc = maxLoc; j.minScore = minscore;
     // (gap symbols stay compact in the log's string: a long deletion's 'D's would not fit its slot; the pool copy expands them)
     j.flags = (kind == 6 ? BBMSA_FILL_UNLIMITED_RAW : BBMSA_FILL_LIMITED) | BBMSA_DO_SCORE | BBMSA_DO_TRACEBACK | BBMSA_TRACE_KEEP_GAPS;
-    if (ss.ngaps || (maxLoc - minLoc + 1) > D.plainColumns) {
-        const unsigned k = atomicAdd(&D.counters[1], 1u);
-        if ((long long)k >= D.gjobCap) return NO_ROOM;
+    if (wide) {
         D.gjobs[k] = j; D.ginfo[k] = info;
         bbmsa_gaps g; g.ngaps = ss.ngaps;
         for (int q = 0; q < BBMSA_MAX_GAPS; q++) g.gaps[q] = q < ss.ngaps ? ss.gaps[q] : 0;
         D.ggaps[k] = g;
-        return (int)k | GAPPED_BIT;
-    }
-    const unsigned k = atomicAdd(&D.counters[0], 1u);
-    if ((long long)k >= D.jobCap) return NO_ROOM;
-    D.jobs[k] = j; D.jinfo[k] = info;
-    return (int)k;
+    } else { D.jobs[k] = j; D.jinfo[k] = info; }
 }
 __device__ inline const uint8_t *fill_match(const Dev &D, int job) {
     return (job & GAPPED_BIT) ? D.gmatch + (long long)(job & ~GAPPED_BIT) * D.gmatchStride : D.match + (long long)job * D.matchStride;
@@ -608,7 +607,7 @@ __global__ __launch_bounds__(128) void final_begin_kernel(const Dev D) {
 
 // ---------------------------------------------------------------------------------------------- kernel 2: one round of genMatchString
 // Advances a read until it needs a fill (returns true: still active) or has finished genMatchString (PC_DONE).
-__device__ bool final_advance(const Dev &D, long long r, FinalRead &f, PreAlloc &pre) {
+__device__ bool final_advance(const Dev &D, long long r, FinalRead &f, PreAlloc &pre, bool &wantEmit) {
     const Settings &S = D.S;
     const bbidx_read rr = D.reads[r];
     const int L = rr.len, maxSw = max_quality(S, L), maxI = max_imperfect(S, L);
@@ -675,13 +674,10 @@ __device__ bool final_advance(const Dev &D, long long r, FinalRead &f, PreAlloc 
             }
             break;
         }
-        case PC_EMIT_FILL: {
-            const int job = emit_final_fill(D, r, rr, s[cur], cur, f.minLoc, f.maxLoc, f.fillKind == 6 ? 0 : f.minscore, f.fillKind, f.seq);
+        case PC_EMIT_FILL:                                                      // the kernel emits (a wavefront's fills together) and parks the read
             D.mcount[r] = n;
-            if (job == NO_ROOM) return true;                                    // log full: the same step next round
-            f.seq++; f.pending = job; f.pc = PC_FILL_BACK;
-            return true;                                                        // wait for the DP
-        }
+            wantEmit = true;
+            return true;
         case PC_FILL_BACK: {                                                    // a fill came back (:371-483, :523-622)
             const bbmsa_result &res = fill_result(D, f.pending);
             const int nsc = res.status == BBMSA_ST_OK ? res.score_len : 0;
@@ -877,7 +873,27 @@ __global__ __launch_bounds__(128) void final_round_kernel(const Dev D) {
         if (total) { if (lane == 0) base = pool_alloc_units(D, total); base = __shfl(base, 0, 64); }
         if (base && units) { pre.ref = base + (int)(incl - units); pre.units = units; }
     }
-    if (f.pc != PC_DONE) { stillActive = final_advance(D, r, f, pre); D.fin[r] = f; }
+    bool wantEmit = false;
+    if (f.pc != PC_DONE) stillActive = final_advance(D, r, f, pre, wantEmit);
+    {   // the fills this wavefront asks for: one atomicAdd per log, slots by rank.  A slot beyond the log's capacity is not written: the
+        // read stays in PC_EMIT_FILL and asks again next round, before which the host has grown the log (as NO_ROOM in emit_fill)
+        const int cur = f.sorting ? 0 : f.i;
+        bool wide = false;
+        if (wantEmit) wide = final_fill_is_wide(D, D.ms[r * D.cap + cur], f.minLoc, f.maxLoc);
+        const unsigned long long mp = __ballot(wantEmit && !wide), mg = __ballot(wantEmit && wide);
+        unsigned bp = 0, bg = 0;
+        if (mp) { if (lane == __builtin_ctzll(mp)) bp = atomicAdd(&D.counters[0], (unsigned)__builtin_popcountll(mp)); bp = __shfl(bp, __builtin_ctzll(mp)); }
+        if (mg) { if (lane == __builtin_ctzll(mg)) bg = atomicAdd(&D.counters[1], (unsigned)__builtin_popcountll(mg)); bg = __shfl(bg, __builtin_ctzll(mg)); }
+        if (wantEmit) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned k = wide ? bg + (unsigned)__builtin_popcountll(mg & below) : bp + (unsigned)__builtin_popcountll(mp & below);
+            if ((long long)k < (wide ? D.gjobCap : D.jobCap)) {
+                write_final_fill(D, r, D.reads[r], D.ms[r * D.cap + cur], cur, f.minLoc, f.maxLoc, f.fillKind == 6 ? 0 : f.minscore, f.fillKind, f.seq, wide, k);
+                f.seq++; f.pending = wide ? ((int)k | GAPPED_BIT) : (int)k; f.pc = PC_FILL_BACK;
+            }
+        }
+    }
+    if (r >= 0) D.fin[r] = f;
     const unsigned long long m = __ballot(stillActive);
     if (m) {
         unsigned base = 0;
