@@ -73,11 +73,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO_PATH):
+    so_path = os.environ.get("BBMAP_AMD_SO") or SO_PATH          # (experiments: a variant build, scripts/build_variant.py)
+    if not os.path.exists(so_path):
         raise BBMapAmdError(
             "libbbmap_amd.so is missing (%s). Build it with `python -m bbmap_amd.build`; "
-            "there is no CPU fallback." % SO_PATH)
-    L = C.CDLL(SO_PATH)
+            "there is no CPU fallback." % so_path)
+    L = C.CDLL(so_path)
     L.bbmap_last_error.restype = C.c_char_p
     L.bbmap_abi_version.restype = C.c_int
     L.bbmsa_create.argtypes = [C.POINTER(bbmsa_config), C.POINTER(C.c_void_p)]

@@ -20,6 +20,7 @@
 // Banded fills (MSA.bandwidth / bandwidthRatio > 0) and shapes beyond this kernel's limits are
 // handed to the generic kernel (msa_fill_generic.hip) through `slow_list`.
 #include "msa_common.h"
+#include "msa_cell.h"
 
 namespace bbmsa {
 
@@ -77,18 +78,17 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
     int *insC = lds + TL;
     int *delExt = lds + 2 * TL;       // jni/...c:229-233 as a table of the streak (index <= 83)
     int *insExt = delExt + 128;               // POINTSoff_INS_ARRAY[streak+1], index min(streak,20)
-    int *subExt = insExt + 32;                // POINTSoff_SUB_ARRAY[streak+1], index min(streak,5)
     // The match/substitution plane's three case distinctions as ONE 16-byte lookup: index = min(streak, 5) | match << 3 | prevMatch << 4,
     // entry = {points of staying in the plane (jni/...c:497-531), points of entering it from D / I (MATCH or SUB), what the prune
     // test subtracts from the limit (MATCH2 or SUB3, :486), 0}.  Five selects and two compares per cell less than spelling it out.
     int4 *mTab = reinterpret_cast<int4 *>(delExt + 192);
+    LdsPen pen; pen.delC = delC; pen.insC = insC; pen.delExt = delExt; pen.insExt = insExt; pen.mTab = mTab;
     for (int i = threadIdx.x; i < TL; i += blockDim.x) {
         delC[i] = calc_del_off(i);
         insC[i] = calc_ins_cum_off(i);
     }
     for (int i = threadIdx.x; i < 128; i += blockDim.x) delExt[i] = del_extend(i);
     if (threadIdx.x < 32) insExt[threadIdx.x] = ins_extend(threadIdx.x);
-    if (threadIdx.x < 8) subExt[threadIdx.x] = sub_extend(threadIdx.x);
     if (threadIdx.x < 32) {
         const int st = threadIdx.x & 7, mt = (threadIdx.x >> 3) & 1, pv = threadIdx.x >> 4;
         int4 e;
@@ -349,95 +349,30 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                 const int row = r0 + k;
                 bool act = inRange & (started | notLimited);              // rows beyond the read prune through vlimP
                 if (BANDED) act = act && (!banded || (c >= row - halfband && c <= upMaxG + 1));
-                const int cl1 = call1[k];
-                const bool match = (cl1 == ref1) & !refN;
-                const int limitP = max(vlimP[k], hlP);
-                const int limit = limitP - 2048;
-                const int delNeeded = max(0, row - c - 1);
-                const int insNeeded = max(0, (rows - row) - insNeededBase);
-                // A cell needs deletions (left of the corridor) or insertions (right of it), never both: jobs whose window is
-                // more than two columns narrower than the read, the only shape where both can hold, are handed on at job
-                // setup.  So one table serves the cell: X = delC or insC, pen0 = X[needed], and the "still needed after this
-                // streak" term X[time + needed] - X[time] of the plane that continues such a run.
-                const bool needDel = delNeeded > 0, needIns = insNeeded > 0;
-                const int need = delNeeded + insNeeded;
-                const int *X = needDel ? delC : insC;
-                int pen0 = X[need];
-                const int pruneVal = subfloor;                          // what an unvisited cell reads as
-
-                // ---- match / substitution plane
-                const int streakM = dgM & kTimeMask;
-                const int sdm = dgM & kScoreMask;
-                const int mDI = max(dgD, dgI) & kScoreMask;
-                const bool prevMatch = pm8 != 0;
-                const int mb8 = match ? 8 : 0;
-                int4 mt = mTab[min(streakM, 5) | mb8 | (pm8 << 1)];
-                asm volatile("" : "+v"(mt.x), "+v"(pen0));
-                const int t3 = max(floorP, limitP - mt.z);
-                const bool pruneM = !act | gap | (max(dgM, max(dgD, dgI)) < t3);      // (bitwise: no short-circuit branches)
-                const int addA = (refN | (cl1 == 'N')) ? 0 : mt.x;                    // (a match has neither base N)
-                const int sa = sdm + addA;
-                const int sbc = mDI + mt.y;
-                const bool aWinsM = sa >= sbc;
-                const int scoreM = max(sa, sbc);
-                const int timeM = (aWinsM & (match == prevMatch)) ? streakM + 1 : 1;
-                const int penM = pen0;
-                const bool goodM = !pruneM & (scoreM + penM >= limit);
-                const int nM = goodM ? (scoreM | timeM) : pruneVal;
-
-                // ---- deletion plane (same row, previous column)
-                const int streakD = pD[k] & kTimeMask;
-                const int slm = pM[k] & kScoreMask, sld = pD[k] & kScoreMask;
-                const bool pruneD = !act | (max(pM[k], pD[k]) < max(limitP, delForce[k]));
-                int dext = delExt[min(streakD, 80 | (streakD & 3))];
-                asm volatile("" : "+v"(dext));
-                const int dsa = slm + P_DEL;
-                const int dsb = sld + dext;
-                const bool aWinsD = dsa >= dsb;
-                const int scoreD = max(dsa, dsb) + refPen;
-                const int timeD = aWinsD ? 1 : streakD + 1;
-                // (penD and goodD follow the insertion plane: they share its table lookup)
-
-                // ---- insertion plane (row above, same column)
-                const int streakI = upI & kTimeMask;
-                const int sum = upM & kScoreMask, sui = upI & kScoreMask;
-                const int insForce = (k == 0) ? ((rowOne && cGt1) ? INT_MAX : min(insHiForce[k], cLtLastForce))
-                                              : min(insHiForce[k], cLtLastForce);
-                const bool pruneI = !act | gap | (max(upM, upI) < max(limitP, insForce));
-                int iext = insExt[min(streakI, 20)];
-                asm volatile("" : "+v"(iext));
-                const int isa = sum + P_INS;
-                const int isb = sui + iext;
-                const bool aWinsI = isa >= isb;
-                const int scoreI = max(isa, isb);
-                const int timeI = aWinsI ? 1 : streakI + 1;
-                const int timeX = needDel ? timeD : timeI;
-                int x2 = X[timeX + need] - X[timeX];                     // 0 when nothing is still needed
-                asm volatile("" : "+v"(x2));
-                const int penD = needIns ? pen0 : x2;
-                const bool goodD = !pruneD & (scoreD + penD >= limit);
-                const int nD = goodD ? (scoreD | (timeD > kMaxTime ? kMaxTime - 3 : timeD)) : pruneVal;
-                const int penI = needDel ? pen0 : x2;
-                const bool goodI = !pruneI & (scoreI + penI >= limit);
-                const int nI = goodI ? (scoreI | timeI) : pruneVal;
+                CellIn ci_;
+                ci_.row = row; ci_.c = c; ci_.rows = rows; ci_.insNeededBase = insNeededBase;
+                ci_.cl1 = call1[k]; ci_.ref1 = ref1; ci_.refN = refN; ci_.gap = gap; ci_.match = (call1[k] == ref1) & !refN; ci_.act = act;
+                ci_.refPen = refPen; ci_.limitP = max(vlimP[k], hlP); ci_.floorP = floorP; ci_.subfloor = subfloor;
+                ci_.dgM = dgM; ci_.dgD = dgD; ci_.dgI = dgI; ci_.lM = pM[k]; ci_.lD = pD[k]; ci_.upM = upM; ci_.upI = upI;
+                ci_.delForce = delForce[k];
+                ci_.insForce = (k == 0) ? ((rowOne && cGt1) ? INT_MAX : min(insHiForce[k], cLtLastForce)) : min(insHiForce[k], cLtLastForce);
+                ci_.pm8 = pm8;
+                const CellOut co = cell_update<Scheme11ts, false>(pen, ci_);            // msa_cell.h
+                const int nM = co.nM, nD = co.nD, nI = co.nI;
+                const bool goodM = co.goodM, goodD = co.goodD, goodI = co.goodI;
+                const int mb8 = co.mb8;
                 if (MAT) {
                     if (inRange & rowValid[k]) {
                         int *cellp = planeM + (long long)(row - 1) * planeW + (c - 1);
-                        const int tD = timeD > kMaxTime ? kMaxTime - 3 : timeD;
                         // (the reference clamps the stored time at MAX_TIME - MASK5 in every plane, :563, :618, :659)
                         // skipped by the prune test: plain subfloor (:486, :567, :620); computed but below the limit: subfloor | time
-                        const int sM = pruneM ? pruneVal : (goodM ? nM : (pruneVal | (timeM > kMaxTime ? kMaxTime - 3 : timeM)));
-                        const int sD = pruneD ? pruneVal : (goodD ? nD : (pruneVal | tD));
-                        const int sI = pruneI ? pruneVal : (goodI ? nI : (pruneVal | (timeI > kMaxTime ? kMaxTime - 3 : timeI)));
+                        const int sM = co.pruneM ? subfloor : (goodM ? nM : (subfloor | clamp_cell_time<Scheme11ts>(co.timeM)));
+                        const int sD = co.pruneD ? subfloor : (goodD ? nD : (subfloor | clamp_cell_time<Scheme11ts>(co.timeD)));
+                        const int sI = co.pruneI ? subfloor : (goodI ? nI : (subfloor | clamp_cell_time<Scheme11ts>(co.timeI)));
                         cellp[0] = sM; cellp[planeInts] = sD; cellp[2 * planeInts] = sI;
                     }
                 }
-
-                // ---- traceback record (MultiStateAligner11tsJNI.java:389-443): what traceback2 would decide here
-                const bool msStay = (timeM > 1) | (sdm >= mDI);
-                const unsigned nibM = msStay ? 0u : (((dgD | kTimeMask) >= dgI) ? 1u : 2u);
-                const unsigned nib = nibM | (aWinsD ? 0u : 4u) | (aWinsI ? 0u : 8u);
-                dacc[k] |= nib << sh;
+                dacc[k] |= co.nib << sh;
 
                 // ---- bookkeeping
                 const bool good = goodM | goodD | goodI;

@@ -16,6 +16,7 @@
 // recovered from the rows' first / last good columns.  Banded fills are handed to the one-job-per-thread kernel
 // (msa_fill_generic.hip); windows narrower than the read are taken here.
 #include "msa_common.h"
+#include "msa_cell.h"
 
 namespace bbmsa {
 
@@ -50,22 +51,6 @@ namespace {
 
 __device__ __forceinline__ int lane_up(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }
 
-template <class S> __device__ __forceinline__ int ctime(int t) { return t > S::MAXT ? S::MAXT - 3 : t; }
-template <class S> __device__ __forceinline__ int del_ext(int streak) {
-    int c = (streak & 3) == 0 ? S::DEL5 : 0;
-    c = streak < 80 ? S::DEL4 : c; c = streak < 20 ? S::DEL3 : c; c = streak < 5 ? S::DEL2 : c; c = streak == 0 ? S::DEL : c;
-    return c;
-}
-template <class S> __device__ __forceinline__ int ins_ext(int streak) {
-    int c = S::INS4;
-    c = streak < 20 ? S::INS3 : c; c = streak < 5 ? S::INS2 : c; c = streak == 0 ? S::INS : c;
-    return c;
-}
-template <class S> __device__ __forceinline__ int sub_ext(int streak) {
-    int c = S::SUB3;
-    c = streak < 5 ? S::SUB2 : c; c = streak == 0 ? S::SUB : c;
-    return c;
-}
 __device__ __forceinline__ unsigned load_coherent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // what this wave wrote earlier (boundary rows, the reversed match string) is read back past the vector L1, which may still hold
 // the lines as they were before the writes
@@ -318,7 +303,7 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
                 const int c0v = S::col0(min(row, rows));
                 pM[k] = c0v; pD[k] = c0v; pI[k] = c0v;
                 minGood[k] = -1; maxGood[k] = -2; dacc[k] = 0;
-                mPrev[k] = (call1[k] == '!') ? 1 : 0;
+                mPrev[k] = (call1[k] == '!') ? 8 : 0;
                 delForce[k] = (row < S::BAR_D1 || row > rows - S::BAR_D1) ? INT_MAX : INT_MIN;
                 insHiForce[k] = (row > rows - S::BAR_I1) ? INT_MAX : INT_MIN;
             }
@@ -374,80 +359,32 @@ __global__ __launch_bounds__(64) void msa_fill_strip_kernel(const StripParams p)
                     int dgM = svM, dgD = svD, dgI = svI;
                     svM = upM; svD = upD; svI = upI;
                     bool started = upMin >= 0;
-                    bool prevMatch = (call0First == ref0) & (ref0 != 'N');
+                    int pm8 = ((call0First == ref0) & (ref0 != 'N')) ? 8 : 0;
+                    const SpelledPen<S> pen;
 #pragma unroll
                     for (int k = 0; k < R; k++) {
                         const int row = r0 + k;
-                        const bool act = inRange & (started | notLimited);
-                        const int cl1 = call1[k];
-                        const bool match = (cl1 == ref1) & !refN;
-                        const int limitP = max(vlimP[k], hlP);
-                        const int limit = limitP - ONE;
-                        const int delNeeded = max(0, row - c - 1);
-                        const int insNeeded = max(0, (rows - row) - insNeededBase);
-                        const int delPen = S::del_off(delNeeded), insPen = S::ins_cum_off(insNeeded);
+                        CellIn ci;                                             // the cell itself: msa_cell.h, shared with the wavefront kernel
+                        ci.row = row; ci.c = c; ci.rows = rows; ci.insNeededBase = insNeededBase;
+                        ci.cl1 = call1[k]; ci.ref1 = ref1; ci.refN = refN; ci.gap = gap; ci.match = (call1[k] == ref1) & !refN;
+                        ci.act = inRange & (started | notLimited);
+                        ci.refPen = refPen; ci.limitP = max(vlimP[k], hlP); ci.floorP = floorP; ci.subfloor = subfloor;
+                        ci.dgM = dgM; ci.dgD = dgD; ci.dgI = dgI; ci.lM = pM[k]; ci.lD = pD[k]; ci.upM = upM; ci.upI = upI;
+                        ci.delForce = delForce[k];
+                        ci.insForce = max((k == 0 && rowOneLow && cGt1) ? INT_MAX : INT_MIN, min(insHiForce[k], cLtLastForce));
+                        ci.pm8 = pm8;
+                        const CellOut co = cell_update<S, true>(pen, ci);
+                        dacc[k] |= co.nib << sh;
 
-                        // ---- match / substitution plane
-                        const int streakM = dgM & S::TMASK;
-                        const int sdm = dgM & S::SMASK;
-                        const int mDI = max(dgD, dgI) & S::SMASK;
-                        const int t3 = max(floorP, limitP - (match ? S::MATCH2 : S::SUB3));
-                        const bool pruneM = !act | gap | (max(dgM, max(dgD, dgI)) < t3);
-                        int addA = prevMatch ? (streakM <= 1 ? S::SUBR : S::SUB) : sub_ext<S>(streakM);
-                        addA = (refN | (cl1 == 'N')) ? 0 : addA;
-                        addA = match ? (prevMatch ? S::MATCH2 : S::MATCH) : addA;
-                        const int sa = sdm + addA;
-                        const int sbc = mDI + (match ? S::MATCH : S::SUB);
-                        const bool aWinsM = sa >= sbc;
-                        const int scoreM = max(sa, sbc);
-                        const int timeM = (aWinsM & (match == prevMatch)) ? streakM + 1 : 1;
-                        const int penM = delNeeded > 0 ? delPen : (insNeeded > 0 ? insPen : 0);
-                        const bool goodM = !pruneM & (scoreM + penM >= limit);     // the offsets are negative: score >= limit - offset
-                        const int nM = goodM ? (scoreM | ctime<S>(timeM)) : subfloor;
-
-                        // ---- deletion plane (same row, previous column)
-                        const int streakD = pD[k] & S::TMASK;
-                        const int slm = pM[k] & S::SMASK, sld = pD[k] & S::SMASK;
-                        const bool pruneD = !act | (max(pM[k], pD[k]) < max(limitP, delForce[k]));
-                        const int dsa = slm + S::DEL, dsb = sld + del_ext<S>(streakD);
-                        const bool aWinsD = dsa >= dsb;
-                        const int scoreD = max(dsa, dsb) + refPen;
-                        const int timeD = aWinsD ? 1 : streakD + 1;
-                        const int penD = insNeeded > 0 ? insPen : (delNeeded > 0 ? S::del_off(timeD + delNeeded) - S::del_off(timeD) : 0);
-                        const bool goodD = !pruneD & (scoreD + penD >= limit);
-                        const int nD = goodD ? (scoreD | ctime<S>(timeD)) : subfloor;
-
-                        // ---- insertion plane (row above, same column)
-                        const int streakI = upI & S::TMASK;
-                        const int sum = upM & S::SMASK, sui = upI & S::SMASK;
-                        const int insLow = (k == 0 && rowOneLow && cGt1) ? INT_MAX : INT_MIN;
-                        const int insForce = max(insLow, min(insHiForce[k], cLtLastForce));
-                        const bool pruneI = !act | gap | (max(upM, upI) < max(limitP, insForce));
-                        const int isa = sum + S::INS, isb = sui + ins_ext<S>(streakI);
-                        const bool aWinsI = isa >= isb;
-                        const int scoreI = max(isa, isb);
-                        const int timeI = aWinsI ? 1 : streakI + 1;
-                        const int penI = delNeeded > 0 ? delPen : (insNeeded > 0 ? S::ins_cum_off(timeI + insNeeded) - S::ins_cum_off(timeI) : 0);
-                        const bool goodI = !pruneI & (scoreI + penI >= limit);
-                        const int nI = goodI ? (scoreI | ctime<S>(timeI)) : subfloor;
-
-                        // ---- traceback record: what traceback2 / score2 would decide at this cell (time > 1: stay; else the
-                        // predecessor comparison on scores); the clamped time decides "stay", as it does on the stored cell
-                        const bool msStay = (ctime<S>(timeM) > 1) | (sdm >= mDI);
-                        const unsigned nibM = msStay ? 0u : (((dgD | S::TMASK) >= dgI) ? 1u : 2u);
-                        const unsigned nib = nibM | (aWinsD ? 0u : 4u) | (aWinsI ? 0u : 8u);
-                        dacc[k] |= nib << sh;
-
-                        const bool good = goodM | goodD | goodI;
+                        const bool good = co.goodM | co.goodD | co.goodI;
                         minGood[k] = (good & (minGood[k] < 0)) ? c : minGood[k];
                         maxGood[k] = good ? c : maxGood[k];
                         dgM = pM[k]; dgD = pD[k]; dgI = pI[k];
-                        pM[k] = nM; pD[k] = nD; pI[k] = nI;
-                        upM = nM; upI = nI;
+                        pM[k] = co.nM; pD[k] = co.nD; pI[k] = co.nI;
+                        upM = co.nM; upI = co.nI;
                         started = minGood[k] >= 0;
-                        const int mp = mPrev[k];
-                        mPrev[k] = match ? 1 : 0;
-                        prevMatch = mp != 0;
+                        pm8 = mPrev[k];
+                        mPrev[k] = co.mb8;
                     }
                     lastRef = ref1;
 
