@@ -525,6 +525,14 @@ def pacbio_main(args):
         dom_ms, dom_bytes = kern[dom]["ms"], kern[dom]["algorithmic_bytes"]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         reads_per_step = n // 2
+        traffic, traffic_src = None, None                       # counter traffic of a committed profile of this very workload, if there is one
+        try:
+            ent = json.load(open(os.path.join(ROOT, "profiles", "traffic_r04.json"))).get("pacbio", {}).get(dom)
+            if ent and ent.get("pieces_per_step") == n and args.pacbio_genome == "hg38":
+                traffic = ent["hbm_bytes_per_launch"]
+                traffic_src = "committed profile %s (rocprofv3 --pmc passes on this workload, not this run)" % ent["source"]
+        except Exception:
+            traffic = None
         out_json = {
             "metric": "aligned_reads_per_sec", "value": reads_per_step * world * args.steps / elapsed, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -542,9 +550,10 @@ def pacbio_main(args):
                        "probe_list_entries_per_step": int(ps[0] + ps[1]), "probe_extend_calls_per_step": int(ps[2]), "probe_stats_raw": [int(x) for x in ps],
                        "stage_ms": {key[3:]: round(v, 3) for key, v in ms.items()}, "index_build_s_gpu": t_ix, "library_first_call_s": t_lib, "parity": parity},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": dom, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(dom_bytes), "kernels": kern,
-                         "note": "both kernels are instruction-bound integer work (heap merge of ~1,400 lists; ~180 VALU per DP cell): the HBM "
-                                 "fraction is reported as the contract asks"}}
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": dom, "kernel_ms": dom_ms,
+                         "algorithmic_bytes_per_launch": int(dom_bytes), "kernels": kern,
+                         "note": "the long-read probe is latency-bound: 1.5 wavefronts per SIMD (36 KB of LDS each), 12.6 % of the VALU issue rate, waves "
+                                 "waiting 53 % of their cycles, L2 hit rate 8 % (profiles/r04_pacbio_pmc_summary.txt); the strip DP is instruction-bound"}}
         if cpu is not None:
             out_json["cpu_baseline"] = cpu
         print(json.dumps(out_json))
@@ -787,7 +796,7 @@ def main():
         dom_ms, dom_bytes = kern[dom]["ms"], kern[dom]["algorithmic_bytes"]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r03.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_r04.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
@@ -837,8 +846,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": dom, "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(dom_bytes), "kernels": kern,
                          "note": ("latency-bound gather kernel: 34 % of the VALU issue rate, waves waiting 53 % of their cycles at 5 waves per SIMD "
-                                  "(profiles/r03_hg38_pmc_summary.txt); HBM is not what limits it" if dom == "probe_wave_kernel" else
-                                  "integer DP: VALU-bound (82 % of the VALU issue rate while it runs, profiles/r03_hg38_pmc_summary.txt); its "
+                                  "(profiles/r04_hg38_pmc_summary.txt); HBM is not what limits it" if dom == "probe_wave_kernel" else
+                                  "integer DP: instruction-bound (8.6e10 VALU wave-instructions per step = 42 % of the VALU issue rate over the DP stages' "
+                                  "wall time, four waves per SIMD of one dependent chain each; profiles/r04_hg38_pmc_summary.txt); its "
                                   "algorithmic bytes are a few hundred per fill, so an HBM fraction says nothing about it")},
         }
         if cpu is not None:
