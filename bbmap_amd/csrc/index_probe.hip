@@ -740,10 +740,27 @@ int bbidx_finish_create(bbidx_ctx *c, const std::vector<const int *> &hs, const 
         if (ok) rc = upload(c, hf.data(), hf.size(), (const bbidx::KeyEntry *const **)&c->dev.fused);
         else c->kernelKind = BBIDX_KERNEL_LANE;
     }
-    if (rc == BBMAP_OK && hipMalloc(&c->d_queue, 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
-    if (rc == BBMAP_OK && hipMalloc(&c->d_stats, bbidx::STAT_SHARDS * 64) != hipSuccess) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipMalloc failed");
-    if (rc == BBMAP_OK && (hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess)) rc = ifail(BBMAP_E_HIP, "bbidx_create: hipEventCreate failed");
+    if (rc == BBMAP_OK) rc = bbidx_launch_init(c, &c->own);
     return rc;
+}
+
+int bbidx_launch_init(bbidx_ctx *c, bbidx_launch *ls) {
+    IHIP(hipSetDevice(c->device));
+    IHIP(hipMalloc(&ls->d_queue, 64));
+    IHIP(hipMalloc(&ls->d_stats, bbidx::STAT_SHARDS * 64));
+    IHIP(hipEventCreate(&ls->ev[0]));
+    IHIP(hipEventCreate(&ls->ev[1]));
+    ls->timed = false; ls->d_longWs = nullptr; ls->longBlocks = 0;
+    return BBMAP_OK;
+}
+void bbidx_launch_free(bbidx_launch *ls) {
+    if (!ls) return;
+    if (ls->d_queue) (void)hipFree(ls->d_queue);
+    if (ls->d_stats) (void)hipFree(ls->d_stats);
+    if (ls->d_longWs) (void)hipFree(ls->d_longWs);
+    if (ls->ev[0]) (void)hipEventDestroy(ls->ev[0]);
+    if (ls->ev[1]) (void)hipEventDestroy(ls->ev[1]);
+    *ls = bbidx_launch();
 }
 
 extern "C" int bbidx_create(int32_t device, const bbidx_index_desc *d, bbidx_ctx **out) {
@@ -797,10 +814,7 @@ extern "C" void bbidx_destroy(bbidx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (void *p : c->allocs) (void)hipFree(p);
-    if (c->d_queue) (void)hipFree(c->d_queue);
-    if (c->d_stats) (void)hipFree(c->d_stats);
-    if (c->d_longWs) (void)hipFree(c->d_longWs);
-    for (int i = 0; i < 2; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    bbidx_launch_free(&c->own);
     delete c;
 }
 
@@ -814,34 +828,41 @@ extern "C" int bbidx_find_batch_device_rc(bbidx_ctx *c, void *stream_, int64_t n
                                           const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo,
                                           bbidx_site *sites, int32_t max_sites, int32_t *nsites, uint8_t *bases_rc_out) {
     if (!c) return ifail(BBMAP_E_ARG, "bbidx_find_batch_device: null context");
+    return bbidx_find_batch_device_with(c, &c->own, stream_, n, reads, bases, baseScores, keyinfo, sites, max_sites, nsites, bases_rc_out);
+}
+
+int bbidx_find_batch_device_with(bbidx_ctx *c, bbidx_launch *ls, void *stream_, int64_t n, const bbidx_read *reads,
+                                 const uint8_t *bases, const int8_t *baseScores, const int32_t *keyinfo,
+                                 bbidx_site *sites, int32_t max_sites, int32_t *nsites, uint8_t *bases_rc_out) {
+    if (!c || !ls) return ifail(BBMAP_E_ARG, "bbidx_find_batch_device: null context");
     if (n < 0 || n > 0x7fffffffLL || max_sites < 1) return ifail(BBMAP_E_ARG, "bbidx_find_batch_device: bad size");
     if (n == 0) return BBMAP_OK;
     if (!reads || !bases || !baseScores || !keyinfo || !sites || !nsites) return ifail(BBMAP_E_ARG, "bbidx_find_batch_device: null buffer");
     hipStream_t stream = (hipStream_t)stream_;
     IHIP(hipSetDevice(c->device));
-    IHIP(hipMemsetAsync(c->d_queue, 0, 64, stream));
-    IHIP(hipMemsetAsync(c->d_stats, 0, bbidx::STAT_SHARDS * 64, stream));
+    IHIP(hipMemsetAsync(ls->d_queue, 0, 64, stream));
+    IHIP(hipMemsetAsync(ls->d_stats, 0, bbidx::STAT_SHARDS * 64, stream));
     bbidx::Params P;
-    P.stats = c->d_stats;
+    P.stats = ls->d_stats;
     P.ix = c->dev; P.reads = reads; P.bases = bases; P.baseScores = baseScores; P.keyinfo = keyinfo;
-    P.sites = sites; P.nsites = nsites; P.nreads = n; P.maxSites = max_sites; P.queue = c->d_queue;
+    P.sites = sites; P.nsites = nsites; P.nreads = n; P.maxSites = max_sites; P.queue = ls->d_queue;
     P.onlyPending = 0;
     P.rcOut = bases_rc_out;
     long long blocks = (n + 63) / 64;
     if (blocks > c->blocks) blocks = c->blocks;
-    IHIP(hipEventRecord(c->ev[0], stream));
+    IHIP(hipEventRecord(ls->ev[0], stream));
     if (c->dev.p.profile == BBIDX_PROFILE_PACBIO || c->kernelKind == BBIDX_KERNEL_LONG) {
         // mapPacBio's reads (thousands of bases, hundreds of keys), or the long-read kernel asked for by name
         if (!c->dev.fused) return ifail(BBMAP_E_NOMEM, "bbidx_find_batch_device: the long-read kernel needs the fused key table, which could not be allocated");
-        if (!c->d_longWs) {
-            c->longBlocks = bbidx_long_blocks(c->dev.p.profile == BBIDX_PROFILE_PACBIO ? 1 : 0);
-            if (c->longBlocks < 1) return ifail(BBMAP_E_HIP, "bbidx_find_batch_device: the long-read kernel does not fit this device");
-            IHIP(hipMalloc(&c->d_longWs, (size_t)c->longBlocks * (size_t)bbidx_long_workspace_ints_per_block() * 4));
+        if (!ls->d_longWs) {
+            ls->longBlocks = bbidx_long_blocks(c->dev.p.profile == BBIDX_PROFILE_PACBIO ? 1 : 0);
+            if (ls->longBlocks < 1) return ifail(BBMAP_E_HIP, "bbidx_find_batch_device: the long-read kernel does not fit this device");
+            IHIP(hipMalloc(&ls->d_longWs, (size_t)ls->longBlocks * (size_t)bbidx_long_workspace_ints_per_block() * 4));
         }
-        const int rc = bbidx_launch_long(P, stream, c->dev.p.profile == BBIDX_PROFILE_PACBIO ? 1 : 0, c->d_longWs, c->longBlocks);
+        const int rc = bbidx_launch_long(P, stream, c->dev.p.profile == BBIDX_PROFILE_PACBIO ? 1 : 0, ls->d_longWs, ls->longBlocks);
         if (rc != BBMAP_OK) return rc;
-        IHIP(hipEventRecord(c->ev[1], stream));
-        c->timed = true;
+        IHIP(hipEventRecord(ls->ev[1], stream));
+        ls->timed = true;
         return BBMAP_OK;
     }
     if (c->kernelKind == BBIDX_KERNEL_AUTO) {
@@ -856,8 +877,8 @@ extern "C" int bbidx_find_batch_device_rc(bbidx_ctx *c, void *stream_, int64_t n
     }
     hipLaunchKernelGGL(bbidx::probe_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, P);
     IHIP(hipGetLastError());
-    IHIP(hipEventRecord(c->ev[1], stream));
-    c->timed = true;
+    IHIP(hipEventRecord(ls->ev[1], stream));
+    ls->timed = true;
     return BBMAP_OK;
 }
 
@@ -912,13 +933,17 @@ done:
 // stats[0..4] = list entries consumed by the prescan, by the walk, extendScore calls, reference bytes compared,
 // site records written.
 extern "C" int bbidx_last_stats(bbidx_ctx *c, int64_t *stats5, float *kernel_ms) {
-    if (!c || !c->timed) return ifail(BBMAP_E_ARG, "bbidx_last_stats: nothing launched yet");
+    if (!c) return ifail(BBMAP_E_ARG, "bbidx_last_stats: null context");
+    return bbidx_last_stats_with(c, &c->own, stats5, kernel_ms);
+}
+int bbidx_last_stats_with(bbidx_ctx *c, bbidx_launch *ls, int64_t *stats5, float *kernel_ms) {
+    if (!c || !ls || !ls->timed) return ifail(BBMAP_E_ARG, "bbidx_last_stats: nothing launched yet");
     IHIP(hipSetDevice(c->device));
-    IHIP(hipEventSynchronize(c->ev[1]));
-    if (kernel_ms) IHIP(hipEventElapsedTime(kernel_ms, c->ev[0], c->ev[1]));
+    IHIP(hipEventSynchronize(ls->ev[1]));
+    if (kernel_ms) IHIP(hipEventElapsedTime(kernel_ms, ls->ev[0], ls->ev[1]));
     if (stats5) {
         std::vector<unsigned long long> h((size_t)bbidx::STAT_SHARDS * 8);
-        IHIP(hipMemcpy(h.data(), c->d_stats, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        IHIP(hipMemcpy(h.data(), ls->d_stats, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         for (int j = 0; j < 5; j++) stats5[j] = 0;
         for (int s = 0; s < bbidx::STAT_SHARDS; s++) for (int j = 0; j < 5; j++) stats5[j] += (int64_t)h[(size_t)s * 8 + j];
     }

@@ -1034,6 +1034,8 @@ struct ToLL { __host__ __device__ long long operator()(int x) const { return (lo
 struct bbmap_ctx {
     bbmap_config cfg;
     bbidx_ctx *index;
+    hipStream_t hostStream = nullptr;   // bbmap_map_batch (host buffers in and out) runs on it
+    bbidx_launch probeLs;       // this context's probe launches: queue, work counters, events (the index is shared, read-only; index_ctx.h)
     bbmsa_ctx *msa, *msaGapped;
     bbmapper::Settings S;
     std::vector<void *> allocs;
@@ -1117,8 +1119,10 @@ extern "C" void bbmap_destroy(bbmap_ctx *c) {
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->tierThread.joinable()) c->tierThread.join();
     if (c->tier) bbmap_destroy(c->tier);
+    bbidx_launch_free(&c->probeLs);
     if (c->d_packTmp) (void)hipFree(c->d_packTmp);
     for (int i = 0; i < 7; i++) if (c->hio.p[i]) (void)hipFree(c->hio.p[i]);
+    if (c->hostStream) (void)hipStreamDestroy(c->hostStream);
     if (c->tierStream) (void)hipStreamDestroy(c->tierStream);
     if (c->dpStream) (void)hipStreamDestroy(c->dpStream);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
@@ -1160,6 +1164,7 @@ static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *par
     c->cfg = *cfg; c->index = index;
     int rc = BBMAP_OK;
     auto bail = [&](int code) { bbmap_destroy(c); return code; };
+    if ((rc = bbidx_launch_init(index, &c->probeLs)) != BBMAP_OK) return bail(rc);
     // settings
     bbmapper::Settings &S = c->S;
     const float R = cfg->minRatio;
@@ -1489,8 +1494,8 @@ static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const 
     MHIP(hipMemsetAsync(c->d_counters, 0, 64 * 4, stream));
     MHIP(hipEventRecord(c->ev[0], stream));
     // ---- probe (BBIndex.findAdvanced); reverse complements are written on the way
-    MTRY(bbidx_find_batch_device_rc(c->index, stream, n_reads, reads, bases, baseScores, keyinfo, c->d_psites, c->cfg.max_sites,
-                                    c->d_pnsites, writeRc ? bases + minus_delta : nullptr));
+    MTRY(bbidx_find_batch_device_with(c->index, &c->probeLs, stream, n_reads, reads, bases, baseScores, keyinfo, c->d_psites, c->cfg.max_sites,
+                                      c->d_pnsites, writeRc ? bases + minus_delta : nullptr));
     MHIP(hipEventRecord(c->ev[1], stream));
     bbmapper::Dev D;
     fill_dev(c, D, n_reads, reads, bases, minus_delta);
@@ -1518,9 +1523,9 @@ static int map_records(bbmap_ctx *c, hipStream_t stream, int64_t n_reads, const 
         MHIP(hipGetLastError());
         MTRY(read_counters(c, stream));
         if (round == 0) {
-            // the probe is over: its statistics are read now (the tier's probe launch reuses the index context's counters)
+            // the probe is over: its statistics are read now
             float pms = 0; long long ps[5];       // (not for the tier's own pass: the synchronous copy inside would wait for the main stream)
-            if (writeRc && bbidx_last_stats(c->index, (int64_t *)ps, &pms) == BBMAP_OK) for (int i = 0; i < 5; i++) c->stats.probe_stats[i] = ps[i];
+            if (writeRc && bbidx_last_stats_with(c->index, &c->probeLs, (int64_t *)ps, &pms) == BBMAP_OK) for (int i = 0; i < 5; i++) c->stats.probe_stats[i] = ps[i];
             c->overAfterBegin = c->h_counters[3];
             if (c->tier && c->h_counters[16] > 0 && c->tier->msa != c->msa) tier_start_async(c, c->h_counters[16]);     // (a tier that borrows the DP context runs after the pass)
         }
@@ -1823,18 +1828,23 @@ extern "C" int bbmap_map_batch(bbmap_ctx *c, int64_t n_reads, const bbidx_read *
     MTRY(hio_grow(c, 4, (size_t)(n_reads + 1) * 4));
     MTRY(hio_grow(c, 5, (size_t)(n_reads + 1) * 8));
     MTRY(hio_grow(c, 6, (size_t)(sites_cap > 0 ? sites_cap : 1) * sizeof(bbmap_msite)));
-    MHIP(hipMemcpy(c->hio.p[0], reads, (size_t)n_reads * sizeof(bbidx_read), hipMemcpyHostToDevice));
-    MHIP(hipMemcpy(c->hio.p[1], bases, nb, hipMemcpyHostToDevice));
-    MHIP(hipMemcpy(c->hio.p[2], baseScores, nb, hipMemcpyHostToDevice));
-    MHIP(hipMemcpy(c->hio.p[3], keyinfo, (size_t)keyinfo_ints * 4, hipMemcpyHostToDevice));
-    MTRY(bbmap_map_batch_device(c, nullptr, n_reads, (const bbidx_read *)c->hio.p[0], (uint8_t *)c->hio.p[1], (int64_t)nb,
+    // A stream of this context's own, non-blocking: several mapping threads, each with its own bbmap_ctx on one shared index (BBMap's
+    // thread model), then overlap on the GPU instead of queueing behind one another on the legacy default stream.
+    if (!c->hostStream) MHIP(hipStreamCreateWithFlags(&c->hostStream, hipStreamNonBlocking));
+    hipStream_t hs = c->hostStream;
+    MHIP(hipMemcpyAsync(c->hio.p[0], reads, (size_t)n_reads * sizeof(bbidx_read), hipMemcpyHostToDevice, hs));
+    MHIP(hipMemcpyAsync(c->hio.p[1], bases, nb, hipMemcpyHostToDevice, hs));
+    MHIP(hipMemcpyAsync(c->hio.p[2], baseScores, nb, hipMemcpyHostToDevice, hs));
+    MHIP(hipMemcpyAsync(c->hio.p[3], keyinfo, (size_t)keyinfo_ints * 4, hipMemcpyHostToDevice, hs));
+    MTRY(bbmap_map_batch_device(c, hs, n_reads, (const bbidx_read *)c->hio.p[0], (uint8_t *)c->hio.p[1], (int64_t)nb,
                                 (const int8_t *)c->hio.p[2], (const int32_t *)c->hio.p[3]));
-    MTRY(bbmap_pack_sites_device(c, nullptr, n_reads, (int32_t *)c->hio.p[4], (int64_t *)c->hio.p[5], (bbmap_msite *)c->hio.p[6], sites_cap));
-    MHIP(hipMemcpy(nsites_out, c->d_mcount, (size_t)n_reads * 4, hipMemcpyDeviceToHost));      // counts, or the flags (-1, -2, -3)
-    MHIP(hipMemcpy(offsets_out, c->hio.p[5], (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost));
+    MTRY(bbmap_pack_sites_device(c, hs, n_reads, (int32_t *)c->hio.p[4], (int64_t *)c->hio.p[5], (bbmap_msite *)c->hio.p[6], sites_cap));
+    MHIP(hipMemcpyAsync(nsites_out, c->d_mcount, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));      // counts, or the flags (-1, -2, -3)
+    MHIP(hipMemcpyAsync(offsets_out, c->hio.p[5], (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, hs));
+    MHIP(hipStreamSynchronize(hs));
     long long total = offsets_out[n_reads];
     const long long have = total < sites_cap ? total : sites_cap;
-    if (have > 0) MHIP(hipMemcpy(sites_out, c->hio.p[6], (size_t)have * sizeof(bbmap_msite), hipMemcpyDeviceToHost));
+    if (have > 0) { MHIP(hipMemcpyAsync(sites_out, c->hio.p[6], (size_t)have * sizeof(bbmap_msite), hipMemcpyDeviceToHost, hs)); MHIP(hipStreamSynchronize(hs)); }
     bbmap_overflow_output ov;
     MTRY(bbmap_get_overflow_output(c, &ov));
     if (ov.n_reads > 0) {

@@ -277,3 +277,57 @@ def test_average_pair_dist_follows_the_host_between_batches():
     assert (outs[0]["sites"]["pairedScore"] != outs[1]["sites"]["pairedScore"]).any()
     mp.close()
     di.close()
+
+
+def test_contexts_of_several_threads_share_one_index():
+    """BBMap's thread model: every mapping thread has its own read lists and, here, its own bbmap_ctx; the index is one.  Four contexts
+    on ONE DeviceIndex, stepped at the same time from four threads (each on a stream of its own), must give what each gives alone --
+    site lists, fills and final records.  (Until round 4 the persistent probe waves' work queue belonged to the index context: two
+    probes in flight took reads from each other's queue and half the reads came back unmapped.)"""
+    import threading
+
+    import torch
+    L, k, T = 150, 12, 4
+    ref = W.make_reference(400000, seed=11, pad=2000, repeat_frac=0.15)
+    di = DeviceIndex.build([ref], k=k)
+    offs = O.make_offsets(L, k, 1.9)
+    ks = [100 * k] * len(offs)
+    mps, alone = [], []
+    for t in range(T):
+        reads, _ = W.make_pairs(ref, 1500, read_len=L, seed=20 + t, pad=2000, hard_frac=0.08)
+        mp = Mapper(di, reads.size // L, L, offs, ks, paired=True, max_sites=32)
+        mp.load_reads(reads)
+        mp.step()
+        o = mp.fetch()
+        alone.append((o["nsites"].copy(), o["sites"].copy(), o["final"].copy(), len(o["jobs"]), len(o["gjobs"])))
+        mps.append(mp)
+    assert sum(int((a[2]["mapped"] > 0).sum()) for a in alone) > 0.95 * T * 3000
+    streams = [torch.cuda.Stream() for _ in mps]
+    errs = []
+
+    def run(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(3):
+                    mps[i].step()
+        except Exception as e:                                   # (a failure inside a thread must fail the test)
+            errs.append(repr(e))
+    th = [threading.Thread(target=run, args=(i,)) for i in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i, mp in enumerate(mps):
+        o = mp.fetch()
+        ns, st, fin, nj, ng = alone[i]
+        assert np.array_equal(o["nsites"], ns), i
+        for f in ("chrom", "strand", "start", "stop", "score", "slowScore", "pairedScore", "perfect", "rescued"):
+            assert np.array_equal(o["sites"][f], st[f]), (i, f)
+        for f in fin.dtype.names:
+            if f not in ("match_off", "reserved"):
+                assert np.array_equal(o["final"][f], fin[f]), (i, f)
+        assert (len(o["jobs"]), len(o["gjobs"])) == (nj, ng)
+        mp.close()
+    di.close()
