@@ -491,7 +491,7 @@ def pacbio_main(args):
     parity = None
     if rank == 0 and args.parity_sample > 0:
         from tests.mapper_check import compare
-        cnt = min(n, max(2, args.parity_sample if args.parity_sample < 600 else 8))
+        cnt = min(n, max(2, args.parity_sample if args.parity_sample < 600 else 32))        # 32 pieces: 3-4 s of the CPU oracle on 16 threads
         orc = map_reads(oi, recs[:cnt], blob, keyinfo, base_scores=bs, cap=1024, threads=min(usable_cores(), 8))
         good = [i for i in range(cnt) if out["nsites"][i] >= 0 or out["nsites"][i] == -3]
         bad = compare(out, orc, cnt, False, reads_range=good)

@@ -32,4 +32,4 @@ def test_struct_layouts_match_header():
 
 
 def test_abi_version():
-    assert _lib.load().bbmap_abi_version() == 5
+    assert _lib.load().bbmap_abi_version() == 6
