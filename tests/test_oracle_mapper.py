@@ -17,7 +17,8 @@ def _setup(L=150, k=12, size=150000, seed=5):
 def test_single_ended_reads_map_to_their_origin():
     ref, oi, offs, ks = _setup()
     reads, _, truth = W.make_reads_and_jobs(ref, 600, seed=3, pad=2000)
-    out = O.map_batch(oi, reads, None, 150, offs, ks)
+    # (the lists as scoreSlow leaves them: the final stage lowers a list's scores when several sites tie, applyClearzone3)
+    out = O.map_batch(oi, reads, None, 150, offs, ks, params=O.map_default_params(finalStage=0))
     n1, top = out["nsites1"], out["sites1"][:, 0]
     assert (n1 > 0).mean() > 0.99
     assert ((n1 > 0) & (np.abs(top["start"] - truth["start"]) <= 40)).mean() > 0.98
@@ -34,7 +35,7 @@ def test_pairs_rescue_and_fill_log():
     oi.s.p.quitAfterTwoPerfects = 0
     reads, truth = W.make_pairs(ref, 500, seed=4, pad=2000, hard_frac=0.1)
     r = reads.reshape(-1, 150)
-    out = O.map_batch(oi, r[0::2].copy(), r[1::2].copy(), 150, offs, ks)
+    out = O.map_batch(oi, r[0::2].copy(), r[1::2].copy(), 150, offs, ks, params=O.map_default_params(finalStage=0))
     n1, n2 = out["nsites1"], out["nsites2"]
     t1, t2 = out["sites1"][:, 0], out["sites2"][:, 0]
     assert ((n1 > 0) & (np.abs(t1["start"] - truth["start1"]) <= 40) & (t1["strand"] == truth["strand1"])).mean() > 0.97
