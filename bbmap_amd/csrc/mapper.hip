@@ -34,6 +34,7 @@
 void bbmap_set_error(const char *msg);
 void bbmsa_use_narrow(bbmsa_ctx *c, bool on);          // msa_host.hip (internal, see msa_ctx.h)
 int bbmsa_wait_first_pass(bbmsa_ctx *c, void *waiter);
+void bbmsa_sort_by_width(bbmsa_ctx *c, bool on);
 
 namespace bbmapper {
 
@@ -1364,8 +1365,11 @@ static int run_fills(bbmap_ctx *c, hipStream_t stream, const uint8_t *bases, lon
     // however few jobs there are: worth it only for the big first rounds of scoreSlow (163 k of 459 k fills finish there in 4.8 ms
     // on the bench workload).  The final stage's fills never fit its band (see msa_ctx.h), nor do the second context's wide windows.
     static const long long narrowMin = getenv("BBMAP_NARROW_MIN_JOBS") ? atoll(getenv("BBMAP_NARROW_MIN_JOBS")) : 32768;
+    static const bool sortWide = !(getenv("BBMAP_SORT_WIDE") && atoi(getenv("BBMAP_SORT_WIDE")) == 0);      // (experiments: 0 switches the width order off)
     bbmsa_use_narrow(c->msa, !finalStage && nNew >= narrowMin);
-    if (c->msaGapped != c->msa) bbmsa_use_narrow(c->msaGapped, false);
+    // (not the first context's: its windows span 162..256 columns, and sorted its pass ends 4 ms earlier -- leaving the second
+    // context's latency-bound wide pass to finish on its own: final stage 79.6 -> 85.5 ms)
+    if (c->msaGapped != c->msa) { bbmsa_use_narrow(c->msaGapped, false); bbmsa_sort_by_width(c->msaGapped, sortWide); }
     // the second context's launches first, on their own stream: its blocks take their share of the CUs and the plain context's
     // persistent blocks fill the rest (and the slots the others free)
     hipStream_t gs = (c->dpStream && nNew > 0) ? c->dpStream : stream;

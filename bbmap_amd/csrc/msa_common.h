@@ -128,7 +128,7 @@ struct FillParams {
     unsigned int *queue;          // work-queue head (zeroed before launch)
     unsigned int *dirbuf;         // traceback direction nibbles, one slot per resident job
     long long dir_slot_dwords;
-    const int *list;              // job indices to process (NULL = all njobs), filled by the narrow kernel
+    const int *list;              // job indices to process (NULL = all njobs), filled by the narrow kernel or the width sort
     const unsigned int *list_count;
     int *slow_list;               // jobs the fast kernel hands to the generic kernel
     unsigned int *slow_count;

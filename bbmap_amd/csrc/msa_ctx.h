@@ -30,6 +30,10 @@ struct bbmsa_ctx {
     int narrowBlocks, narrowSlack;     // 0 blocks = disabled
     bool narrowOff;                    // switched off by the caller for launches whose jobs it cannot take (bbmsa_use_narrow)
     bool narrowUsed;                   // whether the last launch ran it
+    // widest windows first (bbmsa_sort_by_width): two jobs share a wavefront and step together, so a 600-column job beside a
+    // 200-column one idles half the wave for 400 steps; in width order neighbours are alike, and the longest jobs do not end up last
+    bool sortByWidth;
+    unsigned int *d_widthHist;
     unsigned long long *d_narrowDir;
     int *d_fastList;
     long long fastCap;
@@ -63,6 +67,10 @@ void bbmsa_use_narrow(bbmsa_ctx *c, bool on);
 // are resident on every CU by then, the second context's passes (among them the latency-bound wide pass, which needs something
 // to overlap with) only start when those drain: measured, the final stage 86 -> 93 ms.
 int bbmsa_wait_first_pass(bbmsa_ctx *c, void *waiter);
+// Launches of this context hand their jobs to the wavefront kernel in descending window width (a counting sort by columns / 8 in
+// front of the first pass); results are indexed by job as always.  The mapper asks for it on its second context, whose windows
+// span 170..640+ columns.
+void bbmsa_sort_by_width(bbmsa_ctx *c, bool on);
 
 // msa_legacy.hip: persistent buffers, stream and the call combiner of a BBMSA_LEGACY_ONLY context (c->d_matrix / d_limits exist)
 int bbmsa_legacy_create(bbmsa_ctx *c);

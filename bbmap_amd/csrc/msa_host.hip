@@ -30,6 +30,33 @@ template <class S> __global__ void msa_fill_generic_kernel(const GenericParams p
 __global__ void msa_fill_narrow_kernel(const NarrowParams p);
 }  // namespace bbmsa
 
+namespace bbmsa {
+constexpr int WIDTH_BUCKETS = 1024;            // columns / 8, clamped
+__device__ inline int job_width_bucket(const bbmsa_job &t, int maxColumns) {
+    int a = t.refStartLoc, b = t.refEndLoc;
+    if (t.flags & BBMSA_CLAMP_WINDOW) { a = max(0, a); b = min(t.ref_len - 1, b); if (b - a >= maxColumns) b = min(t.ref_len - 1, a + maxColumns - 1); }
+    const int cols = max(0, b - a + 1);
+    return WIDTH_BUCKETS - 1 - min(WIDTH_BUCKETS - 1, cols >> 3);            // bucket 0 = the widest
+}
+__global__ void width_hist_kernel(const bbmsa_job *jobs, long long n, int maxColumns, unsigned *hist) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&hist[job_width_bucket(jobs[i], maxColumns)], 1u);
+}
+__global__ void width_scan_kernel(unsigned *hist, unsigned *listCount, unsigned n) {      // one block of WIDTH_BUCKETS threads: exclusive prefix sums in place
+    __shared__ unsigned s[WIDTH_BUCKETS];
+    const int t = threadIdx.x;
+    s[t] = hist[t];
+    __syncthreads();
+    for (int d = 1; d < WIDTH_BUCKETS; d <<= 1) { const unsigned v = t >= d ? s[t - d] : 0u; __syncthreads(); s[t] += v; __syncthreads(); }
+    hist[t] = s[t] - hist[t];
+    if (t == 0) *listCount = n;
+}
+__global__ void width_scatter_kernel(const bbmsa_job *jobs, long long n, int maxColumns, unsigned *cursor, int *list) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) list[atomicAdd(&cursor[job_width_bucket(jobs[i], maxColumns)], 1u)] = (int)i;
+}
+}  // namespace bbmsa
+
 static thread_local char g_err[512] = "";
 
 static int fail(int code, const char *fmt, const char *detail = "") {
@@ -243,6 +270,7 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     }
     // narrow-window kernel: only without a band (a band changes the window rule); BBMSA_NARROW=0 disables it
     c->narrowBlocks = 0; c->narrowOff = false; c->narrowUsed = false;
+    c->sortByWidth = false; c->d_widthHist = nullptr;
     c->narrowSlack = env_int("BBMSA_NARROW_SLACK", 2000);
     if (!c->banded && env_int("BBMSA_NARROW", 1) != 0) {
         int perCU = 0;
@@ -264,6 +292,8 @@ extern "C" void bbmsa_destroy(bbmsa_ctx *c) {
     bbmsa_legacy_destroy(c);
     if (c->d_dir) (void)hipFree(c->d_dir);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_widthHist) (void)hipFree(c->d_widthHist);
+
     if (c->d_slowList) (void)hipFree(c->d_slowList);
     if (c->d_matrix) (void)hipFree(c->d_matrix);
     if (c->d_limits) (void)hipFree(c->d_limits);
@@ -357,7 +387,8 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
         if (c->wideBlocks > 0) HIP_TRY(hipMalloc(&c->d_slowList2, (size_t)n_jobs * 4));
         c->slowCap = n_jobs;
     }
-    if (c->narrowBlocks > 0 && n_jobs > c->fastCap) {
+    const bool sortJobs = c->sortByWidth && !n_jobs_dev && n_jobs >= 256 && !(c->narrowBlocks > 0 && !c->narrowOff);
+    if ((c->narrowBlocks > 0 || sortJobs) && n_jobs > c->fastCap) {
         if (c->d_fastList) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_fastList)); c->d_fastList = nullptr; }
         HIP_TRY(hipMalloc(&c->d_fastList, (size_t)n_jobs * 4));
         c->fastCap = n_jobs;
@@ -380,13 +411,22 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
         hipLaunchKernelGGL(bbmsa::msa_fill_narrow_kernel, dim3((unsigned)nb), dim3(64), 0, stream, np);
         HIP_TRY(hipGetLastError());
     }
+    if (sortJobs) {                    // (never together with the narrow kernel: both write the wavefront kernel's list)
+        if (!c->d_widthHist) HIP_TRY(hipMalloc(&c->d_widthHist, bbmsa::WIDTH_BUCKETS * 4));
+        HIP_TRY(hipMemsetAsync(c->d_widthHist, 0, bbmsa::WIDTH_BUCKETS * 4, stream));
+        const unsigned sb = (unsigned)((n_jobs + 255) / 256);
+        hipLaunchKernelGGL(bbmsa::width_hist_kernel, dim3(sb), dim3(256), 0, stream, jobs, (long long)n_jobs, c->cfg.maxColumns, c->d_widthHist);
+        hipLaunchKernelGGL(bbmsa::width_scan_kernel, dim3(1), dim3(bbmsa::WIDTH_BUCKETS), 0, stream, c->d_widthHist, c->d_counters + 4, (unsigned)n_jobs);
+        hipLaunchKernelGGL(bbmsa::width_scatter_kernel, dim3(sb), dim3(256), 0, stream, jobs, (long long)n_jobs, c->cfg.maxColumns, c->d_widthHist, c->d_fastList);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(c->ev[3], stream));
 
     bbmsa::FillParams fp;
     fp.jobs = jobs; fp.reads = reads; fp.refs = refs; fp.results = results; fp.match = match;
     fp.njobs = n_jobs; fp.njobs_dev = n_jobs_dev;
     fp.queue = c->d_counters; fp.dirbuf = c->d_dir; fp.dir_slot_dwords = c->dirSlotDwords;
-    fp.list = useNarrow ? c->d_fastList : nullptr; fp.list_count = c->d_counters + 4;
+    fp.list = (useNarrow || sortJobs) ? c->d_fastList : nullptr; fp.list_count = c->d_counters + 4;
     fp.slow_list = c->d_slowList; fp.slow_count = c->d_counters + 1;
     fp.match_stride = match_stride; fp.lanesPerJob = c->G; fp.fastCols = c->fastCols; fp.tmpBytes = c->tmpBytes; fp.tableLen = c->tableLen;
     fp.maxRows = c->cfg.maxRows; fp.maxColumns = c->cfg.maxColumns;
@@ -427,6 +467,7 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
 }
 
 void bbmsa_use_narrow(bbmsa_ctx *c, bool on) { if (c) c->narrowOff = !on; }
+void bbmsa_sort_by_width(bbmsa_ctx *c, bool on) { if (c) c->sortByWidth = on; }
 int bbmsa_wait_first_pass(bbmsa_ctx *c, void *waiter) {
     if (!c || !c->timed) return BBMAP_OK;
     HIP_TRY(hipStreamWaitEvent((hipStream_t)waiter, c->ev[3], 0));       // recorded right in front of the last launch's first pass
