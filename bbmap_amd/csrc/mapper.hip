@@ -35,6 +35,7 @@ void bbmap_set_error(const char *msg);
 void bbmsa_use_narrow(bbmsa_ctx *c, bool on);          // msa_host.hip (internal, see msa_ctx.h)
 int bbmsa_wait_first_pass(bbmsa_ctx *c, void *waiter);
 void bbmsa_sort_by_width(bbmsa_ctx *c, bool on);
+int bbmsa_set_latency_jobs(bbmsa_ctx *c, int64_t n);
 
 namespace bbmapper {
 
@@ -1228,6 +1229,13 @@ static int create_impl(bbidx_ctx *index, const bbmap_config *cfg, bbmap_ctx *par
     }
     const long long n = cfg->max_reads;
     const int cap = cfg->max_sites;
+    if (!pacbio) {
+        // launches of a few hundred fills (the late rounds of scoreSlow and of the final stage) are one wavefront's latency: they take
+        // the 64-lane geometry, whose step is the shorter chain (msa_ctx.h; 236 -> 231 ms per step for the second context alone)
+        const long long lat = getenv("BBMAP_LATENCY_JOBS") ? atoll(getenv("BBMAP_LATENCY_JOBS")) : 4096;
+        if ((rc = bbmsa_set_latency_jobs(c->msa, lat)) != BBMAP_OK) return bail(rc);
+        if (c->msaGapped != c->msa && (rc = bbmsa_set_latency_jobs(c->msaGapped, lat)) != BBMAP_OK) return bail(rc);
+    }
     // starting capacities of the two fill logs; they grow when a batch needs more (grow_logs)
     const int jpr = cfg->jobsPerRead > 0 ? cfg->jobsPerRead : 3;
     c->jobCap = n * jpr + 1024;

@@ -34,6 +34,7 @@ struct bbmsa_ctx {
     // 200-column one idles half the wave for 400 steps; in width order neighbours are alike, and the longest jobs do not end up last
     bool sortByWidth;
     unsigned int *d_widthHist;
+    long long latencyJobs;             // launches with at most this many jobs go straight to the 64-lane geometry (bbmsa_set_latency_jobs)
     unsigned long long *d_narrowDir;
     int *d_fastList;
     long long fastCap;
@@ -71,6 +72,11 @@ int bbmsa_wait_first_pass(bbmsa_ctx *c, void *waiter);
 // front of the first pass); results are indexed by job as always.  The mapper asks for it on its second context, whose windows
 // span 170..640+ columns.
 void bbmsa_sort_by_width(bbmsa_ctx *c, bool on);
+// Launches of at most n jobs skip the first pass and run in the wide pass's geometry (64 lanes x ceil(rows / 64) rows per lane, one job
+// per block): with few jobs a launch costs one wavefront's dependent chain, and three rows per lane make a step ~450 instructions
+// instead of ~740.  Measured on the mapper's late rounds (a few hundred fills each): 236.0 -> 230.9 ms per step for the second
+// context alone.  0 = off (the default of a context).
+int bbmsa_set_latency_jobs(bbmsa_ctx *c, int64_t n);
 
 // msa_legacy.hip: persistent buffers, stream and the call combiner of a BBMSA_LEGACY_ONLY context (c->d_matrix / d_limits exist)
 int bbmsa_legacy_create(bbmsa_ctx *c);

@@ -83,6 +83,31 @@ static int env_int(const char *name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// The wavefront kernel's second geometry: 64 lanes per job, one job per 64-thread block, an LDS column buffer as wide as maxColumns.
+// It takes the windows wider than the first pass's buffer (the wide pass) and, at the caller's request, whole launches that hold
+// too few jobs to be anything but a wavefront's latency (bbmsa_set_latency_jobs).
+static int setup_wide_pass(bbmsa_ctx *c) {
+    if (c->wideBlocks > 0) return BBMAP_OK;
+    c->wideR = (c->cfg.maxRows + 63) / 64;
+    c->wideCols = c->cfg.maxColumns;
+    c->wideTmpBytes = ((64 * c->wideR + c->wideCols + 8) + 3) & ~3;
+    const int perJob = (c->wideCols + 2) * 2 + c->wideTmpBytes / 4;
+    c->wideLdsBytes = (bbmsa::lds_table_ints(c->wideTableLen) + perJob) * 4;
+    const void *wfn = bbmsa::fast_kernel_for(c->wideR, c->banded);
+    if (wfn && c->wideLdsBytes <= 160 * 1024) {
+        if (c->wideLdsBytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(wfn, hipFuncAttributeMaxDynamicSharedMemorySize, c->wideLdsBytes));
+        int per = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, wfn, 64, c->wideLdsBytes));
+        if (per < 1) per = 1;
+        if (per > 8) per = 8;
+        const long long slotDwords = (long long)(((c->wideCols + 64 - 1) >> 3) + 1) * c->wideR * 64;
+        HIP_TRY(hipMalloc(&c->d_wideDir, (size_t)((long long)c->numCUs * per * slotDwords * 4)));
+        c->wideDirSlotDwords = slotDwords;
+        c->wideBlocks = c->numCUs * per;
+    }
+    return BBMAP_OK;
+}
+
 extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     if (!cfg || !out) return fail(BBMAP_E_ARG, "bbmsa_create: null argument");
     *out = nullptr;
@@ -249,25 +274,8 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     HIP_TRY(hipMalloc(&c->d_matrix, (size_t)(threads * perThread)));
     HIP_TRY(hipMalloc(&c->d_limits, (size_t)(threads * (cfg->maxRows + cfg->maxColumns + 4) * 4)));
     // wide pass geometry (only when some windows can exceed the first pass's column buffer)
-    c->wideBlocks = 0;
-    if (cfg->maxColumns > fastCols) {
-        c->wideR = (cfg->maxRows + 63) / 64;
-        c->wideCols = cfg->maxColumns;
-        c->wideTmpBytes = ((64 * c->wideR + c->wideCols + 8) + 3) & ~3;
-        const int perJob = (c->wideCols + 2) * 2 + c->wideTmpBytes / 4;
-        c->wideLdsBytes = (bbmsa::lds_table_ints(c->wideTableLen) + perJob) * 4;
-        const void *wfn = bbmsa::fast_kernel_for(c->wideR, c->banded);
-        if (wfn && c->wideLdsBytes <= 160 * 1024) {
-            if (c->wideLdsBytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(wfn, hipFuncAttributeMaxDynamicSharedMemorySize, c->wideLdsBytes));
-            int per = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, wfn, 64, c->wideLdsBytes));
-            if (per < 1) per = 1;
-            if (per > 8) per = 8;
-            c->wideBlocks = c->numCUs * per;
-            c->wideDirSlotDwords = (long long)(((c->wideCols + 64 - 1) >> 3) + 1) * c->wideR * 64;
-            HIP_TRY(hipMalloc(&c->d_wideDir, (size_t)((long long)c->wideBlocks * c->wideDirSlotDwords * 4)));
-        }
-    }
+    c->wideBlocks = 0; c->latencyJobs = 0;
+    if (cfg->maxColumns > fastCols) { const int rc = setup_wide_pass(c); if (rc != BBMAP_OK) return rc; }
     // narrow-window kernel: only without a band (a band changes the window rule); BBMSA_NARROW=0 disables it
     c->narrowBlocks = 0; c->narrowOff = false; c->narrowUsed = false;
     c->sortByWidth = false; c->d_widthHist = nullptr;
@@ -387,7 +395,7 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
         if (c->wideBlocks > 0) HIP_TRY(hipMalloc(&c->d_slowList2, (size_t)n_jobs * 4));
         c->slowCap = n_jobs;
     }
-    const bool sortJobs = c->sortByWidth && !n_jobs_dev && n_jobs >= 256 && !(c->narrowBlocks > 0 && !c->narrowOff);
+    const bool sortJobs = c->sortByWidth && !n_jobs_dev && n_jobs >= 256 && n_jobs > c->latencyJobs && !(c->narrowBlocks > 0 && !c->narrowOff);
     if ((c->narrowBlocks > 0 || sortJobs) && n_jobs > c->fastCap) {
         if (c->d_fastList) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(c->d_fastList)); c->d_fastList = nullptr; }
         HIP_TRY(hipMalloc(&c->d_fastList, (size_t)n_jobs * 4));
@@ -432,11 +440,16 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
     fp.maxRows = c->cfg.maxRows; fp.maxColumns = c->cfg.maxColumns;
     fp.bandwidth = c->cfg.bandwidth; fp.bandwidthRatio = c->cfg.bandwidthRatio;
 
+    // A launch with few jobs is a wavefront's latency, not throughput: (columns + lanes - 1) steps of one dependent chain.  The wide
+    // pass's geometry (64 lanes x 3 rows, one job per block) has the shorter chain per step (3 rows instead of 5: ~450 instead of
+    // ~740 instructions), so such launches go to it directly (bbmsa_set_latency_jobs; the mapper's late rounds hold a few hundred fills).
+    const bool latency = c->wideBlocks > 0 && !n_jobs_dev && !useNarrow && n_jobs <= c->latencyJobs;
     const int jobsPerBlock = 4 * (64 / c->G);
     long long blocks = (n_jobs + jobsPerBlock - 1) / jobsPerBlock;
     if (blocks > c->blocks) blocks = c->blocks;
     void *args[] = {&fp};
-    HIP_TRY(hipLaunchKernel(bbmsa::fast_kernel_for(c->R, c->banded), dim3((unsigned)blocks), dim3(256), args, (size_t)c->ldsBytes, stream));
+    if (!latency)
+        HIP_TRY(hipLaunchKernel(bbmsa::fast_kernel_for(c->R, c->banded), dim3((unsigned)blocks), dim3(256), args, (size_t)c->ldsBytes, stream));
     const int *genList = c->d_slowList;
     const unsigned int *genCount = c->d_counters + 1;
     if (c->wideBlocks > 0) {
@@ -445,10 +458,12 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
         bbmsa::FillParams wp = fp;
         wp.queue = c->d_counters + 8; wp.dirbuf = c->d_wideDir; wp.dir_slot_dwords = c->wideDirSlotDwords;
         wp.list = c->d_slowList; wp.list_count = c->d_counters + 1;
+        if (latency) { wp.list = nullptr; wp.list_count = nullptr; }          // every job of the launch
         wp.slow_list = c->d_slowList2; wp.slow_count = c->d_counters + 7;
         wp.lanesPerJob = 64; wp.fastCols = c->wideCols; wp.tmpBytes = c->wideTmpBytes; wp.tableLen = c->wideTableLen;
         void *wargs[] = {&wp};
-        HIP_TRY(hipLaunchKernel(bbmsa::fast_kernel_for(c->wideR, c->banded), dim3((unsigned)c->wideBlocks), dim3(64), wargs, (size_t)c->wideLdsBytes, stream));
+        const long long wblocks = latency && n_jobs < c->wideBlocks ? n_jobs : c->wideBlocks;
+        HIP_TRY(hipLaunchKernel(bbmsa::fast_kernel_for(c->wideR, c->banded), dim3((unsigned)wblocks), dim3(64), wargs, (size_t)c->wideLdsBytes, stream));
         genList = c->d_slowList2; genCount = c->d_counters + 7;
     }
     HIP_TRY(hipEventRecord(c->ev[1], stream));
@@ -468,6 +483,14 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
 
 void bbmsa_use_narrow(bbmsa_ctx *c, bool on) { if (c) c->narrowOff = !on; }
 void bbmsa_sort_by_width(bbmsa_ctx *c, bool on) { if (c) c->sortByWidth = on; }
+int bbmsa_set_latency_jobs(bbmsa_ctx *c, int64_t n) {
+    if (!c || c->scheme != BBMSA_SCHEME_11TS || c->legacyOnly) return BBMAP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (n > 0) { const int rc = setup_wide_pass(c); if (rc != BBMAP_OK) return rc; }
+    if (n > 0 && c->slowCap > 0 && !c->d_slowList2) HIP_TRY(hipMalloc(&c->d_slowList2, (size_t)c->slowCap * 4));   // (its hand-over list)
+    c->latencyJobs = c->wideBlocks > 0 ? n : 0;
+    return BBMAP_OK;
+}
 int bbmsa_wait_first_pass(bbmsa_ctx *c, void *waiter) {
     if (!c || !c->timed) return BBMAP_OK;
     HIP_TRY(hipStreamWaitEvent((hipStream_t)waiter, c->ev[3], 0));       // recorded right in front of the last launch's first pass
