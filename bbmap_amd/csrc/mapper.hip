@@ -598,7 +598,7 @@ __global__ __launch_bounds__(128) void score_kernel(const Dev D) {
     Site *s = D.ms + r * D.cap;
     int near = 0; bool force = false;
     for (int j = 0; j < n; j++) {
-        Site ss = s[j];
+        Site &ss = s[j];                                   // in place: a site is 128 bytes, the loop touches a dozen of its fields
         const int oldScore = ss.score;
         const uint8_t *bases = D.bases + rr.bases_off + (ss.strand ? D.minusDelta : 0);
         if (ss.perfect) { near++; set_slow_score(ss, maxSw); ss.score = maxSw; ss.ngaps = 0; }
@@ -617,7 +617,6 @@ __global__ __launch_bounds__(128) void score_kernel(const Dev D) {
                 else set_perfect(ss, bases, len, ref, reflen);
             } else if (oldScore >= maxImp) force = true;
         }
-        s[j] = ss;
     }
     const int numNear = force ? -near : near;
     sort_sites<false>(s, n);

@@ -332,15 +332,25 @@ __device__ int score_no_indels_match(const Settings &S, const uint8_t *read, int
     int score = 0, mode = -1, t = 0;
     unsigned *mw = reinterpret_cast<unsigned *>(match);              // (pool strings start on a 4-byte boundary: four symbols per store)
     unsigned acc = 0;
-    for (int i = 0; i < len; i++) {
-        const int c = read[i], r = ref[refStart + i];
-        unsigned sym;
-        if (c == r && c != 'N') { if (mode == 0) { t++; score += S.ptsMatch2; } else { t = 0; score += S.ptsMatch; } sym = 'm'; mode = 0; }
-        else if (c >= 128 || c == 'N') sym = 'N';
-        else if (r >= 128 || r == 'N') sym = 'N';
-        else { sym = 'S'; if (mode == 1) t++; else t = 0; score += (t + 1 > 5 ? S.ptsSub3 : (t + 1 > 1 ? S.ptsSub2 : S.ptsSub)); mode = 1; }
-        acc |= sym << (8 * (i & 3));
-        if ((i & 3) == 3) { mw[i >> 2] = acc; acc = 0; }
+    Words A, B;                                                      // (aligned word loads of the read and the reference, as scoreNoIndels)
+    A.init(read, len); B.init(ref + refStart, len);
+    for (int i0 = 0; i0 < len; i0 += 4) {
+        const unsigned c4 = A.next(), r4 = B.next();
+        acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = i0 + q;
+            if (i < len) {
+                const int c = (int)((c4 >> (8 * q)) & 255u), r = (int)((r4 >> (8 * q)) & 255u);
+                unsigned sym;
+                if (c == r && c != 'N') { if (mode == 0) { t++; score += S.ptsMatch2; } else { t = 0; score += S.ptsMatch; } sym = 'm'; mode = 0; }
+                else if (c >= 128 || c == 'N') sym = 'N';
+                else if (r >= 128 || r == 'N') sym = 'N';
+                else { sym = 'S'; if (mode == 1) t++; else t = 0; score += (t + 1 > 5 ? S.ptsSub3 : (t + 1 > 1 ? S.ptsSub2 : S.ptsSub)); mode = 1; }
+                acc |= sym << (8 * q);
+            }
+        }
+        if (i0 + 4 <= len) mw[i0 >> 2] = acc;
     }
     for (int i = len & ~3; i < len; i++) match[i] = (uint8_t)(acc >> (8 * (i & 3)));
     return score;
