@@ -730,8 +730,12 @@ __device__ bool final_advance(const Dev &D, long long r, FinalRead &f, PreAlloc 
                     }
                 }
                 uint8_t *m = pool_ptr(D, ref);
-                if (gsyms == 0) for (int q = 0; q < clen; q++) m[q] = src[q];
-                else {
+                if (gsyms == 0) {                                               // (log slots and pool strings both start on 4-byte boundaries)
+                    const unsigned *sw = reinterpret_cast<const unsigned *>(src);
+                    unsigned *dw = reinterpret_cast<unsigned *>(m);
+                    for (int q = 0; q < (clen >> 2); q++) dw[q] = sw[q];
+                    for (int q = clen & ~3; q < clen; q++) m[q] = src[q];
+                } else {
                     int o = 0;
                     for (int q = 0; q < clen; q++) { const uint8_t ch = src[q]; if (ch != '-') m[o++] = ch; else for (int g = 0; g < GAPLEN; g++) m[o++] = 'D'; }
                 }
