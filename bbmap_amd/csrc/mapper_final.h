@@ -866,7 +866,13 @@ __device__ int first_request(const Dev &D, long long r, const FinalRead &f) {
     return 0;
 }
 
-__global__ __launch_bounds__(128) void final_round_kernel(const Dev D) {
+// (Left to itself the compiler gives this state machine 248 VGPRs -- site records are 32 registers each -- and ONE wavefront per SIMD,
+// for a kernel that waits on scattered loads.  Asked for 4 blocks per CU it keeps 128 and spills 112 bytes more per lane: the final
+// stage 74.9 -> 72.6 ms; at 6 / 8 blocks (80 / 64 VGPRs) the spills cost more than the waves bring: 77.2 / 77.4.)
+#ifndef FINAL_ROUND_MIN_BLOCKS
+#define FINAL_ROUND_MIN_BLOCKS 4
+#endif
+__global__ __launch_bounds__(128, FINAL_ROUND_MIN_BLOCKS) void final_round_kernel(const Dev D) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long count = D.activeIn ? D.nActiveIn : D.nreads;
     const int lane = threadIdx.x & 63;
