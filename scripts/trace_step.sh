@@ -11,7 +11,7 @@ f = glob.glob("gpurun_out/trace_step/t/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last step starts at the last probe_wave_kernel launch with a large grid
-idx = [i for i, r in enumerate(rows) if "probe_wave_kernel" in r["Kernel_Name"] and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 10_000_000]
+idx = [i for i, r in enumerate(rows) if "probe_wave_kernel" in r["Kernel_Name"] and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 40_000_000]
 start = idx[-1]
 t0 = int(rows[start]["Start_Timestamp"])
 with open("gpurun_out/trace_step/last_step.txt", "w") as out:
