@@ -130,6 +130,8 @@ struct FillParams {
     long long dir_slot_dwords;
     const int *list;              // job indices to process (NULL = all njobs), filled by the narrow kernel or the width sort
     const unsigned int *list_count;
+    int priority;                 // s_setprio for the launch's wavefronts (0..3): the one-job-per-block passes are a dependent chain per job
+                                  // and share their SIMDs with the throughput passes of the other stream
     int *slow_list;               // jobs the fast kernel hands to the generic kernel
     unsigned int *slow_count;
     int match_stride;

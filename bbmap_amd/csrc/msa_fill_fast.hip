@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
     }
     __syncthreads();
 
+    if (p.priority == 3) __builtin_amdgcn_s_setprio(3);
+    else if (p.priority == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p.priority == 1) __builtin_amdgcn_s_setprio(1);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int G = p.lanesPerJob;

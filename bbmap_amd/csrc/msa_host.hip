@@ -434,7 +434,7 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
     fp.jobs = jobs; fp.reads = reads; fp.refs = refs; fp.results = results; fp.match = match;
     fp.njobs = n_jobs; fp.njobs_dev = n_jobs_dev;
     fp.queue = c->d_counters; fp.dirbuf = c->d_dir; fp.dir_slot_dwords = c->dirSlotDwords;
-    fp.list = (useNarrow || sortJobs) ? c->d_fastList : nullptr; fp.list_count = c->d_counters + 4;
+    fp.list = (useNarrow || sortJobs) ? c->d_fastList : nullptr; fp.list_count = c->d_counters + 4; fp.priority = 0;
     fp.slow_list = c->d_slowList; fp.slow_count = c->d_counters + 1;
     fp.match_stride = match_stride; fp.lanesPerJob = c->G; fp.fastCols = c->fastCols; fp.tmpBytes = c->tmpBytes; fp.tableLen = c->tableLen;
     fp.maxRows = c->cfg.maxRows; fp.maxColumns = c->cfg.maxColumns;
@@ -461,6 +461,8 @@ int bbmsa_align_impl(bbmsa_ctx *c, void *stream_, int64_t n_jobs, const uint32_t
         if (latency) { wp.list = nullptr; wp.list_count = nullptr; }          // every job of the launch
         wp.slow_list = c->d_slowList2; wp.slow_count = c->d_counters + 7;
         wp.lanesPerJob = 64; wp.fastCols = c->wideCols; wp.tmpBytes = c->wideTmpBytes; wp.tableLen = c->wideTableLen;
+        static const int widePrio = env_int("BBMSA_WIDE_PRIORITY", 2);
+        wp.priority = widePrio;
         void *wargs[] = {&wp};
         const long long wblocks = latency && n_jobs < c->wideBlocks ? n_jobs : c->wideBlocks;
         HIP_TRY(hipLaunchKernel(bbmsa::fast_kernel_for(c->wideR, c->banded), dim3((unsigned)wblocks), dim3(64), wargs, (size_t)c->wideLdsBytes, stream));

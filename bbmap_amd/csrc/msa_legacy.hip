@@ -163,7 +163,7 @@ int run_batch(bbmsa_ctx *c, Batch &b) {
         fp.jobs = d_jobs; fp.reads = d_bytes; fp.refs = d_bytes; fp.results = b.d_results; fp.match = nullptr;
         fp.njobs = n; fp.njobs_dev = nullptr;
         fp.queue = b.d_counters; fp.dirbuf = S->d_dir; fp.dir_slot_dwords = S->dirSlotDwords;
-        fp.list = nullptr; fp.list_count = nullptr;
+        fp.list = nullptr; fp.list_count = nullptr; fp.priority = 0;
         fp.slow_list = b.d_slow; fp.slow_count = b.d_counters + 1;
         fp.match_stride = 0; fp.lanesPerJob = 64; fp.fastCols = S->cols; fp.tmpBytes = S->tmpBytes; fp.tableLen = S->tableLen;
         fp.maxRows = c->cfg.maxRows; fp.maxColumns = c->cfg.maxColumns;
