@@ -29,6 +29,11 @@ constexpr int kTableLen = 3072;       // upper bound of the delC / insC LDS tabl
 // matrix side + 1 (and is clamped below 2048), the "still needed" indel length never exceeds the rows.  Ints of LDS in front of the per-job areas:
 __host__ __device__ inline int lds_table_ints(int tableLen) { return 2 * tableLen + 320; }   // + delExt[128], insExt[32], subExt[8] (padded to 192), mTab[32][4]
 
+// Ints of LDS one job of the wavefront kernel takes behind the tables: horizLimit + ONE per column (an int), the window's reference
+// bytes (one byte per column; until round 4 an int2 per column held both: 8 bytes, which kept the second DP context's 640-column
+// jobs at two blocks per CU) and the reversed match string.
+__host__ __device__ inline int lds_job_ints(int fastCols, int tmpBytes) { return (fastCols + 2) + ((fastCols + 2 + 3) >> 2) + ((tmpBytes + 3) >> 2); }
+
 // closed forms of calcDelScoreOffset (jni/...c:316-336) and of the cumulative
 // POINTSoff_INS_ARRAY_C table (MultiStateAligner11tsJNI.java:1582-1601)
 __host__ __device__ inline int calc_del_off(int len) {

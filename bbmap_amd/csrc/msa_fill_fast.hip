@@ -110,10 +110,11 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
     const int jobsPerWave = 64 / G;
     const int groupBase = sub * G;           // first wave lane of my job group
 
-    const int perJobLds = (p.fastCols + 2) * 2 + (p.tmpBytes + 3) / 4;   // ints
+    const int perJobLds = lds_job_ints(p.fastCols, p.tmpBytes);
     int *myLds = lds + lds_table_ints(TL) + (wave * jobsPerWave + sub) * perJobLds;
-    int2 *colinfo = reinterpret_cast<int2 *>(myLds);                      // [c] = {horizLimit[c], ref byte of column c}
-    uint8_t *tmp = reinterpret_cast<uint8_t *>(myLds + (p.fastCols + 2) * 2);
+    int *colHl = myLds;                                                   // [c] = horizLimit[c] + 2048
+    uint8_t *colRef = reinterpret_cast<uint8_t *>(myLds + (p.fastCols + 2));     // [c] = reference byte of column c
+    uint8_t *tmp = reinterpret_cast<uint8_t *>(myLds + (p.fastCols + 2) + ((p.fastCols + 2 + 3) >> 2));
 
     const long long slot = ((long long)blockIdx.x * (blockDim.x >> 6) + wave) * jobsPerWave + sub;
     unsigned *dir = p.dirbuf + slot * p.dir_slot_dwords;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
 
         // column info into LDS: reference bytes by the whole group, horizLimit by its first lane
         if (run) {
-            for (int c = gl + 1; c <= columns; c += G) colinfo[c].y = rf[c - 1];
+            for (int c = gl + 1; c <= columns; c += G) colRef[c] = rf[c - 1];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -255,13 +256,13 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
             int h = minScoreOff;
             bool prevDef = false;
             for (int i = columns - 1; i >= 0; i--) {
-                colinfo[i + 1].x = (limited ? h : kNegInf) + 2048;      // horizLimit[i+1] + 2048 (see the fill loop)
-                const int cb = colinfo[i + 1].y;                         // ref[refStartLoc+i]
+                colHl[i + 1] = (limited ? h : kNegInf) + 2048;      // horizLimit[i+1] + 2048 (see the fill loop)
+                const int cb = colRef[i + 1];                         // ref[refStartLoc+i]
                 const bool def = fully_defined(cb);
                 const int cost = def ? (prevDef ? P_MATCH2 : P_MATCH) : ((prevDef && cb == '-') ? P_DEL : 0);
                 h = max(h - cost, floorv);
                 prevDef = def;
-                if (MAT && limited) p.limits[p.limits_off[j] + rows + 1 + i + 1] = colinfo[i + 1].x - 2048;      // horizLimit[i + 1]
+                if (MAT && limited) p.limits[p.limits_off[j] + rows + 1 + i + 1] = colHl[i + 1] - 2048;      // horizLimit[i + 1]
             }
             if (MAT && limited) p.limits[p.limits_off[j] + rows + 1] = h;                                        // horizLimit[0]
         }
@@ -319,8 +320,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
             if (c >= 1 && run) {
             const bool inRange = c <= columns;
             const int cc = min(c, columns);
-            const int2 ci = colinfo[cc];
-            const int hlP = ci.x, ref1 = ci.y;                           // ci.x holds horizLimit + 2048
+            const int hlP = colHl[cc], ref1 = colRef[cc];                // (horizLimit + 2048)
             const int ref0 = c < 2 ? '!' : lastRef;
             const bool gap = ref1 == '-';
             const bool refN = ref1 == 'N';
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                     const int fbPrev = __shfl((int)(nibv & 3u), groupBase + min(fb, G - 1), 64);
                     const int consumed = (fb < G && fbInside) ? fb + 1 : fb;
                     if (wantTrace && gl < consumed) {
-                        const int cb = rd[rr - 1], rb = colinfo[cq].y;
+                        const int cb = rd[rr - 1], rb = colRef[cq];
                         tmp[n + gl] = (cb == rb) ? 'm' : ((!fully_defined(cb) || !fully_defined(rb)) ? 'N' : 'S');
                     }
                     stateTime += fb;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, BBMSA_MIN_WAVES(R)) void msa_fill_fast_kernel(
                     int prev;
                     if (state == 1) {
                         prev = (nibv & 4u) ? 1 : 0;
-                        const int rb = colinfo[col].y;
+                        const int rb = colRef[col];
                         if (wantTrace && gl == 0) tmp[n] = (rb == '-') ? '-' : 'D';
                         if (rb == '-') gapSyms++;
                         col--;

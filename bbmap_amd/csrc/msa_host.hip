@@ -91,7 +91,7 @@ static int setup_wide_pass(bbmsa_ctx *c) {
     c->wideR = (c->cfg.maxRows + 63) / 64;
     c->wideCols = c->cfg.maxColumns;
     c->wideTmpBytes = ((64 * c->wideR + c->wideCols + 8) + 3) & ~3;
-    const int perJob = (c->wideCols + 2) * 2 + c->wideTmpBytes / 4;
+    const int perJob = bbmsa::lds_job_ints(c->wideCols, c->wideTmpBytes);
     c->wideLdsBytes = (bbmsa::lds_table_ints(c->wideTableLen) + perJob) * 4;
     const void *wfn = bbmsa::fast_kernel_for(c->wideR, c->banded);
     if (wfn && c->wideLdsBytes <= 160 * 1024) {
@@ -229,7 +229,7 @@ extern "C" int bbmsa_create(const bbmsa_config *cfg, bbmsa_ctx **out) {
     c->fastCols = fastCols;
     c->tmpBytes = ((G * c->R + fastCols + 8) + 3) & ~3;
     const int jobsPerWave = 64 / G;
-    const int perJobInts = (fastCols + 2) * 2 + c->tmpBytes / 4;
+    const int perJobInts = bbmsa::lds_job_ints(fastCols, c->tmpBytes);
     {   // index = time + needed: time <= min(longer side + 1, 2047 (clamped)), needed <= rows.  The first pass only takes windows of
         // up to fastCols columns, so its tables are sized for those; the wide pass has its own (wideTableLen).
         const int side = (cfg->maxColumns > cfg->maxRows ? cfg->maxColumns : cfg->maxRows) + 2;

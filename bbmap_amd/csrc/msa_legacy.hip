@@ -294,7 +294,7 @@ int bbmsa_legacy_create(bbmsa_ctx *c) {
         S->tableLen = (side < 2048 ? side : 2048) + maxRows + 8;
         if (S->tableLen > bbmsa::kTableLen) S->tableLen = bbmsa::kTableLen;
         S->tableLen = (S->tableLen + 3) & ~3;
-        const int perJob = (S->cols + 2) * 2 + S->tmpBytes / 4;
+        const int perJob = bbmsa::lds_job_ints(S->cols, S->tmpBytes);
         S->ldsBytes = (bbmsa::lds_table_ints(S->tableLen) + perJob) * 4;
         c->banded = !(c->cfg.bandwidth < 1 && c->cfg.bandwidthRatio <= 0.0f);
         const void *kfn = bbmsa::fast_kernel_mat_for(S->R, c->banded);
