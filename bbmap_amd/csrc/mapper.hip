@@ -1450,12 +1450,11 @@ static int run_final_stage(bbmap_ctx *c, hipStream_t stream, bbmapper::Dev &D, i
                 long long nu = c->poolUnits * 2, need = used + ((long long)c->h_counters[20] - used) * 2 + 65536;
                 if (nu < need) nu = need;
                 if (nu > 0x7ffffff0LL) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: the final stage's match strings exceed 8 GB; map smaller batches");
-                std::vector<void *> dead;
-                MTRY(regrow(c, stream, &c->d_pool, (size_t)used * 4, (size_t)nu * 4, dead));
+                DeadArrays guard(stream);                          // (frees the old pool when this scope is left, also on an error return)
+                MTRY(regrow(c, stream, &c->d_pool, (size_t)used * 4, (size_t)nu * 4, guard.v));
                 c->h_counters[34] = (unsigned)used;
                 MHIP(hipMemcpyAsync(c->d_counters + 20, c->h_counters + 34, 4, hipMemcpyHostToDevice, stream));
                 MHIP(hipStreamSynchronize(stream));
-                for (void *q : dead) (void)hipFree(q);
                 c->poolUnits = nu; D.pool = c->d_pool; D.poolUnits = nu;
             }
             nActive = c->h_counters[2];
@@ -1472,10 +1471,9 @@ static int run_final_stage(bbmap_ctx *c, hipStream_t stream, bbmapper::Dev &D, i
         if ((long long)c->h_counters[20] + (long long)c->h_counters[25] + 64 > c->poolUnits) {      // room for toLocalAlignment's strings
             const long long nu = (long long)c->h_counters[20] + (long long)c->h_counters[25] + 65536;
             if (nu > 0x7ffffff0LL) return mfail(BBMAP_E_NOMEM, "bbmap_map_batch_device: the final stage's match strings exceed 8 GB; map smaller batches");
-            std::vector<void *> dead;
-            MTRY(regrow(c, stream, &c->d_pool, (size_t)c->h_counters[20] * 4, (size_t)nu * 4, dead));
+            DeadArrays guard(stream);
+            MTRY(regrow(c, stream, &c->d_pool, (size_t)c->h_counters[20] * 4, (size_t)nu * 4, guard.v));
             MHIP(hipStreamSynchronize(stream));
-            for (void *q : dead) (void)hipFree(q);
             c->poolUnits = nu; D.pool = c->d_pool; D.poolUnits = nu;
         }
         hipLaunchKernelGGL(bbmapper::final_local_kernel, dim3((unsigned)((units + TB - 1) / TB)), dim3(TB), 0, stream, D);
