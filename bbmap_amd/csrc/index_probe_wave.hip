@@ -109,8 +109,8 @@ struct U {
 
 // one list per lane (the reference's Quad heap entries), compacted: lanes 0..n-1
 #ifndef BBIDX_LIST_BUF
-#define BBIDX_LIST_BUF 4
-#endif
+#define BBIDX_LIST_BUF 2      // look-ahead entries per list in registers (4 until round 4: since the whole-cycle walk takes most cycles, the
+#endif                        // sequential path's buffers are worth less than their registers: 63.2 -> 62.3 ms per 2 M reads; 1 entry: 67.9)
 constexpr int NB = BBIDX_LIST_BUF;
 typedef const int __attribute__((address_space(1))) *GlobalInts;   // global_load instead of flat_load (no LDS counter traffic)
 #ifndef BBIDX_BULK_MIN
