@@ -38,6 +38,16 @@ struct CellOut {
     int mb8;                                 // match as 8 / 0: the next row's / next column's pm8
 };
 
+// (-DBBMSA_LDS_PINS pins every looked-up value to a VGPR at the place it was loaded, asm volatile("" : "+v"(x)).  Rounds 2-3 needed
+// that: the compiler hoisted the table loads of all the rows of a lane to the top of the step and spilled what they displaced.
+// With the cell as one inlined function it no longer does, and each pin is an s_waitcnt lgkmcnt(0) right behind its ds_read -- six
+// exposed LDS round trips per cell: without them 19 instead of 26 spilled VGPRs and the step 224.5 -> 221.5 ms.)
+#ifdef BBMSA_LDS_PINS
+#define BBMSA_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define BBMSA_PIN(x) do { } while (0)
+#endif
+
 // ---- lookup policies
 struct MEntry { int addA, bonus, t3sub; };   // points of staying in the match plane, of entering it from D / I, what its prune test subtracts
 struct NeedPen { bool needDel, needIns; int need; const int *X; int pen0, penDel, penIns; };   // pen0: the match plane's; penDel / penIns: SpelledPen only
@@ -48,7 +58,7 @@ struct LdsPen {
     const int4 *mTab;                        // index = min(streak, 5) | match << 3 | prevMatch << 4
     __device__ __forceinline__ MEntry m_entry(int streakM, int mb8, int pm8, bool, bool) const {
         int4 mt = mTab[min(streakM, 5) | mb8 | (pm8 << 1)];
-        asm volatile("" : "+v"(mt.x));
+        BBMSA_PIN(mt.x);
         MEntry e; e.addA = mt.x; e.bonus = mt.y; e.t3sub = mt.z;
         return e;
     }
@@ -60,16 +70,16 @@ struct LdsPen {
         NeedPen n; n.needDel = delNeeded > 0; n.needIns = insNeeded > 0; n.need = delNeeded + insNeeded;
         n.X = n.needDel ? delC : insC;
         int p0 = n.X[n.need];
-        asm volatile("" : "+v"(p0));
+        BBMSA_PIN(p0);
         n.pen0 = p0; n.penDel = 0; n.penIns = 0;
         return n;
     }
-    __device__ __forceinline__ int del_ext(int streakD) const { int d = delExt[min(streakD, 80 | (streakD & 3))]; asm volatile("" : "+v"(d)); return d; }
-    __device__ __forceinline__ int ins_ext(int streakI) const { int i = insExt[min(streakI, 20)]; asm volatile("" : "+v"(i)); return i; }
+    __device__ __forceinline__ int del_ext(int streakD) const { int d = delExt[min(streakD, 80 | (streakD & 3))]; BBMSA_PIN(d); return d; }
+    __device__ __forceinline__ int ins_ext(int streakI) const { int i = insExt[min(streakI, 20)]; BBMSA_PIN(i); return i; }
     __device__ __forceinline__ void rest(const NeedPen &n, int, int, int timeD, int timeI, int &penD, int &penI) const {
         const int timeX = n.needDel ? timeD : timeI;
         int x2 = n.X[timeX + n.need] - n.X[timeX];                     // 0 when nothing is still needed
-        asm volatile("" : "+v"(x2));
+        BBMSA_PIN(x2);
         penD = n.needIns ? n.pen0 : x2;
         penI = n.needDel ? n.pen0 : x2;
     }
